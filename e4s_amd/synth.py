@@ -1,0 +1,200 @@
+"""Seeded synthetic weights / inputs for the E4S hot path.
+
+The reference ships no checkpoints, so parity, smoke and
+bench all run on synthetic weights.  Every tensor is drawn from its own
+``torch.Generator`` seeded by crc32(key): the values do not depend on module
+construction order, so the reference modules (when generating golden
+fixtures), the CPU oracle and the HIP engine can all be loaded with bit-equal
+weights on any box.
+
+Key names and shapes follow the reference ``Net3.state_dict()``
+(src/models/networks.py:41-82, src/models/stylegan2/model.py:451-571,
+src/models/encoders/psp_encoders.py:238-262) -- SURVEY.md 8(b).
+"""
+import math
+import zlib
+
+import torch
+
+STYLE_DIM = 512
+GEN_CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512, 64: 512, 128: 256, 256: 128, 512: 64, 1024: 32}
+ENC_BLOCKS = ((64, 128, 3), (128, 256, 4), (256, 512, 14), (512, 512, 3))
+
+
+def encoder_units():
+    units = []
+    for cin, depth, n in ENC_BLOCKS:
+        units.append((cin, depth, 2))
+        units += [(depth, depth, 1)] * (n - 1)
+    return units
+
+
+def net3_param_spec(out_size=1024, remaining_layer_idx=13, num_seg_cls=12, n_mlp=8):
+    """[(key, shape, kind)] in reference state_dict order.  kind selects the synthetic
+    distribution: 'randn', 'conv' (randn/sqrt(fan_in)), 'prelu', 'bias', 'modbias',
+    'noisew', 'blur' (fixed FIR buffer), 'noisebuf'."""
+    spec = []
+    # encoder ------------------------------------------------------------
+    spec.append(("encoder.input_layer.0.weight", (64, 3, 3, 3), "conv"))
+    spec.append(("encoder.input_layer.2.weight", (64,), "prelu"))
+    for i, (cin, d, _s) in enumerate(encoder_units()):
+        p = f"encoder.body.{i}."
+        if cin != d:
+            spec.append((p + "shortcut_layer.0.weight", (d, cin, 1, 1), "conv"))
+        spec.append((p + "res_layer.1.weight", (d, cin, 3, 3), "conv"))
+        spec.append((p + "res_layer.2.weight", (d,), "prelu"))
+        spec.append((p + "res_layer.3.weight", (d, d, 3, 3), "conv"))
+        spec.append((p + "res_layer.5.fc1.weight", (d // 16, d, 1, 1), "conv"))
+        spec.append((p + "res_layer.5.fc2.weight", (d, d // 16, 1, 1), "conv"))
+    # LocalMLPs ----------------------------------------------------------
+    nw = remaining_layer_idx if remaining_layer_idx != 17 else 18
+    for i in range(num_seg_cls):
+        p = f"MLPs.{i}.mlp."
+        spec.append((p + "0.weight", (512, 1280), "randn"))
+        spec.append((p + "0.bias", (512,), "bias"))
+        spec.append((p + "2.weight", (512 * nw, 512), "randn"))
+        spec.append((p + "2.bias", (512 * nw,), "bias"))
+    # generator ----------------------------------------------------------
+    for i in range(n_mlp):
+        spec.append((f"G.style.{i + 1}.weight", (512, 512), "randn_lr"))
+        spec.append((f"G.style.{i + 1}.bias", (512,), "bias"))
+    spec.append(("G.input.input", (1, 512, 4, 4), "randn"))
+
+    def styled(p, cin, cout, up):
+        out = [(p + "conv.weight", (1, cout, cin, 3, 3), "randn")]
+        if up:
+            out.append((p + "conv.blur.kernel", (4, 4), "blur"))
+        out += [(p + "conv.modulation.weight", (cin, 512), "randn"),
+                (p + "conv.modulation.bias", (cin,), "modbias"),
+                (p + "noise.weight", (1,), "noisew"),
+                (p + "activate.bias", (cout,), "bias")]
+        return out
+
+    def torgb(p, cin, up):
+        out = [(p + "bias", (1, 3, 1, 1), "bias")]
+        if up:
+            out.append((p + "upsample.kernel", (4, 4), "blur"))
+        out += [(p + "conv.weight", (1, 3, cin, 1, 1), "randn"),
+                (p + "conv.modulation.weight", (cin, 512), "randn"),
+                (p + "conv.modulation.bias", (cin,), "modbias")]
+        return out
+
+    spec += styled("G.conv1.", 512, 512, False)
+    spec += torgb("G.to_rgb1.", 512, False)
+    log_size = int(math.log2(out_size))
+    convs, rgbs = [], []
+    cin = 512
+    for j, rl in enumerate(range(3, log_size + 1)):
+        cout = GEN_CHANNELS[2 ** rl]
+        convs += styled(f"G.convs.{2 * j}.", cin, cout, True)
+        convs += styled(f"G.convs.{2 * j + 1}.", cout, cout, False)
+        rgbs += torgb(f"G.to_rgbs.{j}.", cout, True)
+        cin = cout
+    spec += convs + rgbs
+    for l in range((log_size - 2) * 2 + 1):
+        r = 2 ** ((l + 5) // 2)
+        spec.append((f"G.noises.noise_{l}", (1, 1, r, r), "noisebuf"))
+    return spec
+
+
+def _gen(key, seed):
+    g = torch.Generator()
+    g.manual_seed((zlib.crc32(key.encode()) + 7919 * seed) & 0x7FFFFFFF)
+    return g
+
+
+def synth_tensor(key, shape, kind, seed=0):
+    g = _gen(key, seed)
+    if kind == "blur":
+        k = torch.tensor([1.0, 3.0, 3.0, 1.0])
+        k = k[None, :] * k[:, None]
+        return k / k.sum() * 4.0
+    x = torch.randn(shape, generator=g, dtype=torch.float32)
+    if kind in ("randn", "noisebuf"):
+        return x
+    if kind == "randn_lr":                      # EqualLinear(lr_mul=0.01): randn / lr_mul
+        return x / 0.01
+    if kind == "conv":
+        fan_in = shape[1] * shape[2] * shape[3]
+        return x / math.sqrt(fan_in)
+    if kind == "prelu":
+        return 0.25 + 0.05 * x
+    if kind == "bias":
+        return 0.1 * x
+    if kind == "modbias":                       # reference bias_init=1
+        return 1.0 + 0.1 * x
+    if kind == "noisew":
+        return 0.1 + 0.02 * x
+    raise ValueError(kind)
+
+
+def synth_state_dict(out_size=1024, remaining_layer_idx=13, num_seg_cls=12, seed=0):
+    return {k: synth_tensor(k, s, kind, seed)
+            for k, s, kind in net3_param_spec(out_size, remaining_layer_idx, num_seg_cls)}
+
+
+def synth_latent_avg(out_size=1024, seed=0):
+    n_latent = int(math.log2(out_size)) * 2 - 2
+    return 0.1 * torch.randn(n_latent, 512, generator=_gen("latent_avg", seed))
+
+
+def synth_noise(out_size=1024, seed=0, batch=1):
+    """17 noise maps [batch,1,2^r,2^r] (model.py:512-516)."""
+    log_size = int(math.log2(out_size))
+    out = []
+    for l in range((log_size - 2) * 2 + 1):
+        r = 2 ** ((l + 5) // 2)
+        out.append(torch.randn(batch, 1, r, r, generator=_gen(f"noise{l}", seed)))
+    return out
+
+
+def synth_image(batch=1, size=1024, seed=0, tag="img"):
+    return torch.randn(batch, 3, size, size, generator=_gen(tag, seed)).clamp_(-1, 1)
+
+
+def onehot(labels, num_cls=12):
+    """labelMap2OneHot (src/utils/torch_utils.py:166-172). labels [B,1,H,W] int64."""
+    b, _, h, w = labels.shape
+    out = torch.zeros(b, num_cls, h, w, device=labels.device)
+    return out.scatter_(1, labels, 1.0)
+
+
+def synth_labels_blocks(batch=1, size=512, cells=64, num_cls=12, seed=0, tag="blk"):
+    """Pessimistic mask: random label per (size/cells)^2 block -- every region populated,
+    boundaries everywhere (SURVEY.md 8(d) synthetic mask (ii))."""
+    lab = torch.randint(0, num_cls, (batch, 1, cells, cells), generator=_gen(tag, seed))
+    rep = size // cells
+    return lab.repeat_interleave(rep, 2).repeat_interleave(rep, 3)
+
+
+def synth_labels_face(batch=1, size=512, num_cls=12, seed=0, tag="face"):
+    """Face-like label map built from ellipses: background 0, hair, skin, brows, eyes,
+    nose, mouth, neck, ears ... -- large smooth regions with a few small ones, the
+    realistic case for region-select.  Deterministic per (seed, sample)."""
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, size), torch.linspace(-1, 1, size), indexing="ij")
+    out = torch.zeros(batch, 1, size, size, dtype=torch.int64)
+    for b in range(batch):
+        g = _gen(f"{tag}{b}", seed)
+        j = (torch.rand(8, generator=g) - 0.5) * 0.08
+        lab = torch.zeros(size, size, dtype=torch.int64)
+
+        def ell(cx, cy, rx, ry):
+            return ((xs - cx) / rx) ** 2 + ((ys - cy) / ry) ** 2 <= 1.0
+
+        cx, cy = float(j[0]), float(j[1])
+        lab[ell(cx, cy - 0.15, 0.62, 0.75)] = 4                 # hair
+        lab[ell(cx, cy + 0.95, 0.30, 0.45)] = 8                 # neck
+        lab[ell(cx - 0.52, cy + 0.05, 0.08, 0.16)] = 7          # ears
+        lab[ell(cx + 0.52, cy + 0.05, 0.08, 0.16)] = 7
+        lab[ell(cx, cy + 0.08, 0.48, 0.62)] = 1                 # skin
+        lab[ell(cx - 0.2, cy - 0.18, 0.13, 0.035)] = 2          # brows
+        lab[ell(cx + 0.2, cy - 0.18, 0.13, 0.035)] = 2
+        lab[ell(cx - 0.2, cy - 0.06, 0.10, 0.05)] = 3           # eyes
+        lab[ell(cx + 0.2, cy - 0.06, 0.10, 0.05)] = 3
+        lab[ell(cx, cy + 0.12 + float(j[2]), 0.09, 0.17)] = 5   # nose
+        lab[ell(cx, cy + 0.40, 0.20, 0.085)] = 6                # mouth / lips
+        lab[ell(cx, cy + 0.40, 0.12, 0.03)] = 9                 # teeth
+        if num_cls > 11:
+            lab[ell(cx - 0.55, cy + 0.27, 0.03, 0.05)] = 11     # ear ring
+        out[b, 0] = lab.clamp_(max=num_cls - 1)
+    return out

@@ -1,0 +1,307 @@
+"""CPU oracle for the E4S hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch fp32 *restatement* of the reference algorithm
+(e4s2022/e4s) for the path named in BASELINE.json: the Net3 regional style
+encoder, the 12 LocalMLPs and the mask-guided StyleGAN2 generator.  It is
+written functionally over a ``state_dict`` (no nn.Module tree) and keeps the
+reference's *redundant* formulation on purpose (12 full region passes, blur as
+a separate FIR, materialised modulated weights) so that it is an independent
+check of the fused HIP kernels.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import it.  The product package ``e4s_amd`` never
+does, and has no CPU fallback.
+
+Parity pin: ``tests/golden/*.pt`` were produced by running the REAL reference
+modules (imported from /root/reference with the op shim of SURVEY.md 8(c)) on
+the seeded synthetic weights of ``e4s_amd.synth``; ``tests/test_oracle_golden.py``
+checks this restatement against them.  The script that made them is
+``tests/golden/make_golden.py``.
+
+Each function cites the reference file:line (relative to the reference root)
+it restates.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# L0/L1 operators
+# --------------------------------------------------------------------------
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    """Zero-insert upsample, pad/crop, true 2-D convolution with ``kernel``, decimate.
+
+    Restates src/models/stylegan2/op/upfirdn2d_kernel.cu:52-137 (kernel flipped
+    on load, :77; out size :167-168) as executed by the pure-PyTorch fallback
+    src/pretrained/gpen/face_model/op/upfirdn2d.py:159-193.
+    x: [N,C,H,W]; kernel: [kh,kw]; same pad on both axes (pad0 before, pad1 after).
+    """
+    n, c, h, w = x.shape
+    kh, kw = kernel.shape
+    p0, p1 = pad
+    y = x.reshape(n * c, 1, h, w)
+    if up > 1:
+        z = y.new_zeros(n * c, 1, h * up, w * up)
+        z[:, :, ::up, ::up] = y
+        y = z
+    y = F.pad(y, [max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)])
+    y = y[:, :, max(-p0, 0): y.shape[2] - max(-p1, 0), max(-p0, 0): y.shape[3] - max(-p1, 0)]
+    y = F.conv2d(y, torch.flip(kernel, [0, 1]).reshape(1, 1, kh, kw))
+    y = y[:, :, ::down, ::down]
+    return y.reshape(n, c, y.shape[2], y.shape[3])
+
+
+def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """scale * lrelu(x + b_c).  src/models/stylegan2/op/fused_bias_act_kernel.cu:19-49
+    (act=3, grad=0), fallback form src/pretrained/gpen/face_model/op/fused_act.py:92-96."""
+    shape = (1, -1) + (1,) * (x.ndim - 2)
+    return scale * F.leaky_relu(x + bias.view(shape), negative_slope)
+
+
+def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
+    """The native op itself, all six (act, grad) modes.
+    src/models/stylegan2/op/fused_bias_act_kernel.cu:27-47."""
+    v = x
+    if bias is not None and bias.numel() > 0:
+        shape = (1, -1) + (1,) * (x.ndim - 2)
+        v = v + bias.view(shape)
+    code = act * 10 + grad
+    if code in (12, 32):
+        y = torch.zeros_like(v)
+    elif code == 30:
+        y = torch.where(v > 0, v, v * alpha)
+    elif code == 31:
+        y = torch.where(ref > 0, v, v * alpha)
+    else:  # 10, 11, default
+        y = v
+    return y * scale
+
+
+def make_blur_kernel(k=(1, 3, 3, 1)):
+    """src/models/stylegan2/model.py:22-31."""
+    k = torch.tensor(k, dtype=torch.float32)
+    k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+def equal_linear(x, weight, bias, lr_mul=1.0):
+    """src/models/stylegan2/model.py:135-169 (activation=None branch)."""
+    scale = (1.0 / math.sqrt(weight.shape[1])) * lr_mul
+    return F.linear(x, weight * scale, None if bias is None else bias * lr_mul)
+
+
+# --------------------------------------------------------------------------
+# Generator
+# --------------------------------------------------------------------------
+def modulated_conv2d(x, style, weight, mod_w, mod_b, demodulate=True, upsample=False):
+    """One region pass.  src/models/stylegan2/model.py:276-320 (fused branch).
+    x [B,Cin,H,W]; style [B,512]; weight [1,Cout,Cin,k,k]."""
+    b, cin, h, w = x.shape
+    _, cout, _, k, _ = weight.shape
+    s = equal_linear(style, mod_w, mod_b).view(b, 1, cin, 1, 1)        # :276, bias_init=1 :231
+    wgt = (1.0 / math.sqrt(cin * k * k)) * weight * s                  # :277
+    if demodulate:
+        d = torch.rsqrt(wgt.pow(2).sum([2, 3, 4]) + 1e-8)              # :279-281
+        wgt = wgt * d.view(b, cout, 1, 1, 1)
+    if upsample:
+        wt = wgt.transpose(1, 2).reshape(b * cin, cout, k, k)          # :289-295
+        y = F.conv_transpose2d(x.reshape(1, b * cin, h, w), wt, padding=0, stride=2, groups=b)
+        y = y.view(b, cout, y.shape[2], y.shape[3])
+        y = upfirdn2d(y, make_blur_kernel() * 4.0, pad=(1, 1))         # Blur :206-213,300
+    else:
+        y = F.conv2d(x.reshape(1, b * cin, h, w), wgt.view(b * cout, cin, k, k),
+                     padding=k // 2, groups=b)                         # :312-318
+        y = y.view(b, cout, h, w)
+    return y
+
+
+def _region_compose(conv_fn, style, mask, out_hw):
+    """Mask-guided injection: sum_r conv(x, style[:, r]) * nearest(mask)[:, r].
+    src/models/stylegan2/model.py:386-400 / :426-439."""
+    seg = F.interpolate(mask, size=out_hw, mode="nearest")
+    acc = None
+    for r in range(style.shape[1]):
+        y = conv_fn(style[:, r]) * seg[:, r].unsqueeze(1)
+        acc = y if acc is None else acc + y
+    return acc
+
+
+def styled_conv(sd, pfx, x, style, mask, noise, upsample, masked):
+    """src/models/stylegan2/model.py:382-406."""
+    w, mw, mb = sd[pfx + "conv.weight"], sd[pfx + "conv.modulation.weight"], sd[pfx + "conv.modulation.bias"]
+    fn = lambda st: modulated_conv2d(x, st, w, mw, mb, True, upsample)
+    if masked:
+        h, wd = x.shape[2:]
+        out = _region_compose(fn, style, mask, (h * 2, wd * 2) if upsample else (h, wd))
+    else:
+        out = fn(style)
+    out = out + sd[pfx + "noise.weight"] * noise                       # NoiseInjection :329-335
+    return fused_leaky_relu(out, sd[pfx + "activate.bias"])            # :404
+
+
+def to_rgb(sd, pfx, x, style, mask, skip, masked):
+    """src/models/stylegan2/model.py:422-448."""
+    w, mw, mb = sd[pfx + "conv.weight"], sd[pfx + "conv.modulation.weight"], sd[pfx + "conv.modulation.bias"]
+    fn = lambda st: modulated_conv2d(x, st, w, mw, mb, False, False)
+    out = _region_compose(fn, style, mask, x.shape[2:]) if masked else fn(style)
+    out = out + sd[pfx + "bias"]
+    if skip is not None:
+        out = out + upfirdn2d(skip, make_blur_kernel() * 4.0, up=2, pad=(2, 1))   # Upsample :34-53
+    return out
+
+
+def generator_forward(sd, latent, mask, noise, size, remaining_layer_idx, pfx="G."):
+    """Generator.forward with input_is_latent=True, one 4-D latent.
+    src/models/stylegan2/model.py:576-667.  latent [B,R,n_latent,512]; mask one-hot
+    [B,R,Hm,Wm]; noise: list of (2*log2(size)-3) tensors broadcastable to [B,1,H,W].
+    Returns (image [B,3,size,size], feats at 16x16 after convs[2])."""
+    K = remaining_layer_idx
+    log_size = int(math.log2(size))
+    b = latent.shape[0]
+    x = sd[pfx + "input.input"].repeat(b, 1, 1, 1)
+    x = styled_conv(sd, pfx + "conv1.", x, latent[:, :, 0], mask, noise[0], False, True)   # :529 mask_op=True
+    skip = to_rgb(sd, pfx + "to_rgb1.", x, latent[:, :, 1], mask, None, True)
+    feats = None
+    i = 1
+    for j, res_log in enumerate(range(3, log_size + 1)):
+        conv_masked = not (res_log > 2 + K // 2)                       # :537,545
+        rgb_masked = not (K != 17 and res_log >= 2 + K // 2)           # :553
+        c1, c2, tr = f"{pfx}convs.{2 * j}.", f"{pfx}convs.{2 * j + 1}.", f"{pfx}to_rgbs.{j}."
+        if i < K:                                                      # :639
+            x = styled_conv(sd, c1, x, latent[:, :, i], mask, noise[i], True, conv_masked)
+            if i + 2 == 5:                                             # split_layer_idx=5, networks.py:52
+                feats = x
+            x = styled_conv(sd, c2, x, latent[:, :, i + 1], mask, noise[i + 1], False, conv_masked)
+            if K == 17 or i + 2 != K:
+                skip = to_rgb(sd, tr, x, latent[:, :, i + 2], mask, skip, rgb_masked)
+            else:
+                skip = to_rgb(sd, tr, x, latent[:, 0, i + 2], mask, skip, rgb_masked)    # :650-653
+        else:
+            x = styled_conv(sd, c1, x, latent[:, 0, i], mask, noise[i], True, conv_masked)
+            x = styled_conv(sd, c2, x, latent[:, 0, i + 1], mask, noise[i + 1], False, conv_masked)
+            skip = to_rgb(sd, tr, x, latent[:, 0, i + 2], mask, skip, rgb_masked)
+        i += 2
+    return skip, feats
+
+
+# --------------------------------------------------------------------------
+# Regional style encoder
+# --------------------------------------------------------------------------
+ENC_BLOCKS = ((64, 128, 3), (128, 256, 4), (256, 512, 14), (512, 512, 3))    # psp_encoders.py:242-247
+
+
+def encoder_unit_plan():
+    """(in_channel, depth, stride) of the 24 units. helpers.py:25-26."""
+    units = []
+    for cin, depth, n in ENC_BLOCKS:
+        units.append((cin, depth, 2))
+        units += [(depth, depth, 1)] * (n - 1)
+    return units
+
+
+def _inorm(x):
+    return F.instance_norm(x, eps=1e-5)                                # InstanceNorm2d defaults
+
+
+def encoder_unit(sd, pfx, x, cin, depth, stride):
+    """bottleneck_IR_SE_Ours.  src/models/encoders/helpers.py:122-144, SE :56-72."""
+    if cin == depth:
+        sc = x[:, :, ::stride, ::stride]                               # MaxPool2d(1, stride)
+    else:
+        sc = _inorm(F.conv2d(x, sd[pfx + "shortcut_layer.0.weight"], stride=stride))
+    r = _inorm(x)
+    r = F.conv2d(r, sd[pfx + "res_layer.1.weight"], padding=1)
+    r = F.prelu(r, sd[pfx + "res_layer.2.weight"])
+    r = F.conv2d(r, sd[pfx + "res_layer.3.weight"], stride=stride, padding=1)
+    r = _inorm(r)
+    se = r.mean((2, 3), keepdim=True)
+    se = F.relu(F.conv2d(se, sd[pfx + "res_layer.5.fc1.weight"]))
+    se = torch.sigmoid(F.conv2d(se, sd[pfx + "res_layer.5.fc2.weight"]))
+    return r * se + sc
+
+
+def region_mean(feats, mask):
+    """get_per_comp_styleCode.  src/models/encoders/psp_encoders.py:264-283.
+    Exact zeros for empty regions."""
+    seg = F.interpolate(mask, size=feats.shape[2:], mode="nearest").bool()
+    b, c = feats.shape[:2]
+    out = feats.new_zeros(b, seg.shape[1], c)
+    for i in range(b):
+        for j in range(seg.shape[1]):
+            area = int(seg[i, j].sum())
+            if area > 0:
+                out[i, j] = feats[i].masked_select(seg[i, j]).reshape(c, area).mean(1)
+    return out
+
+
+def encoder_forward(sd, x256, mask, pfx="encoder."):
+    """FSEncoder_PSP.forward.  src/models/encoders/psp_encoders.py:285-309."""
+    x = F.conv2d(x256, sd[pfx + "input_layer.0.weight"], padding=1)
+    x = F.prelu(_inorm(x), sd[pfx + "input_layer.2.weight"])
+    taps = {}
+    for i, (cin, depth, stride) in enumerate(encoder_unit_plan()):
+        x = encoder_unit(sd, f"{pfx}body.{i}.", x, cin, depth, stride)
+        if i in (6, 20, 23):
+            taps[i] = x
+    codes = torch.cat([region_mean(taps[6], mask), region_mean(taps[20], mask),
+                       region_mean(taps[23], mask)], dim=2)
+    return codes, torch.zeros_like(x)
+
+
+# --------------------------------------------------------------------------
+# Net3 API
+# --------------------------------------------------------------------------
+def get_style_vectors(sd, img, mask):
+    """Net3.get_style_vectors.  src/models/networks.py:121-133."""
+    return encoder_forward(sd, F.interpolate(img, (256, 256), mode="bilinear"), mask)
+
+
+def cal_style_codes(sd, style_vectors, latent_avg, remaining_layer_idx):
+    """Net3.cal_style_codes, start_from_latent_avg=True, learn_in_w=False.
+    src/models/networks.py:135-158; LocalMLP :15-39 (nn.LeakyReLU default slope 0.01)."""
+    K = remaining_layer_idx
+    nw = K if K != 17 else 18
+    b, r, _ = style_vectors.shape
+    codes = []
+    for i in range(r):
+        h = equal_linear(style_vectors[:, i], sd[f"MLPs.{i}.mlp.0.weight"], sd[f"MLPs.{i}.mlp.0.bias"])
+        h = F.leaky_relu(h, 0.01)
+        h = equal_linear(h, sd[f"MLPs.{i}.mlp.2.weight"], sd[f"MLPs.{i}.mlp.2.bias"])
+        codes.append(h.view(b, nw, 512))
+    codes = torch.stack(codes, dim=1)
+    if K != 17:
+        codes = codes + latent_avg[:K].view(1, 1, K, 512)
+        rest = latent_avg[K:].view(1, 1, -1, 512).expand(b, r, -1, -1)
+        return torch.cat([codes, rest], dim=2)
+    return codes + latent_avg.view(1, 1, -1, 512)
+
+
+def gen_img(sd, style_codes, mask, noise, size, remaining_layer_idx):
+    """Net3.gen_img.  src/models/networks.py:160-182."""
+    return generator_forward(sd, style_codes, mask, noise, size, remaining_layer_idx)
+
+
+def swap_style_vectors(target_sv, driven_sv, num_cls=12):
+    """swap_comp_style_vector with the face-swap defaults.
+    scripts/face_swap.py:117-146, call site :261-262 (keep 0,4,10,11 from target)."""
+    out = target_sv.clone()
+    for c in sorted(set(range(num_cls)) - {0, 4, 11, 10}):
+        out[:, c] = driven_sv[:, c]
+    if torch.sum(driven_sv[:, 7]) == 0:
+        out[:, 7] = (target_sv[:, 7] + driven_sv[:, 7]) / 2
+    if torch.sum(driven_sv[:, 9]) == 0:
+        out[:, 9] = target_sv[:, 9]
+    return out
+
+
+def face_swap_core(sd, driven, driven_mask, target, target_mask, swapped_mask, latent_avg, noise,
+                   size, remaining_layer_idx):
+    """The E4S-core unit of work: scripts/face_swap.py:237-273."""
+    d_sv, _ = get_style_vectors(sd, driven, driven_mask)
+    t_sv, _ = get_style_vectors(sd, target, target_mask)
+    sv = swap_style_vectors(t_sv, d_sv)
+    codes = cal_style_codes(sd, sv, latent_avg, remaining_layer_idx)
+    img, _ = gen_img(sd, codes, swapped_mask, noise, size, remaining_layer_idx)
+    return img

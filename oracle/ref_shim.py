@@ -1,0 +1,99 @@
+"""Import the REAL reference modules (read-only, from /root/reference) on CPU.
+
+TEST INFRASTRUCTURE ONLY; works only where /root/reference exists (the build
+container), never on the GPU box.  Used by tests/golden/make_golden.py to
+generate fixtures and by tests/test_oracle_vs_reference.py to validate the
+restatement in oracle/e4s_oracle.py.  Nothing from the reference is copied:
+the modules are executed where they lie.
+
+Recipe: SURVEY.md 8(c).  ``src.models.stylegan2.op`` JIT-compiles CUDA at
+import (op/fused_act.py:8-15), so it is pre-seeded in sys.modules with the
+reference's own pure-PyTorch fallbacks from the GPEN copy
+(src/pretrained/gpen/face_model/op/fused_act.py:92-96, upfirdn2d.py:149-193)
+and the pure-Python conv2d_gradfix.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+REF_ROOT = os.environ.get("E4S_REFERENCE_ROOT", "/root/reference")
+
+
+def available():
+    return os.path.isfile(os.path.join(REF_ROOT, "src", "models", "networks.py"))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_CACHE = {}
+
+
+def reference_modules():
+    """Returns a namespace with Net3, Generator, fused_leaky_relu, upfirdn2d (reference code)."""
+    if "ns" in _CACHE:
+        return _CACHE["ns"]
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    # our repo also has a top-level ``src`` shim package; make sure the reference's wins here
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
+    sys.path.insert(0, REF_ROOT)
+    src = os.path.join(REF_ROOT, "src")
+    fa = _load("ref_gpen_fused_act", os.path.join(src, "pretrained/gpen/face_model/op/fused_act.py"))
+    up = _load("ref_gpen_upfirdn2d", os.path.join(src, "pretrained/gpen/face_model/op/upfirdn2d.py"))
+    gf = _load("src.models.stylegan2.op.conv2d_gradfix",
+               os.path.join(src, "models/stylegan2/op/conv2d_gradfix.py"))
+
+    class FusedLeakyReLU(nn.Module):
+        def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
+            super().__init__()
+            self.bias = nn.Parameter(torch.zeros(channel))
+            self.negative_slope, self.scale = negative_slope, scale
+
+        def forward(self, x):
+            return fa.fused_leaky_relu(x, self.bias, self.negative_slope, self.scale, "cpu")
+
+    op = types.ModuleType("src.models.stylegan2.op")
+    op.__path__ = []
+    op.FusedLeakyReLU = FusedLeakyReLU
+    op.fused_leaky_relu = lambda x, b, ns=0.2, sc=2 ** 0.5: fa.fused_leaky_relu(x, b, ns, sc, "cpu")
+    upmod = up
+
+    def ref_upfirdn2d(x, k, up=1, down=1, pad=(0, 0)):
+        return upmod.upfirdn2d(x, k, up, down, pad, "cpu")
+
+    op.upfirdn2d = ref_upfirdn2d
+    op.conv2d_gradfix = gf
+    sys.modules["src.models.stylegan2.op"] = op
+    sys.modules["src.models.stylegan2.op.conv2d_gradfix"] = gf
+    from src.models.networks import Net3                # reference code, unmodified
+    from src.models.stylegan2.model import Generator, ModulatedConv2d, StyledConv, ToRGB
+    ns = types.SimpleNamespace(Net3=Net3, Generator=Generator, ModulatedConv2d=ModulatedConv2d,
+                               StyledConv=StyledConv, ToRGB=ToRGB,
+                               fused_leaky_relu=op.fused_leaky_relu, upfirdn2d=op.upfirdn2d)
+    sys.path.remove(REF_ROOT)
+    _CACHE["ns"] = ns
+    return ns
+
+
+def make_opts(out_size=1024, remaining_layer_idx=13, num_seg_cls=12):
+    return types.SimpleNamespace(fsencoder_type="psp", remaining_layer_idx=remaining_layer_idx,
+                                 num_seg_cls=num_seg_cls, out_size=out_size, train_G=False,
+                                 start_from_latent_avg=True, learn_in_w=False)
+
+
+def build_reference_net3(state_dict, latent_avg, out_size=1024, remaining_layer_idx=13):
+    ns = reference_modules()
+    net = ns.Net3(make_opts(out_size, remaining_layer_idx))
+    net.load_state_dict(state_dict, strict=True)
+    net.latent_avg = latent_avg
+    return net.eval()

@@ -1,0 +1,126 @@
+"""Generate tests/golden/*.pt by running the REAL reference (from /root/reference) on CPU.
+
+Run in the build container only:  python tests/golden/make_golden.py
+The fixtures are small (strided / cropped outputs) and committed; the GPU box
+has no /root/reference and only reads the .pt files.
+
+What is pinned:
+  ops.pt      known-answer vectors for upfirdn2d / fused_leaky_relu
+              + seeded random cases over the (up, down, pad, kernel) modes the path uses
+  net256.pt   Net3(out_size=256, K=13): style vectors, style codes, full 256^2 image, feats16
+              (block-random mask: every region at every tile)
+  net1024.pt  Net3(out_size=1024, K=13): the E4S-core swap (2x encoder, swap, MLPs, generator)
+              on a face-like mask; image stored strided (::8) plus a full-res centre crop
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from e4s_amd import synth  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+
+
+def ops_cases():
+    ns = ref_shim.reference_modules()
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k2 = (k1[None] * k1[:, None]) / 64.0
+    out = {"kat": [], "rand": []}
+
+    def up(x, k, **kw):
+        return ns.upfirdn2d(x, k, **kw)
+
+    a22 = torch.tensor([[1.0, 2.0], [3.0, 4.0]]).view(1, 1, 2, 2)
+    out["kat"].append(dict(op="upfirdn2d", x=a22, k=4 * k2, up=2, down=1, pad=(2, 1), y=up(a22, 4 * k2, up=2, pad=(2, 1))))
+    a33 = torch.arange(1.0, 10.0).view(1, 1, 3, 3)
+    out["kat"].append(dict(op="upfirdn2d", x=a33, k=4 * k2, up=1, down=1, pad=(1, 1), y=up(a33, 4 * k2, pad=(1, 1))))
+    a44 = torch.arange(1.0, 17.0).view(1, 1, 4, 4)
+    out["kat"].append(dict(op="upfirdn2d", x=a44, k=k2, up=1, down=2, pad=(1, 1), y=up(a44, k2, down=2, pad=(1, 1))))
+    out["kat"].append(dict(op="upfirdn2d", x=a22, k=a22[0, 0].clone(), up=1, down=1, pad=(1, 0),
+                           y=up(a22, a22[0, 0].clone(), pad=(1, 0))))
+    xb = torch.tensor([[-1.0, 0.0, 2.0]])
+    bb = torch.tensor([0.5, -0.5, 0.5])
+    out["kat"].append(dict(op="fused_leaky_relu", x=xb, b=bb, y=ns.fused_leaky_relu(xb, bb)))
+
+    g = torch.Generator().manual_seed(1234)
+    modes = [  # (N, C, H, W, kernel, up, down, pad)
+        (2, 3, 9, 9, 4 * k2, 1, 1, (1, 1)),      # Blur after transposed conv (model.py:206-213)
+        (1, 3, 8, 8, 4 * k2, 2, 1, (2, 1)),      # Upsample of the RGB skip (model.py:34-53)
+        (2, 5, 16, 16, k2, 1, 1, (2, 2)),        # D ConvLayer blur k=3 (model.py:683-689)
+        (2, 5, 16, 16, k2, 1, 1, (1, 1)),        # D skip blur k=1
+        (1, 4, 12, 10, k2, 1, 2, (1, 1)),        # Downsample (model.py:56-75)
+        (1, 2, 7, 5, torch.randn(3, 3, generator=g), 1, 1, (1, 1)),   # asymmetric kernel: flip convention
+        (1, 2, 6, 6, torch.randn(2, 2, generator=g), 2, 1, (1, 0)),
+        (1, 2, 10, 10, k2, 1, 1, (-1, -1)),      # negative pad = crop
+        (1, 2, 9, 9, 4 * k2, 2, 2, (2, 1)),
+    ]
+    for n, c, h, w, k, u, d, p in modes:
+        x = torch.randn(n, c, h, w, generator=g)
+        out["rand"].append(dict(op="upfirdn2d", x=x, k=k.clone(), up=u, down=d, pad=p, y=up(x, k, up=u, down=d, pad=p)))
+    for shape in [(2, 7, 5, 3), (3, 16), (1, 4, 8, 8)]:
+        x = torch.randn(*shape, generator=g)
+        b = torch.randn(shape[1], generator=g)
+        out["rand"].append(dict(op="fused_leaky_relu", x=x, b=b, y=ns.fused_leaky_relu(x, b)))
+    return out
+
+
+@torch.no_grad()
+def net_case(out_size, mask_kind):
+    K = 13
+    sd = synth.synth_state_dict(out_size, K)
+    lat = synth.synth_latent_avg(out_size)
+    net = ref_shim.build_reference_net3(sd, lat, out_size, K)
+    driven = synth.synth_image(1, 1024, tag="driven")
+    target = synth.synth_image(1, 1024, tag="target")
+    if mask_kind == "face":
+        dl = synth.synth_labels_face(1, 512, seed=1)
+        tl = synth.synth_labels_face(1, 512, seed=2)
+        sl = synth.synth_labels_face(1, 512, seed=3)
+    else:
+        dl = synth.synth_labels_blocks(1, 512, 64, seed=1)
+        tl = synth.synth_labels_blocks(1, 512, 64, seed=2)
+        sl = synth.synth_labels_blocks(1, 512, 64, seed=3)
+    dm, tm, sm = synth.onehot(dl), synth.onehot(tl), synth.onehot(sl)
+    noise = synth.synth_noise(out_size)
+    d_sv, d_struct = net.get_style_vectors(driven, dm)
+    t_sv, _ = net.get_style_vectors(target, tm)
+    assert float(d_struct.abs().max()) == 0.0 and tuple(d_struct.shape) == (1, 512, 16, 16)
+    # scripts/face_swap.py:117-146,261-262
+    sv = t_sv.clone()
+    for c in sorted(set(range(12)) - {0, 4, 11, 10}):
+        sv[:, c] = d_sv[:, c]
+    if torch.sum(d_sv[:, 7]) == 0:
+        sv[:, 7] = (t_sv[:, 7] + d_sv[:, 7]) / 2
+    if torch.sum(d_sv[:, 9]) == 0:
+        sv[:, 9] = t_sv[:, 9]
+    codes = net.cal_style_codes(sv)
+    img, _minus1, feats = net.gen_img(torch.zeros(1, 512, 32, 32), codes, sm, noise=noise)
+    assert _minus1 == -1
+    rec = dict(out_size=out_size, K=K, mask_kind=mask_kind, driven_sv=d_sv, target_sv=t_sv, swapped_sv=sv,
+               codes_stride=codes[:, :, :, ::8].clone(), codes_absmean=codes.abs().mean(),
+               feats_stride=feats[:, ::4].clone(), img_mean=img.mean((2, 3)), img_absmean=img.abs().mean((2, 3)))
+    if out_size <= 256:
+        rec["img"] = img.clone()
+    else:
+        rec["img_stride8"] = img[:, :, ::8, ::8].clone()
+        c0 = out_size // 2 - 64
+        rec["img_crop"] = img[:, :, c0:c0 + 128, c0:c0 + 128].clone()
+    return rec
+
+
+def main():
+    torch.manual_seed(0)
+    torch.save(ops_cases(), os.path.join(HERE, "ops.pt"))
+    print("ops.pt done")
+    torch.save(net_case(256, "blocks"), os.path.join(HERE, "net256.pt"))
+    print("net256.pt done")
+    torch.save(net_case(1024, "face"), os.path.join(HERE, "net1024.pt"))
+    print("net1024.pt done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""CPU: the oracle restatement (oracle/e4s_oracle.py) against the golden vectors produced by the
+REAL reference (tests/golden/make_golden.py).  This is what pins the oracle."""
+import torch
+
+from e4s_amd import synth
+from oracle import e4s_oracle as orc
+
+
+def test_ops_kat_and_random(golden):
+    g = golden("ops.pt")
+    assert len(g["kat"]) == 5
+    for case in g["kat"] + g["rand"]:
+        if case["op"] == "upfirdn2d":
+            y = orc.upfirdn2d(case["x"], case["k"], up=case["up"], down=case["down"], pad=case["pad"])
+        else:
+            y = orc.fused_leaky_relu(case["x"], case["b"])
+            y2 = orc.fused_bias_act(case["x"], case["b"], None, 3, 0, 0.2, 2 ** 0.5)
+            assert torch.allclose(y, y2, atol=1e-6)
+        assert y.shape == case["y"].shape
+        assert torch.allclose(y, case["y"], atol=1e-5, rtol=1e-5), case["op"]
+
+
+def test_kat_literals(golden):
+    """The five SURVEY.md 8(c) vectors, spelled out (guards the fixture file itself)."""
+    k = golden("ops.pt")["kat"]
+    assert torch.allclose(k[0]["y"].flatten()[:4], torch.tensor([0.5625, 0.9375, 1.3125, 1.125]))
+    assert torch.allclose(k[1]["y"].flatten(), torch.tensor([11.8125, 13.5625, 17.0625, 18.8125]))
+    assert torch.allclose(k[2]["y"].flatten(), torch.tensor([3.5, 4.703125, 8.3125, 9.515625]))
+    assert torch.allclose(k[3]["y"].flatten(), torch.tensor([1.0, 4.0, 6.0, 20.0]))
+    assert torch.allclose(k[4]["y"].flatten(), torch.tensor([-0.141421, -0.141421, 3.535534]), atol=1e-5)
+
+
+@torch.no_grad()
+def _run_oracle_swap(out_size, mask_kind):
+    K = 13
+    sd = synth.synth_state_dict(out_size, K)
+    lat = synth.synth_latent_avg(out_size)
+    driven = synth.synth_image(1, 1024, tag="driven")
+    target = synth.synth_image(1, 1024, tag="target")
+    mk = synth.synth_labels_face if mask_kind == "face" else (lambda b, s, seed: synth.synth_labels_blocks(b, s, 64, seed=seed))
+    dm, tm, sm = (synth.onehot(mk(1, 512, seed=s)) for s in (1, 2, 3))
+    noise = synth.synth_noise(out_size)
+    d_sv, _ = orc.get_style_vectors(sd, driven, dm)
+    t_sv, _ = orc.get_style_vectors(sd, target, tm)
+    sv = orc.swap_style_vectors(t_sv, d_sv)
+    codes = orc.cal_style_codes(sd, sv, lat, K)
+    img, feats = orc.gen_img(sd, codes, sm, noise, out_size, K)
+    return d_sv, t_sv, sv, codes, img, feats
+
+
+def test_net256_swap_matches_reference(golden):
+    g = golden("net256.pt")
+    d_sv, t_sv, sv, codes, img, feats = _run_oracle_swap(256, "blocks")
+    assert torch.allclose(d_sv, g["driven_sv"], atol=2e-5)
+    assert torch.allclose(t_sv, g["target_sv"], atol=2e-5)
+    assert torch.equal(sv == 0, g["swapped_sv"] == 0)          # exact zeros for empty regions
+    assert torch.allclose(codes[:, :, :, ::8], g["codes_stride"], atol=1e-4, rtol=1e-5)
+    assert torch.allclose(feats[:, ::4], g["feats_stride"], atol=1e-4)
+    assert float((img - g["img"]).abs().max()) < 1e-4           # fp32 vs fp32, same ATen kernels
+
+
+def test_net1024_swap_matches_reference(golden):
+    g = golden("net1024.pt")
+    d_sv, t_sv, sv, codes, img, feats = _run_oracle_swap(1024, "face")
+    assert torch.allclose(d_sv, g["driven_sv"], atol=2e-5)
+    assert torch.allclose(sv, g["swapped_sv"], atol=2e-5)
+    assert torch.allclose(codes[:, :, :, ::8], g["codes_stride"], atol=1e-4, rtol=1e-5)
+    assert float((img[:, :, ::8, ::8] - g["img_stride8"]).abs().max()) < 1e-4
+    c0 = 1024 // 2 - 64
+    assert float((img[:, :, c0:c0 + 128, c0:c0 + 128] - g["img_crop"]).abs().max()) < 1e-4
+    assert torch.allclose(img.mean((2, 3)), g["img_mean"], atol=1e-5)
