@@ -1,0 +1,205 @@
+"""bench.py -- 1024^2 face-swap images/s on N MI355X (BASELINE.json metric) + headline-kernel roofline.
+
+A "step" is one pass of the E4S-core hot path (scripts/face_swap.py:237-273) over one
+batch of synthetic swaps resident in HBM: 2 encoder passes, regional style swap, 12 LocalMLPs and the
+mask-guided 1024^2 generator, per swap.  Workload = BASELINE.json configs[3] sharded the way it
+names it (batch 64 over 8 GPUs = 8 swaps per GPU; weak scaling: per-GPU batch fixed) -- at N=1 that
+is 8 swaps on one GPU; the single-swap latency of configs[1] is reported alongside (`latency_b1_ms`).
+For N>1 each rank runs its shard and the ranks all-gather the [B/N,3,1024,1024] outputs over RCCL
+(the only collective on the path); timing is barrier+sync bracketed, max over ranks.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 ... bench.py --gpus 8
+
+Extra legs (rank 0, N=1): `roofline` = the headline kernel ModulatedConv2d(512,512,3)@64x64 (masked,
+region-gathered) timed with HIP events on its launch stream against the fp32-MFMA peak (157.3 TF);
+`cpu_baseline` = the CPU oracle (oracle/e4s_oracle.py, a port of the reference's pure-PyTorch path)
+timed on the host cores for ONE swap of the same workload, which doubles as an end-to-end parity check.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from e4s_amd import kernels as K  # noqa: E402
+from e4s_amd import synth  # noqa: E402
+from e4s_amd.networks import Net3, face_swap_core  # noqa: E402
+from e4s_amd.options import make_opts  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+SIZE, KREM = 1024, 13
+
+
+def build_inputs(batch, dev, seed_base):
+    driven = synth.synth_image(batch, SIZE, seed=seed_base, tag="bench_d").to(dev)
+    target = synth.synth_image(batch, SIZE, seed=seed_base, tag="bench_t").to(dev)
+    dm = synth.onehot(synth.synth_labels_face(batch, 512, seed=seed_base * 3 + 1)).to(dev)
+    tm = synth.onehot(synth.synth_labels_face(batch, 512, seed=seed_base * 3 + 2)).to(dev)
+    sm = synth.onehot(synth.synth_labels_face(batch, 512, seed=seed_base * 3 + 3)).to(dev)
+    noise = [n.to(dev) for n in synth.synth_noise(SIZE, seed=seed_base, batch=batch)]
+    return driven, dm, target, tm, sm, noise
+
+
+def headline_probe(net, batch, mask, reps):
+    """ModulatedConv2d(512,512,3) at 64x64 (G.convs[7], the north-star's '512x512 modulated conv'), one
+    region-select pass over `batch` images = 2*512*512*9*64*64 FLOP per image."""
+    dev = mask.device
+    layer = net.G.convs[7]
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(batch, 64, 64, 512, generator=g).to(dev)
+    lat = (torch.randn(batch, 12, 18, 512, generator=g) * 0.5).to(dev)
+    labels, _ = K.mask_labels(mask)
+    plan = K.region_plan(labels, 12, 64, 64, 1)
+    mod = layer.conv.modulation
+    s = K.modulate(lat, 8, True, mod.weight, mod.bias)
+    pk = layer.conv.packed()
+    d = K.demod_coefs(s, pk["wsq"], layer.conv.scale)
+    nz = torch.randn(batch, 1, 64, 64, generator=g).to(dev)
+
+    def run():
+        return K.conv_mfma(x, pk["w"], 512, plan=plan, in_scale=s, out_scale=d, noise=nz, noise_w=layer.noise.weight,
+                           bias=layer.activate.bias, act=1)
+    for _ in range(3):
+        run()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        run()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    flops = 2.0 * 512 * 512 * 9 * 64 * 64 * batch
+    ach = flops / (ms * 1e-3) / 1e12
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.isfile(tp):
+        try:
+            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "kernel": "conv_mfma_kernel<128,128,2,2,gather> ModulatedConv2d(512,512,3)@64x64 x%d img" % batch,
+            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": traffic, "avg_launch_ms": round(ms, 4), "flop_per_launch": flops}
+
+
+def cpu_baseline(sd, lat, inputs, hip_img0):
+    """One swap (sample 0 of the bench batch) on the host cores with the CPU oracle."""
+    from oracle import e4s_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    driven, dm, target, tm, sm, noise = [t[:1].cpu() if torch.is_tensor(t) else [n[:1].cpu() for n in t] for t in inputs]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        img = orc.face_swap_core(sd, driven, dm, target, tm, sm, lat, noise, SIZE, KREM)
+        dt = time.perf_counter() - t0
+    err = float((img - hip_img0.cpu()).abs().max())
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 swap (2 encoder passes + 12 LocalMLPs + 1024^2 generator, B=1), same seeded inputs as sample 0 "
+                      "of the GPU batch, 1 timed run, torch %d threads" % cores,
+            "seconds": round(dt, 2)}, err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="swaps per GPU per step (configs[3]: 64 over 8 GPUs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-only", action="store_true", help="run only the headline-kernel probe (for rocprofv3)")
+    ap.add_argument("--probe-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+
+    sd = synth.synth_state_dict(SIZE, KREM)
+    lat = synth.synth_latent_avg(SIZE)
+    net = Net3(make_opts(out_size=SIZE))
+    net.load_state_dict(sd, strict=True)
+    net.latent_avg = lat.to(dev)
+    net = net.to(dev).eval()
+    B = args.batch
+    inputs = build_inputs(B, dev, seed_base=100 + rank)
+
+    if args.probe_only:
+        print(json.dumps(headline_probe(net, B, inputs[4], args.probe_reps)))
+        return
+
+    gathered = torch.empty(world * B, 3, SIZE, SIZE, device=dev) if world > 1 else None
+
+    def step():
+        img = face_swap_core(net, *inputs[:5], noise=inputs[5])
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, img)
+        return img
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        img = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * B * args.steps / dt
+
+    out = {"metric": "1024^2 face-swap images/sec", "value": round(value, 3), "unit": "images/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "E4S-core face swap at 1024^2 (2x Net3 encoder @256^2, style swap, 12 LocalMLPs, "
+                                  "mask-guided StyleGAN2 generator K=13), BASELINE.json configs[3] shard: "
+                                  f"{B} swaps per GPU per step", "per_gpu_batch": B, "global_batch": B * world,
+                      "out_size": SIZE, "parallelism": f"image-parallel x{world}" + (", RCCL all_gather of outputs" if world > 1 else "")}}
+    if rank == 0 and world == 1:
+        # configs[1]: single-swap latency
+        one = [t[:1].contiguous() if torch.is_tensor(t) else [n[:1].contiguous() for n in t] for t in inputs]
+        for _ in range(2):
+            img1 = face_swap_core(net, *one[:5], noise=one[5])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            img1 = face_swap_core(net, *one[:5], noise=one[5])
+        torch.cuda.synchronize()
+        out["latency_b1_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+        out["roofline"] = headline_probe(net, B, inputs[4], args.probe_reps)
+        if not args.no_cpu_baseline:
+            cb, err = cpu_baseline(sd, lat, inputs, img1[0:1])
+            out["cpu_baseline"] = cb
+            out["parity_max_abs_vs_oracle"] = err
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,322 @@
+// Regional style encoder support kernels (src/models/encoders/psp_encoders.py:238-309,
+// src/models/encoders/helpers.py:56-72,122-144, src/models/networks.py:15-39,131).
+// The 3x3 / 1x1 convolutions themselves run on e4s_conv_mfma_f32; everything here is HBM- or
+// latency-bound glue on NHWC tensors: resize, the 3->64 stem conv, InstanceNorm statistics and
+// apply(+gate, +residual, +PReLU), the SE gate, regional average pooling and the LocalMLPs.
+#include "common.h"
+
+namespace {
+
+// ---- bilinear resize, align_corners=False, no antialias; NCHW in -> NHWC out -------------------
+__global__ void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int Hi,
+                                       int Wi, int Ho, int Wo) {
+    const int64_t n = (int64_t)B * Ho * Wo * C;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const float sy = (float)Hi / Ho, sx = (float)Wi / Wo;
+    float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = x + ((int64_t)b * C + c) * Hi * Wi;
+    y[i] = hy * (hx * p[(int64_t)y0 * Wi + x0] + lx * p[(int64_t)y0 * Wi + x1]) +
+           ly * (hx * p[(int64_t)y1 * Wi + x0] + lx * p[(int64_t)y1 * Wi + x1]);
+}
+
+// ---- stem conv: 3x3, pad 1, tiny Cin (3) -> Cout; one thread per (pixel, cout) ------------------
+__global__ void conv3x3_small_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                     int B, int H, int W, int Cin, int Cout) {
+    extern __shared__ float sw[];   // [Cout][Cin*9]
+    const int nw = Cout * Cin * 9;
+    for (int t = threadIdx.x; t < nw; t += blockDim.x) sw[t] = w[t];
+    __syncthreads();
+    const int64_t n = (int64_t)B * H * W * Cout;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int co = (int)(i % Cout);
+    int64_t r = i / Cout;
+    const int ox = (int)(r % W); r /= W;
+    const int oy = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox + kx - 1;
+            if (ix < 0 || ix >= W) continue;
+            const float* xp = x + (((int64_t)b * H + iy) * W + ix) * Cin;
+            for (int ci = 0; ci < Cin; ++ci) acc += xp[ci] * sw[(co * Cin + ci) * 9 + ky * 3 + kx];
+        }
+    }
+    y[i] = acc;
+}
+
+// ---- InstanceNorm statistics: single pass, fp64 partial sums (no cancellation in E[x^2]-mean^2),
+// pixels split over blockIdx.z so the 64-channel early layers still fill the chip ----------------
+__global__ void instnorm_partial_kernel(const float* __restrict__ x, double* __restrict__ ws, int HW, int C, int nsplit) {
+    const int slabs = C / 64;
+    const int split = blockIdx.x % nsplit;
+    const int slab = (blockIdx.x / nsplit) % slabs;
+    const int b = blockIdx.x / (nsplit * slabs);
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;       // 4 pixel groups x 64 channels
+    const int c = slab * 64 + cl;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p0 = split * per, p1 = (p0 + per < HW) ? p0 + per : HW;
+    const float* xb = x + (int64_t)b * HW * C + c;
+    double s = 0.0, q = 0.0;
+    for (int p = p0 + pg; p < p1; p += 4) {
+        const double v = (double)xb[(int64_t)p * C];
+        s += v;
+        q += v * v;
+    }
+    __shared__ double red[2][4][64];
+    red[0][pg][cl] = s;
+    red[1][pg][cl] = q;
+    __syncthreads();
+    if (pg == 0) {
+        s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        q = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        atomicAdd(&ws[((int64_t)b * C + c) * 2 + 0], s);
+        atomicAdd(&ws[((int64_t)b * C + c) * 2 + 1], q);
+    }
+}
+
+__global__ void instnorm_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats,
+                                         float* __restrict__ pooled, int n, int HW, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double mean = ws[i * 2] / HW;
+    double var = ws[i * 2 + 1] / HW - mean * mean;      // biased variance (InstanceNorm2d)
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mean;
+    const float rstd = rsqrtf((float)var + eps);
+    stats[i * 2] = mf;
+    stats[i * 2 + 1] = rstd;
+    // AdaptiveAvgPool2d(1) of the normalised tensor: (mean(x) - mean) * rstd, i.e. the rounding
+    // residue of the mean -- what SEModule actually sees after an InstanceNorm (helpers.py:64-66)
+    if (pooled) pooled[i] = (float)((mean - (double)mf) * (double)rstd);
+}
+
+__global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                      const float* __restrict__ gate, const float* __restrict__ res,
+                                      const float* __restrict__ res_stats, const float* __restrict__ slope,
+                                      float* __restrict__ y, int B, int H, int W, int C, int rs) {
+    const int C4 = C / 4;
+    const int64_t n = (int64_t)B * H * W * C4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C4) * 4;
+    int64_t r = i / C4;
+    const int xx = (int)(r % W); r /= W;
+    const int yy = (int)(r % H);
+    const int b = (int)(r / H);
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float* st = stats + ((int64_t)b * C + c + e) * 2;
+        o[e] = (v[e] - st[0]) * st[1];
+        if (gate) o[e] *= gate[(int64_t)b * C + c + e];
+    }
+    if (res) {
+        const int Hr = H * rs, Wr = W * rs;
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(res + (((int64_t)b * Hr + (int64_t)yy * rs) * Wr + (int64_t)xx * rs) * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = rv[e];
+            if (res_stats) {
+                const float* st = res_stats + ((int64_t)b * C + c + e) * 2;
+                t = (t - st[0]) * st[1];
+            }
+            o[e] += t;
+        }
+    }
+    if (slope) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * slope[c + e];
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+}
+
+// ---- SE gate (helpers.py:56-72): fc1 -> relu -> fc2 -> sigmoid on the pooled vector; one block per sample
+__global__ void se_gate_kernel(const float* __restrict__ pooled_in, const float* __restrict__ fc1,
+                               const float* __restrict__ fc2, float* __restrict__ gate, int C, int Cr) {
+    extern __shared__ float sm[];     // pooled[C], hidden[Cr]
+    float* pooled = sm;
+    float* hidden = sm + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) pooled[c] = pooled_in[(int64_t)b * C + c];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    for (int j = wv; j < Cr; j += nwv) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += fc1[(int64_t)j * C + c] * pooled[c];
+        a = wave_sum(a);
+        if (lane == 0) hidden[j] = a > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f;
+        for (int j = 0; j < Cr; ++j) a += fc2[(int64_t)c * Cr + j] * hidden[j];
+        gate[(int64_t)b * C + c] = 1.f / (1.f + __expf(-a));
+    }
+}
+
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+    const float scale = (float)in / (float)out;
+    const int s = (int)floorf((float)dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
+
+// ---- regional average pooling: block = (b, 64-channel slab); each thread owns one channel for a
+// quarter of the pixels and keeps R running sums in LDS columns it alone touches ------------------
+__global__ void region_mean_kernel(const float* __restrict__ feats, const uint8_t* __restrict__ labels, int Hm, int Wm,
+                                   float* __restrict__ out, int H, int W, int C, int R, int out_stride, int out_off) {
+    extern __shared__ float sm[];          // sums[4][R][64], cnt[R] (as float)
+    const int slabs = C / 64;
+    const int b = blockIdx.x / slabs, slab = blockIdx.x % slabs;
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    float* sums = sm;
+    int* cnt = reinterpret_cast<int*>(sm + 4 * R * 64);
+    for (int t = threadIdx.x; t < 4 * R * 64; t += blockDim.x) sums[t] = 0.f;
+    for (int t = threadIdx.x; t < R; t += blockDim.x) cnt[t] = 0;
+    __syncthreads();
+    const int HW = H * W;
+    const float* fb = feats + (int64_t)b * HW * C + slab * 64 + cl;
+    float* mine = sums + (pg * R) * 64 + cl;
+    for (int p = pg; p < HW; p += 4) {
+        const int yy = p / W, xx = p - yy * W;
+        const int lab = labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
+        mine[lab * 64] += fb[(int64_t)p * C];
+        if (cl == 0) atomicAdd(&cnt[lab], 1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < R * 64; t += blockDim.x) {
+        const int r = t / 64, c = t % 64;
+        const float s = sums[(0 * R + r) * 64 + c] + sums[(1 * R + r) * 64 + c] + sums[(2 * R + r) * 64 + c] +
+                        sums[(3 * R + r) * 64 + c];
+        const int n = cnt[r];
+        out[((int64_t)b * R + r) * out_stride + out_off + slab * 64 + c] = n > 0 ? s / (float)n : 0.f;
+    }
+}
+
+// ---- LocalMLP layer: one wave per (r, o) output neuron, all B samples at once; the weight row is
+// streamed once (this op is bound by reading 12 x 16 MB of fp32 weights) ---------------------------
+constexpr int MAXB = 16;
+__global__ void grouped_linear_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                      const float* __restrict__ bias, const float* __restrict__ add,
+                                      float* __restrict__ y, int B, int R, int K, int O, float scale, int act,
+                                      float alpha) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= (int64_t)R * O) return;
+    const int r = (int)(wid / O), o = (int)(wid % O);
+    const float* wrow = Wt + ((int64_t)r * O + o) * K;
+    float acc[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+    for (int i = lane * 4; i < K; i += 256) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + i);
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            if (b < B) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((int64_t)b * R + r) * K + i);
+                acc[b] += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        if (b < B) {
+            float a = wave_sum(acc[b]);
+            if (lane == 0) {
+                a = a * scale + (bias ? bias[(int64_t)r * O + o] : 0.f);
+                if (act == 1) a = a > 0.f ? a : a * alpha;
+                if (add) a += add[o];
+                y[((int64_t)b * R + r) * O + o] = a;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int e4s_resize_bilinear_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream) {
+    const int64_t n = (int64_t)B * Ho * Wo * C;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, y, B, C, Hi, Wi, Ho, Wo);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_conv3x3_small_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout, void* stream) {
+    const int64_t n = (int64_t)B * H * W * Cout;
+    if (n <= 0) return 0;
+    const size_t smem = (size_t)Cout * Cin * 9 * sizeof(float);
+    if (smem > 48 * 1024) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv3x3_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), smem, as_stream(stream), x, w, y, B, H, W, Cin, Cout);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_instnorm_stats_f32(const float* x, float* stats, float* pooled, double* ws, int B, int HW, int C,
+                                      float eps, void* stream) {
+    if (C % 64) return (int)hipErrorInvalidValue;
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)B * C, st);
+    if (e != hipSuccess) return (int)e;
+    int nsplit = 2048 / (B * (C / 64));
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > HW / 64) nsplit = HW / 64 > 0 ? HW / 64 : 1;
+    hipLaunchKernelGGL(instnorm_partial_kernel, dim3(B * (C / 64) * nsplit), dim3(256), 0, st, x, ws, HW, C, nsplit);
+    E4S_CHECK_LAUNCH();
+    const int n = B * C;
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, stats, pooled, n, HW, eps);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_instnorm_apply_f32(const float* x, const float* stats, const float* gate, const float* res,
+                                      const float* res_stats, const float* slope, float* y, int B, int H, int W, int C,
+                                      int rs, void* stream) {
+    if (C % 4 || rs < 1) return (int)hipErrorInvalidValue;
+    const int64_t n = (int64_t)B * H * W * (C / 4);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(instnorm_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, stats, gate, res, res_stats, slope, y, B, H, W, C, rs);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_se_gate_f32(const float* pooled, const float* fc1, const float* fc2, float* gate, int B, int C,
+                               int Cr, void* stream) {
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(512), (size_t)(C + Cr) * sizeof(float), as_stream(stream), pooled, fc1, fc2, gate, C, Cr);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_region_mean_f32(const float* feats, const uint8_t* labels, int Hm, int Wm, float* out, int B, int H,
+                                   int W, int C, int R, int out_stride, int out_off, void* stream) {
+    if (C % 64 || R > 64) return (int)hipErrorInvalidValue;
+    const size_t smem = (size_t)(4 * R * 64) * sizeof(float) + (size_t)R * sizeof(int);
+    hipLaunchKernelGGL(region_mean_kernel, dim3(B * (C / 64)), dim3(256), smem, as_stream(stream), feats, labels, Hm, Wm, out, H, W, C, R, out_stride, out_off);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_grouped_linear_f32(const float* x, const float* W, const float* bias, const float* add, float* y,
+                                      int B, int R, int K, int O, float scale, int act, float alpha, void* stream) {
+    if (B > MAXB || K % 4) return (int)hipErrorInvalidValue;
+    const int64_t nw = (int64_t)R * O;
+    if (nw <= 0 || B <= 0) return 0;
+    hipLaunchKernelGGL(grouped_linear_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, as_stream(stream), x, W, bias, add, y, B, R, K, O, scale, act, alpha);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,134 @@
+"""Regional style encoder FSEncoder_PSP -- MI355X-native.
+
+Module tree / state_dict identical to the reference (src/models/encoders/psp_encoders.py:238-262,
+src/models/encoders/helpers.py:56-72,122-144): `input_layer.{0,2}`, `body.N.res_layer.{1,2,3,5.fc1,5.fc2}`,
+`body.N.shortcut_layer.0`.  Execution is a fixed schedule of HIP kernels on NHWC tensors:
+
+    IN(x) -> conv3x3 -> PReLU          e4s_instnorm_stats/apply + e4s_conv_mfma_f32 (PReLU in the epilogue)
+    conv3x3(stride) -> IN -> SE        e4s_conv_mfma_f32 + stats(+pooled) + e4s_se_gate_f32
+    (+ shortcut) gate * IN(r) + sc     e4s_instnorm_apply_f32 (one fused pass)
+    36 masked_select chains (264-283)  e4s_region_mean_f32 x3 (no host syncs)
+"""
+from collections import namedtuple
+
+import torch
+from torch import nn
+from torch.nn import Conv2d, InstanceNorm2d, MaxPool2d, Module, PReLU, ReLU, Sequential, Sigmoid, AdaptiveAvgPool2d
+
+from . import kernels as K
+
+
+class Bottleneck(namedtuple("Block", ["in_channel", "depth", "stride"])):
+    """helpers.py:21-22"""
+
+
+def get_block(in_channel, depth, num_units, stride=2):
+    return [Bottleneck(in_channel, depth, stride)] + [Bottleneck(depth, depth, 1) for _ in range(num_units - 1)]
+
+
+def _pack3x3(conv):
+    """[Cout,Cin,3,3] -> [1,9,Cout,Cin] (cached on the module, invalidated by in-place updates)."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version)
+    if getattr(conv, "_e4s_pack", None) is None or conv._e4s_pack[0] != key:
+        with torch.no_grad():
+            cout, cin, kh, kw = w.shape
+            conv._e4s_pack = (key, w.detach().float().permute(2, 3, 0, 1).reshape(1, kh * kw, cout, cin).contiguous())
+    return conv._e4s_pack[1]
+
+
+class SEModule(Module):
+    """helpers.py:56-72 (parameter holder; evaluated by e4s_se_gate_f32)."""
+
+    def __init__(self, channels, reduction):
+        super().__init__()
+        self.avg_pool = AdaptiveAvgPool2d(1)
+        self.fc1 = Conv2d(channels, channels // reduction, kernel_size=1, padding=0, bias=False)
+        self.relu = ReLU(inplace=True)
+        self.fc2 = Conv2d(channels // reduction, channels, kernel_size=1, padding=0, bias=False)
+        self.sigmoid = Sigmoid()
+
+
+class bottleneck_IR_SE_Ours(Module):
+    """helpers.py:122-144"""
+
+    def __init__(self, in_channel, depth, stride):
+        super().__init__()
+        self.in_channel, self.depth, self.stride = in_channel, depth, stride
+        if in_channel == depth:
+            self.shortcut_layer = MaxPool2d(1, stride)
+        else:
+            self.shortcut_layer = Sequential(Conv2d(in_channel, depth, (1, 1), stride, bias=False),
+                                             InstanceNorm2d(depth))
+        self.res_layer = Sequential(InstanceNorm2d(in_channel),
+                                    Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False),
+                                    PReLU(depth),
+                                    Conv2d(depth, depth, (3, 3), stride, 1, bias=False),
+                                    InstanceNorm2d(depth),
+                                    SEModule(depth, 16))
+
+    def run_nhwc(self, x):
+        """x NHWC [B,H,W,Cin] -> NHWC [B,H/stride,W/stride,depth]."""
+        conv1, prelu, conv2, se = self.res_layer[1], self.res_layer[2], self.res_layer[3], self.res_layer[5]
+        st_x, _ = K.instnorm_stats(x)
+        xn = K.instnorm_apply(x, st_x)
+        r = K.conv_mfma(xn, _pack3x3(conv1), self.depth, act=2, slope=prelu.weight)
+        r = K.conv_mfma(r, _pack3x3(conv2), self.depth, istride=self.stride)
+        st_r, pooled = K.instnorm_stats(r, want_pooled=True)
+        gate = K.se_gate(pooled, se.fc1.weight.view(se.fc1.weight.shape[0], -1),
+                         se.fc2.weight.view(se.fc2.weight.shape[0], -1))
+        if self.in_channel == self.depth:
+            return K.instnorm_apply(r, st_r, gate=gate, res=x, rs=self.stride)      # MaxPool2d(1, stride)
+        sc = K.conv_mfma(x, _pack3x3(self.shortcut_layer[0]), self.depth, istride=self.stride, ntaps=1)
+        st_sc, _ = K.instnorm_stats(sc)
+        return K.instnorm_apply(r, st_r, gate=gate, res=sc, res_stats=st_sc)
+
+    def forward(self, x):
+        return K.nhwc_to_nchw(self.run_nhwc(K.nchw_to_nhwc(x)))
+
+
+class FSEncoder_PSP(Module):
+    """psp_encoders.py:238-309"""
+
+    def __init__(self, mode="ir_se", opts=None):
+        super().__init__()
+        assert mode in ["ir_se"], "E4S instantiates FSEncoder_PSP(mode='ir_se') only (networks.py:48)"
+        blocks = [get_block(64, 128, 3), get_block(128, 256, 4), get_block(256, 512, 14), get_block(512, 512, 3)]
+        self.n_styles = 11
+        self.input_layer = Sequential(Conv2d(3, 64, (3, 3), 1, 1, bias=False), InstanceNorm2d(64), PReLU(64))
+        modules = []
+        for block in blocks:
+            for bt in block:
+                modules.append(bottleneck_IR_SE_Ours(bt.in_channel, bt.depth, bt.stride))
+        self.body = Sequential(*modules)
+
+    def get_per_comp_styleCode(self, style_feats, segmap):
+        """psp_encoders.py:264-283 (NCHW feats, one-hot segmap) -> [B,R,C]."""
+        labels, _ = K.mask_labels(segmap)
+        feats = K.nchw_to_nhwc(style_feats)
+        b, c = style_feats.shape[:2]
+        out = torch.empty(b, segmap.shape[1], c, device=feats.device, dtype=torch.float32)
+        K.region_mean_into(feats, labels, out, segmap.shape[1], 0)
+        return out
+
+    def encode_nhwc(self, x256, labels, num_regions):
+        """x256: NHWC [B,256,256,3]; labels uint8 [B,Hm,Wm].  Returns codes [B,R,1280]."""
+        x = K.conv3x3_small(x256, self.input_layer[0].weight)
+        st, _ = K.instnorm_stats(x)
+        x = K.instnorm_apply(x, st, slope=self.input_layer[2].weight)
+        b = x.shape[0]
+        codes = torch.empty(b, num_regions, 256 + 512 + 512, device=x.device, dtype=torch.float32)
+        off = {6: 0, 20: 256, 23: 768}
+        for i, unit in enumerate(self.body):
+            x = unit.run_nhwc(x)
+            if i in off:
+                K.region_mean_into(x, labels, codes, num_regions, off[i])
+        return codes, x
+
+    @torch.no_grad()
+    def forward(self, x, segmap):
+        """x NCHW [B,3,256,256], segmap one-hot [B,R,Hm,Wm] -> (codes [B,R,1280], zeros [B,512,16,16])."""
+        labels, _ = K.mask_labels(segmap)
+        codes, last = self.encode_nhwc(K.nchw_to_nhwc(x), labels, segmap.shape[1])
+        b, h, w, c = last.shape
+        return codes, torch.zeros(b, c, h, w, device=x.device, dtype=torch.float32)

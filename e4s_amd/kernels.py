@@ -1,0 +1,288 @@
+"""Tensor-level wrappers over the C-ABI of libe4s_hip.so.
+
+Each function allocates its outputs with torch (device memory + caching allocator are the
+plumbing PyTorch provides) and enqueues one native call on the current HIP stream.  No function
+here computes anything in torch; a missing library or a CPU tensor raises.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import lib
+from .lib import ConvParams, c_p, call, fptr, ptr, stream
+
+BM = 128          # GEMM row tile of e4s_conv_mfma_f32
+LRELU_GAIN = math.sqrt(2.0)
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
+    return t.contiguous()
+
+
+# ---- 1:1 ops ---------------------------------------------------------------------------------
+def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
+    """fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale) -- fused_bias_act.cpp:11-21."""
+    x = _f32(x)
+    y = torch.empty_like(x)
+    has_b = bias is not None and bias.numel() > 0
+    has_r = ref is not None and ref.numel() > 0
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    call("e4s_fused_bias_act_f32", fptr(x), fptr(_f32(bias)) if has_b else None,
+         fptr(_f32(ref)) if has_r else None, fptr(y), x.numel(), step_b, bias.numel() if has_b else 1,
+         int(act), int(grad), float(alpha), float(scale), stream())
+    return y
+
+
+def channel_sum(g):
+    """sum over every dim but 1 (grad_bias, op/fused_act.py:33-38)."""
+    g = _f32(g)
+    c = g.shape[1]
+    step_b = 1
+    for d in g.shape[2:]:
+        step_b *= d
+    out = torch.empty(c, device=g.device, dtype=torch.float32)
+    call("e4s_channel_sum_f32", fptr(g), fptr(out), g.numel(), step_b, c, stream())
+    return out
+
+
+def upfirdn2d_raw(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """upfirdn2d_op.upfirdn2d(input[major,H,W,minor], kernel, ...) -- upfirdn2d.cpp:12-22."""
+    x = _f32(x)
+    kernel = _f32(kernel)
+    major, in_h, in_w, minor = x.shape
+    kh, kw = kernel.shape
+    out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
+    out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
+    y = torch.empty(major, out_h, out_w, minor, device=x.device, dtype=torch.float32)
+    call("e4s_upfirdn2d_f32", fptr(x), fptr(kernel), fptr(y), major, in_h, in_w, minor, kh, kw, up_x, up_y,
+         down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, stream())
+    return y
+
+
+# ---- layout ----------------------------------------------------------------------------------
+def nchw_to_nhwc(x):
+    x = _f32(x)
+    b, c, h, w = x.shape
+    y = torch.empty(b, h, w, c, device=x.device, dtype=torch.float32)
+    call("e4s_nchw_to_nhwc_f32", fptr(x), fptr(y), b, c, h, w, stream())
+    return y
+
+
+def nhwc_to_nchw(x):
+    x = _f32(x)
+    b, h, w, c = x.shape
+    y = torch.empty(b, c, h, w, device=x.device, dtype=torch.float32)
+    call("e4s_nhwc_to_nchw_f32", fptr(x), fptr(y), b, c, h, w, stream())
+    return y
+
+
+def const_input(inp, batch):
+    """ConstantInput.forward (model.py:345-349): [1,C,H,W] parameter -> NHWC [B,H,W,C]."""
+    inp = _f32(inp)
+    _, c, h, w = inp.shape
+    y = torch.empty(batch, h, w, c, device=inp.device, dtype=torch.float32)
+    call("e4s_const_input_f32", fptr(inp), fptr(y), batch, c, h, w, stream())
+    return y
+
+
+# ---- style prologue --------------------------------------------------------------------------
+def modulate(latent, layer_idx, masked, mod_weight, mod_bias):
+    """s = EqualLinear(512 -> Cin, bias_init=1)(style) for every (sample[, region]) group.
+    latent [B,R,L,512] contiguous.  Returns [G, Cin] with G = B*R (masked) or B (region 0)."""
+    b, r, nl, d = latent.shape
+    cin = mod_weight.shape[0]
+    g = b * r if masked else b
+    stride = nl * d if masked else r * nl * d
+    out = torch.empty(g, cin, device=latent.device, dtype=torch.float32)
+    base = c_p(latent.data_ptr() + layer_idx * d * 4)
+    call("e4s_rowdot_f32", base, stride, fptr(mod_weight), fptr(mod_bias), fptr(out), g, cin, d, 0,
+         1.0 / math.sqrt(d), stream())
+    return out
+
+
+def modulate_vec(style, mod_weight, mod_bias):
+    """Same for an explicit [G, 512] style matrix (module-level forward)."""
+    style = _f32(style)
+    g, d = style.shape
+    cin = mod_weight.shape[0]
+    out = torch.empty(g, cin, device=style.device, dtype=torch.float32)
+    call("e4s_rowdot_f32", fptr(style), d, fptr(mod_weight), fptr(mod_bias), fptr(out), g, cin, d, 0,
+         1.0 / math.sqrt(d), stream())
+    return out
+
+
+def demod_coefs(s, wsq, conv_scale):
+    """conv_scale * rsqrt(conv_scale^2 * sum_ci s^2 Wsq[co,ci] + 1e-8): [G, Cout]."""
+    g, cin = s.shape
+    cout = wsq.shape[0]
+    out = torch.empty(g, cout, device=s.device, dtype=torch.float32)
+    call("e4s_rowdot_f32", fptr(s), cin, fptr(wsq), None, fptr(out), g, cout, cin, 1, float(conv_scale), stream())
+    return out
+
+
+def weight_sqsum(w):
+    """w [Cout,Cin,kh,kw] -> [Cout,Cin] sum of squares over taps."""
+    w = _f32(w)
+    cout, cin = w.shape[:2]
+    taps = w.shape[2] * w.shape[3]
+    out = torch.empty(cout, cin, device=w.device, dtype=torch.float32)
+    call("e4s_weight_sqsum_f32", fptr(w), fptr(out), cout, cin, taps, stream())
+    return out
+
+
+def rgb_weights(w, s, scale):
+    """ws[g,c,ci] = scale*w[c,ci]*s[g,ci]; w [3,Cin]."""
+    g, cin = s.shape
+    out = torch.empty(g, 3, cin, device=s.device, dtype=torch.float32)
+    call("e4s_rgb_weights_f32", fptr(w), fptr(s), fptr(out), g, cin, float(scale), stream())
+    return out
+
+
+# ---- mask plan -------------------------------------------------------------------------------
+def mask_labels(mask):
+    """one-hot [B,R,Hm,Wm] fp32 -> (labels uint8 [B,Hm,Wm], flags int32[1]); flags!=0 => not one-hot."""
+    mask = _f32(mask)
+    b, r, hm, wm = mask.shape
+    labels = torch.empty(b, hm, wm, device=mask.device, dtype=torch.uint8)
+    flags = torch.zeros(1, device=mask.device, dtype=torch.int32)
+    call("e4s_mask_labels", fptr(mask), ptr(labels), ptr(flags), b, r, hm, wm, stream())
+    return labels, flags
+
+
+class RowPlan:
+    __slots__ = ("rows", "tiles", "meta", "tiles_cap", "Ha", "Wa", "nphase", "R")
+
+
+def region_plan(labels, num_regions, ha, wa, nphase):
+    b, hm, wm = labels.shape
+    nkeys = b * num_regions * nphase
+    rows_cap = b * ha * wa * nphase + nkeys * BM
+    tiles_cap = (rows_cap + BM - 1) // BM
+    dev = labels.device
+    pl = RowPlan()
+    pl.rows = torch.empty(rows_cap, device=dev, dtype=torch.int32)
+    pl.tiles = torch.empty(tiles_cap * 4, device=dev, dtype=torch.int32)
+    pl.meta = torch.empty(4, device=dev, dtype=torch.int32)
+    work = torch.empty(3 * nkeys, device=dev, dtype=torch.int32)
+    call("e4s_region_plan", ptr(labels), b, num_regions, hm, wm, ha, wa, nphase, BM, ptr(pl.rows), ptr(pl.tiles),
+         ptr(pl.meta), ptr(work), rows_cap, tiles_cap, stream())
+    pl.tiles_cap, pl.Ha, pl.Wa, pl.nphase, pl.R = tiles_cap, ha, wa, nphase, num_regions
+    return pl
+
+
+# ---- the conv --------------------------------------------------------------------------------
+def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, in_scale=None, out_scale=None,
+              noise=None, noise_w=None, noise_per_channel=False, bias=None, slope=None, act=0, alpha=0.2,
+              gain=LRELU_GAIN, spatial=None, anchors=None):
+    """x NHWC [B,Hi,Wi,Cin]; w [ncls, ntaps, Cout, Cin] -> y NHWC [B,Ho,Wo,Cout].
+    anchors = (Ha, Wa); defaults: up-conv (ncls=4) anchors = input grid, output 2x;
+    strided conv anchors = output grid."""
+    b, hi, wi, cin = x.shape
+    if anchors is None:
+        anchors = (hi // istride, wi // istride)
+    ha, wa = anchors
+    ho, wo = ha * ostride, wa * ostride
+    y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32)
+    p = ConvParams()
+    p.x, p.w, p.y = fptr(x), fptr(w), fptr(y)
+    if plan is not None:
+        p.rows, p.tiles, p.meta, p.tiles_cap = ptr(plan.rows), ptr(plan.tiles), ptr(plan.meta), plan.tiles_cap
+        p.groups_per_batch = plan.R
+    else:
+        p.rows = p.tiles = p.meta = None
+        p.tiles_cap = 0
+        p.groups_per_batch = 1
+    p.B, p.Ha, p.Wa = b, ha, wa
+    p.Hi, p.Wi, p.Ho, p.Wo, p.Cin, p.Cout = hi, wi, ho, wo, cin, cout
+    p.istride, p.ostride, p.ntaps, p.ncls = istride, ostride, ntaps, ncls
+    p.in_scale, p.out_scale = fptr(in_scale), fptr(out_scale)
+    if noise is not None:
+        p.noise, p.noise_w = fptr(noise), fptr(noise_w)
+        p.noise_bstride = ho * wo if noise.shape[0] > 1 else 0
+        p.noise_per_channel = 1 if noise_per_channel else 0
+    else:
+        p.noise = p.noise_w = None
+        p.noise_bstride = 0
+        p.noise_per_channel = 0
+    p.bias, p.slope = fptr(bias), fptr(slope)
+    p.act, p.alpha, p.gain = act, alpha, gain
+    if spatial is None:
+        spatial = plan is None and istride == 1 and ntaps == 9 and ha % 8 == 0 and wa % 16 == 0
+    call("e4s_conv_mfma_f32", ctypes.byref(p), 1 if spatial else 0, stream())
+    return y
+
+
+def torgb(x, ws, bias, skip, k4, labels, num_regions):
+    """x NHWC [B,H,W,Cin]; ws [G,3,Cin]; skip NCHW [B,3,H/2,W/2] or None -> NCHW [B,3,H,W]."""
+    b, h, w, cin = x.shape
+    out = torch.empty(b, 3, h, w, device=x.device, dtype=torch.float32)
+    hm = wm = 0
+    if labels is not None:
+        hm, wm = labels.shape[1:]
+    call("e4s_torgb_f32", fptr(x), fptr(ws), fptr(bias), fptr(skip), fptr(k4), ptr(labels), hm, wm, num_regions,
+         fptr(out), b, h, w, cin, stream())
+    return out
+
+
+# ---- encoder ---------------------------------------------------------------------------------
+def resize_bilinear_to_nhwc(x, ho, wo):
+    x = _f32(x)
+    b, c, hi, wi = x.shape
+    y = torch.empty(b, ho, wo, c, device=x.device, dtype=torch.float32)
+    call("e4s_resize_bilinear_f32", fptr(x), fptr(y), b, c, hi, wi, ho, wo, stream())
+    return y
+
+
+def conv3x3_small(x, w):
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    y = torch.empty(b, h, wd, cout, device=x.device, dtype=torch.float32)
+    call("e4s_conv3x3_small_f32", fptr(x), fptr(w), fptr(y), b, h, wd, cin, cout, stream())
+    return y
+
+
+def instnorm_stats(x, want_pooled=False, eps=1e-5):
+    b, h, w, c = x.shape
+    stats = torch.empty(b, c, 2, device=x.device, dtype=torch.float32)
+    pooled = torch.empty(b, c, device=x.device, dtype=torch.float32) if want_pooled else None
+    ws = torch.empty(b * c * 2, device=x.device, dtype=torch.float64)
+    call("e4s_instnorm_stats_f32", fptr(x), fptr(stats), fptr(pooled), ptr(ws), b, h * w, c, float(eps), stream())
+    return stats, pooled
+
+
+def instnorm_apply(x, stats, gate=None, res=None, res_stats=None, slope=None, rs=1):
+    b, h, w, c = x.shape
+    y = torch.empty_like(x)
+    call("e4s_instnorm_apply_f32", fptr(x), fptr(stats), fptr(gate), fptr(res), fptr(res_stats), fptr(slope), fptr(y),
+         b, h, w, c, rs, stream())
+    return y
+
+
+def se_gate(pooled, fc1, fc2):
+    b, c = pooled.shape
+    cr = fc1.shape[0]
+    gate = torch.empty(b, c, device=pooled.device, dtype=torch.float32)
+    call("e4s_se_gate_f32", fptr(pooled), fptr(fc1), fptr(fc2), fptr(gate), b, c, cr, stream())
+    return gate
+
+
+def region_mean_into(feats, labels, out, num_regions, out_off):
+    b, h, w, c = feats.shape
+    hm, wm = labels.shape[1:]
+    call("e4s_region_mean_f32", fptr(feats), ptr(labels), hm, wm, fptr(out), b, h, w, c, num_regions,
+         out.shape[2], out_off, stream())
+
+
+def grouped_linear(x, w, bias, add, scale, act=0, alpha=0.01):
+    """x [B,R,K]; w [R,O,K]; bias [R,O]; add [O] or None -> [B,R,O]."""
+    b, r, k = x.shape
+    o = w.shape[1]
+    y = torch.empty(b, r, o, device=x.device, dtype=torch.float32)
+    call("e4s_grouped_linear_f32", fptr(x), fptr(w), fptr(bias), fptr(add), fptr(y), b, r, k, o, float(scale),
+         act, float(alpha), stream())
+    return y

@@ -1,0 +1,112 @@
+"""ctypes binding of libe4s_hip.so (include/e4s_hip.h).
+
+This is the thin host-side shim a maintainer of the reference would add in place of
+``torch.utils.cpp_extension.load(...)`` (src/models/stylegan2/op/fused_act.py:8-15,
+upfirdn2d.py:7-14): PyTorch supplies device memory (``Tensor.data_ptr()``) and the current HIP
+stream; the library gets raw pointers and sizes.  There is NO fallback: if the shared object is
+missing, or a tensor is not a contiguous fp32 tensor on a ROCm device, we raise.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libe4s_hip.so")
+ABI_VERSION = 1
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_f = ctypes.c_float
+
+
+class ConvParams(ctypes.Structure):
+    """Mirror of ``e4s_conv_params`` (include/e4s_hip.h)."""
+    _fields_ = [
+        ("x", c_p), ("w", c_p), ("y", c_p), ("rows", c_p), ("tiles", c_p), ("meta", c_p), ("tiles_cap", c_i),
+        ("B", c_i), ("Ha", c_i), ("Wa", c_i),
+        ("Hi", c_i), ("Wi", c_i), ("Ho", c_i), ("Wo", c_i), ("Cin", c_i), ("Cout", c_i),
+        ("istride", c_i), ("ostride", c_i), ("ntaps", c_i), ("ncls", c_i),
+        ("in_scale", c_p), ("out_scale", c_p), ("groups_per_batch", c_i),
+        ("noise", c_p), ("noise_w", c_p), ("noise_bstride", c_l), ("noise_per_channel", c_i),
+        ("bias", c_p), ("slope", c_p), ("act", c_i), ("alpha", c_f), ("gain", c_f),
+    ]
+
+
+# name -> argtypes (all return int except the two info calls); keep in sync with include/e4s_hip.h
+SIGNATURES = {
+    "e4s_fused_bias_act_f32": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_p],
+    "e4s_upfirdn2d_f32": [c_p, c_p, c_p] + [c_i] * 14 + [c_p],
+    "e4s_channel_sum_f32": [c_p, c_p, c_l, c_i, c_i, c_p],
+    "e4s_rowdot_f32": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "e4s_weight_sqsum_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "e4s_rgb_weights_f32": [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    "e4s_mask_labels": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_region_plan": [c_p] + [c_i] * 8 + [c_p, c_p, c_p, c_p, c_i, c_i, c_p],
+    "e4s_conv_mfma_f32": [ctypes.POINTER(ConvParams), c_i, c_p],
+    "e4s_torgb_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_nchw_to_nhwc_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_nhwc_to_nchw_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_const_input_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_resize_bilinear_f32": [c_p, c_p] + [c_i] * 6 + [c_p],
+    "e4s_conv3x3_small_f32": [c_p, c_p, c_p] + [c_i] * 5 + [c_p],
+    "e4s_instnorm_stats_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "e4s_instnorm_apply_f32": [c_p] * 7 + [c_i] * 5 + [c_p],
+    "e4s_se_gate_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "e4s_region_mean_f32": [c_p, c_p, c_i, c_i, c_p] + [c_i] * 7 + [c_p],
+    "e4s_grouped_linear_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p],
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libe4s_hip.so (built in-tree by e4s_amd.build / __graft_entry__.build). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run `python -m e4s_amd.build` (hipcc, gfx950). "
+                           "e4s_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.e4s_abi_version.restype = c_i
+    lib.e4s_build_arch.restype = ctypes.c_char_p
+    if lib.e4s_abi_version() != ABI_VERSION:
+        raise RuntimeError("libe4s_hip.so ABI version mismatch: rebuild with `python -m e4s_amd.build --force`")
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_i
+    _lib = lib
+    return lib
+
+
+def stream():
+    return c_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/uint8/int32/f64 ROCm tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("e4s_amd kernels need tensors on a ROCm device (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError("e4s_amd kernels need contiguous tensors")
+    return c_p(t.data_ptr())
+
+
+def fptr(t):
+    if t is not None and t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32, got {t.dtype}")
+    return ptr(t)
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed: hipError {code}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,162 @@
+"""Net3: regional style encoder + 12 LocalMLPs + mask-guided StyleGAN2 generator.
+
+Same public surface as the reference (src/models/networks.py:41-183): constructor `Net3(opts)`,
+`forward`, `get_style_vectors`, `cal_style_codes`, `gen_img`, plain attribute `latent_avg`, identical
+state_dict keys -- so scripts/face_swap.py, scripts/face_edit.py and checkpoints drop in.  Every
+method is a schedule of HIP kernels (libe4s_hip.so); there is no torch-eager fallback.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from .encoders import FSEncoder_PSP
+from .stylegan2 import EqualLinear, Generator
+
+
+class LocalMLP(nn.Module):
+    """networks.py:15-39: EqualLinear(1280->512) -> LeakyReLU(0.01) -> EqualLinear(512 -> 512*num_w_layers)."""
+
+    def __init__(self, dim_component=512, dim_style=512, num_w_layers=18, latent_squeeze_ratio=1):
+        super().__init__()
+        self.dim_component, self.dim_style, self.num_w_layers = dim_component, dim_style, num_w_layers
+        self.mlp = nn.Sequential(EqualLinear(dim_component, dim_style // latent_squeeze_ratio, lr_mul=1),
+                                 nn.LeakyReLU(),
+                                 EqualLinear(dim_style // latent_squeeze_ratio, dim_style * num_w_layers, lr_mul=1))
+
+    def forward(self, x):
+        """x [B, dim_component] -> [B, num_w_layers, 512] (single-region drop-in)."""
+        l0, l2 = self.mlp[0], self.mlp[2]
+        h = K.grouped_linear(x.unsqueeze(1).contiguous(), l0.weight.unsqueeze(0), l0.bias.unsqueeze(0), None,
+                             l0.scale, act=1, alpha=self.mlp[1].negative_slope)
+        y = K.grouped_linear(h, l2.weight.unsqueeze(0), l2.bias.unsqueeze(0), None, l2.scale)
+        return y.view(-1, self.num_w_layers, self.dim_style)
+
+
+class Net3(nn.Module):
+    def __init__(self, opts):
+        super().__init__()
+        self.opts = opts
+        assert self.opts.fsencoder_type in ["psp"]
+        self.encoder = FSEncoder_PSP(mode="ir_se", opts=self.opts)
+        dim_s_code = 256 + 512 + 512
+        self.split_layer_idx = 5
+        self.remaining_layer_idx = self.opts.remaining_layer_idx
+        K_ = self.remaining_layer_idx
+        self.MLPs = nn.ModuleList([LocalMLP(dim_component=dim_s_code, dim_style=512,
+                                            num_w_layers=K_ if K_ != 17 else 18)
+                                   for _ in range(self.opts.num_seg_cls)])
+        self.G = Generator(size=self.opts.out_size, style_dim=512, n_mlp=8, split_layer_idx=self.split_layer_idx,
+                           remaining_layer_idx=K_)
+        # freeze policy, networks.py:63-82
+        if not self.opts.train_G:
+            for p in self.G.parameters():
+                p.requires_grad = False
+        else:
+            for p in self.G.style.parameters():
+                p.requires_grad = False
+        if K_ != 17:
+            for p in self.G.convs[-(17 - K_):].parameters():
+                p.requires_grad = False
+            for p in self.G.to_rgbs[-(17 - K_) // 2 - 1:].parameters():
+                p.requires_grad = False
+        self._mlp_pack = None
+
+    # ---- stacked LocalMLP weights ([R,O,K]) so the 24 small GEMMs become 2 launches -------------
+    def _mlp_weights(self):
+        ps = [t for m in self.MLPs for t in (m.mlp[0].weight, m.mlp[0].bias, m.mlp[2].weight, m.mlp[2].bias)]
+        key = tuple((t.data_ptr(), t._version) for t in ps)
+        if self._mlp_pack is None or self._mlp_pack[0] != key:
+            with torch.no_grad():
+                w0 = torch.stack([m.mlp[0].weight.detach() for m in self.MLPs]).contiguous()
+                b0 = torch.stack([m.mlp[0].bias.detach() for m in self.MLPs]).contiguous()
+                w2 = torch.stack([m.mlp[2].weight.detach() for m in self.MLPs]).contiguous()
+                b2 = torch.stack([m.mlp[2].bias.detach() for m in self.MLPs]).contiguous()
+            self._mlp_pack = (key, w0, b0, w2, b2)
+        return self._mlp_pack[1:]
+
+    def _require_no_grad(self, *tensors):
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+            raise NotImplementedError("autograd through the HIP path (SURVEY.md 8(f) N1) is not built yet; "
+                                      "use torch.no_grad()")
+
+    # ---- API ------------------------------------------------------------------------------------
+    def get_style_vectors(self, img, mask):
+        """networks.py:121-133: img [B,3,H,W] in [-1,1], one-hot mask [B,R,Hm,Wm] ->
+        ([B,R,1280], zeros [B,512,16,16])."""
+        self._require_no_grad(img)
+        with torch.no_grad():
+            labels, _ = K.mask_labels(mask)
+            x256 = K.resize_bilinear_to_nhwc(img, 256, 256)                  # F.interpolate(...,'bilinear') :131
+            codes, last = self.encoder.encode_nhwc(x256, labels, mask.shape[1])
+            b, h, w, c = last.shape
+            return codes, torch.zeros(b, c, h, w, device=img.device, dtype=torch.float32)
+
+    def cal_style_codes(self, style_vectors):
+        """networks.py:135-158 -> [B,R,n_latent,512]."""
+        self._require_no_grad(style_vectors)
+        if not self.opts.start_from_latent_avg or self.opts.learn_in_w:
+            raise NotImplementedError("only start_from_latent_avg=True, learn_in_w=False (the shipped configs)")
+        with torch.no_grad():
+            K_ = self.remaining_layer_idx
+            nw = K_ if K_ != 17 else 18
+            w0, b0, w2, b2 = self._mlp_weights()
+            sv = style_vectors.detach().to(torch.float32).contiguous()
+            b, r, _ = sv.shape
+            lat = self.latent_avg.to(device=sv.device, dtype=torch.float32)
+            h = K.grouped_linear(sv, w0, b0, None, 1.0 / math.sqrt(w0.shape[2]), act=1, alpha=0.01)
+            add = lat[:nw].reshape(-1).contiguous()
+            codes = K.grouped_linear(h, w2, b2, add, 1.0 / math.sqrt(w2.shape[2])).view(b, r, nw, 512)
+            if K_ != 17:
+                rest = lat[K_:].view(1, 1, -1, 512).expand(b, r, -1, -1)
+                codes = torch.cat([codes, rest], dim=2)
+            return codes
+
+    def gen_img(self, struc_codes, style_codes, mask, randomize_noise=True, noise=None, return_latents=False):
+        """networks.py:160-182 -> (images, latent | -1, feats16)."""
+        images, result_latent, feats = self.G([style_codes], struc_codes, mask, input_is_latent=True,
+                                              randomize_noise=randomize_noise, noise=noise,
+                                              return_latents=return_latents, use_structure_code=False)
+        if return_latents:
+            return images, result_latent, feats
+        return images, -1, feats
+
+    def forward(self, img, mask, resize=False, randomize_noise=True, return_latents=False):
+        """networks.py:85-119 -> (images, feats16[, latent])."""
+        sv, struct = self.get_style_vectors(img, mask)
+        codes = self.cal_style_codes(sv)
+        images, latent, feats = self.G([codes], struct, mask, input_is_latent=True, randomize_noise=randomize_noise,
+                                       return_latents=return_latents, use_structure_code=False)
+        if return_latents:
+            return images, feats, latent
+        return images, feats
+
+
+def swap_comp_style_vector(style_vectors1, style_vectors2, comp_indices, belowFace_interpolation=False):
+    """scripts/face_swap.py:117-146, applied per sample so that batches work.
+    style_vectors1 = target, style_vectors2 = source/driven."""
+    out = style_vectors1.clone()
+    idx = torch.as_tensor(sorted(comp_indices), device=out.device, dtype=torch.long)
+    out[:, idx] = style_vectors2[:, idx]
+    no_ear = (style_vectors2[:, 7].sum(1) == 0)
+    out[no_ear, 7] = (style_vectors1[no_ear, 7] + style_vectors2[no_ear, 7]) / 2
+    no_teeth = (style_vectors2[:, 9].sum(1) == 0)
+    out[no_teeth, 9] = style_vectors1[no_teeth, 9]
+    if belowFace_interpolation:
+        out[:, 8] = (style_vectors1[:, 8] + style_vectors2[:, 8]) / 2
+    return out
+
+
+@torch.no_grad()
+def face_swap_core(net, driven, driven_mask, target, target_mask, swapped_mask, noise=None, randomize_noise=False):
+    """The E4S-core unit of work (scripts/face_swap.py:237-273) on a batch of B swaps:
+    2 encoder passes (fused into one batched pass), regional style swap, LocalMLPs, generator."""
+    b = driven.shape[0]
+    sv, _ = net.get_style_vectors(torch.cat([driven, target], 0), torch.cat([driven_mask, target_mask], 0))
+    d_sv, t_sv = sv[:b], sv[b:]
+    comp = set(range(net.opts.num_seg_cls)) - {0, 4, 11, 10}
+    swapped = swap_comp_style_vector(t_sv, d_sv, comp)
+    codes = net.cal_style_codes(swapped)
+    img, _, _ = net.gen_img(None, codes, swapped_mask, randomize_noise=randomize_noise, noise=noise)
+    return img

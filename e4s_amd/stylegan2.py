@@ -1,0 +1,530 @@
+"""StyleGAN2 generator with mask-guided regional style injection -- MI355X-native.
+
+Host-side mirror of the reference module tree (src/models/stylegan2/model.py:34-667): the same
+class names, constructor arguments, parameter/buffer names and shapes, so reference checkpoints
+(`G.conv1.conv.weight`, `G.convs.N.conv.modulation.weight`, `G.to_rgbs.N.upsample.kernel`, ...)
+load with strict=True.  What differs is the execution: ``Generator.forward`` does not call a
+chain of per-region ATen ops; it drives the fused HIP kernels of libe4s_hip.so
+(e4s_amd/csrc/*.hip) over NHWC activations:
+
+    reference (model.py)                               here
+    ---------------------------------------------      -----------------------------------------
+    modulation + materialised [B,Cout,Cin,3,3]          e4s_rowdot_f32 x2 on cached sum_k W^2
+      weights + demod (276-281)
+    12 x grouped conv * one-hot mask (386-400)          ONE gathered-row MFMA GEMM (region plan)
+    conv_transpose2d + Blur/upfirdn2d (287-300)         4-phase 3x3 polyphase weights, same GEMM
+    NoiseInjection + FusedLeakyReLU (329-335, 404)      GEMM epilogue
+    ToRGB conv + bias + Upsample(skip) (422-448)        e4s_torgb_f32
+
+There is no CPU path: tensors must live on a ROCm device and the library must be built.
+"""
+import math
+import random
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import kernels as K
+from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix
+
+
+def make_kernel(k):
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+class PixelNorm(nn.Module):
+    def forward(self, input):
+        return input * torch.rsqrt(torch.mean(input ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+class Upsample(nn.Module):
+    """model.py:34-53"""
+
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Downsample(nn.Module):
+    """model.py:56-75"""
+
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=1, down=self.factor, pad=self.pad)
+
+
+class Blur(nn.Module):
+    """model.py:78-94"""
+
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        kernel = make_kernel(kernel)
+        if upsample_factor > 1:
+            kernel = kernel * (upsample_factor ** 2)
+        self.register_buffer("kernel", kernel)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualConv2d(nn.Module):
+    """model.py:97-132 (Discriminator only)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride, self.padding = stride, padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input):
+        return conv2d_gradfix.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride,
+                                     padding=self.padding)
+
+
+class EqualLinear(nn.Module):
+    """model.py:135-169"""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        if self.activation:
+            out = F.linear(input, self.weight * self.scale)
+            return fused_leaky_relu(out, self.bias * self.lr_mul)
+        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+
+
+class ScaledLeakyReLU(nn.Module):
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, input):
+        return F.leaky_relu(input, negative_slope=self.negative_slope) * math.sqrt(2)
+
+
+def polyphase_upconv_weights(w, blur_kernel):
+    """Fold conv_transpose2d(stride=2, padding=0) followed by the 4x4 blur with pad (1,1)
+    (model.py:287-300, 206-213) into four phase-specific 3x3 kernels over the INPUT grid.
+
+    With I[q] = sum_{2u+k=q} x[u] W[k] (transposed conv) and out[p] = sum_j I[p+j-1] kflip[j] (upfirdn2d is a
+    true convolution, upfirdn2d_kernel.cu:77), out[p] = sum_u x[u] E[p-2u] with
+        E[t] = sum_j kflip[j] W[t+j-1],  t in [-2, 3].
+    Output pixel p = 2a + py only sees u in {a-1, a, a+1}: tap e (u = a+e-1) uses E[py - 2(e-1)].
+    w [Cout,Cin,3,3], blur_kernel [4,4] -> [4 (py*2+px), 9 (ey*3+ex), Cout, Cin]."""
+    cout, cin = w.shape[:2]
+    kf = torch.flip(blur_kernel, [0, 1])
+    e = F.conv2d(F.pad(w.reshape(cout * cin, 1, 3, 3), (3, 3, 3, 3)), kf[None, None]).reshape(cout, cin, 6, 6)
+    phases = []
+    for py in range(2):
+        for px in range(2):
+            iy = [py + 4 - 2 * ey for ey in range(3)]          # E index = t + 2
+            ix = [px + 4 - 2 * ex for ex in range(3)]
+            sub = e[:, :, iy][:, :, :, ix]
+            phases.append(sub.permute(2, 3, 0, 1).reshape(9, cout, cin))
+    return torch.stack(phases, 0).contiguous()
+
+
+def _param_key(*tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors)
+
+
+class ModulatedConv2d(nn.Module):
+    """model.py:184-320.  Parameters as in the reference; `packed()` lays the weight out for the
+    implicit-GEMM kernel ([ncls][tap][Cout][Cin]) and caches sum_k W^2 for demodulation."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=[1, 3, 3, 1], fused=True):
+        super().__init__()
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel, self.out_channel = in_channel, out_channel
+        self.upsample, self.downsample = upsample, downsample
+        if downsample:
+            raise NotImplementedError("downsampling ModulatedConv2d is never instantiated by E4S")
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+        self.fused = fused
+        self._pack = None
+
+    def packed(self):
+        """Returns dict(w=[ncls,taps,Cout,Cin], wsq=[Cout,Cin] | None, w_rgb=[Cout,Cin] for 1x1)."""
+        key = _param_key(self.weight) + ((_param_key(self.blur.kernel)) if self.upsample else ())
+        if self._pack is not None and self._pack["key"] == key:
+            return self._pack
+        with torch.no_grad():
+            w = self.weight.detach()[0].float()                                  # [Cout,Cin,k,k]
+            cout, cin, k, _ = w.shape
+            pack = {"key": key}
+            if k == 1:
+                pack["w"] = w.reshape(1, 1, cout, cin).contiguous()
+            elif not self.upsample:
+                pack["w"] = w.permute(2, 3, 0, 1).reshape(1, k * k, cout, cin).contiguous()
+            else:
+                pack["w"] = polyphase_upconv_weights(w, self.blur.kernel.detach().float())
+            pack["wsq"] = K.weight_sqsum(w.contiguous()) if self.demodulate else None
+        self._pack = pack
+        return pack
+
+    def forward(self, input, style):
+        """Drop-in single-style forward (NCHW in/out), model.py:242-320."""
+        b = input.shape[0]
+        x = K.nchw_to_nhwc(input)
+        pk = self.packed()
+        s = K.modulate_vec(style, self.modulation.weight, self.modulation.bias)
+        if self.kernel_size == 1:
+            if self.out_channel != 3 or self.demodulate:
+                raise NotImplementedError("1x1 ModulatedConv2d exists only as the ToRGB conv (model.py:417)")
+            ws = K.rgb_weights(pk["w"].view(3, -1), s, self.scale)
+            zero = torch.zeros(3, device=x.device)
+            return K.torgb(x, ws, zero, None, None, None, 1)
+        else:
+            d = K.demod_coefs(s, pk["wsq"], self.scale) if self.demodulate else \
+                torch.full((b, self.out_channel), self.scale, device=x.device)
+            if self.upsample:
+                y = K.conv_mfma(x, pk["w"], self.out_channel, ncls=4, ostride=2, in_scale=s, out_scale=d)
+            else:
+                y = K.conv_mfma(x, pk["w"], self.out_channel, in_scale=s, out_scale=d)
+        return K.nhwc_to_nchw(y)
+
+
+class NoiseInjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def forward(self, image, noise=None):
+        if noise is None:
+            b, _, h, w = image.shape
+            noise = image.new_empty(b, 1, h, w).normal_()
+        return image + self.weight * noise
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, input):
+        return self.input.repeat(input.shape[0], 1, 1, 1)
+
+
+def _prep_noise(noise, b, h, w, device):
+    """Returns (tensor, per_channel).  None -> fresh N(0,1) like NoiseInjection (model.py:329-333)."""
+    if noise is None:
+        return torch.randn(b, 1, h, w, device=device), False
+    noise = noise.to(device=device, dtype=torch.float32)
+    if noise.ndim != 4 or noise.shape[2] != h or noise.shape[3] != w or noise.shape[0] not in (1, b):
+        raise RuntimeError(f"noise of shape {tuple(noise.shape)} is not broadcastable to [{b},C,{h},{w}]")
+    if noise.shape[1] == 1:
+        return noise.contiguous(), False
+    return K.nchw_to_nhwc(noise), True           # [1,C,H,W] noise of scripts/face_edit.py:49-52
+
+
+class StyledConv(nn.Module):
+    """model.py:351-406"""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1],
+                 demodulate=True, mask_op=False):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+        self.mask_op = mask_op
+
+    def run_nhwc(self, x, s, plan, noise):
+        """x NHWC, s [G,Cin] modulation; plan: RowPlan (masked) or None.  Returns NHWC output after
+        noise + bias + leaky-ReLU*sqrt(2)."""
+        conv = self.conv
+        pk = conv.packed()
+        b, h, w, _ = x.shape
+        ho, wo = (2 * h, 2 * w) if conv.upsample else (h, w)
+        d = K.demod_coefs(s, pk["wsq"], conv.scale)
+        nz, per_ch = _prep_noise(noise, b, ho, wo, x.device)
+        return K.conv_mfma(x, pk["w"], conv.out_channel, plan=plan, ncls=4 if conv.upsample else 1,
+                           ostride=2 if conv.upsample else 1, in_scale=s, out_scale=d, noise=nz,
+                           noise_w=self.noise.weight, noise_per_channel=per_ch, bias=self.activate.bias, act=1,
+                           alpha=self.activate.negative_slope, gain=self.activate.scale)
+
+    def forward(self, input, style, mask, noise=None):
+        """Drop-in NCHW forward.  style [B,R,512] + one-hot mask when mask_op else [B,512]."""
+        x = K.nchw_to_nhwc(input)
+        b, h, w, _ = x.shape
+        mod = self.conv.modulation
+        if self.mask_op:
+            r = style.shape[1]
+            s = K.modulate_vec(style.reshape(b * r, -1), mod.weight, mod.bias)
+            labels, _ = K.mask_labels(mask)
+            plan = K.region_plan(labels, r, h, w, 4 if self.conv.upsample else 1)
+        else:
+            s = K.modulate_vec(style, mod.weight, mod.bias)
+            plan = None
+        return K.nhwc_to_nchw(self.run_nhwc(x, s, plan, noise))
+
+
+class ToRGB(nn.Module):
+    """model.py:409-448"""
+
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1], mask_op=False):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+        self.mask_op = mask_op
+
+    def run_nhwc(self, x, s, labels, num_regions, skip):
+        pk = self.conv.packed()
+        ws = K.rgb_weights(pk["w"].view(3, -1), s, self.conv.scale)
+        k4 = self.upsample.kernel if skip is not None else None
+        return K.torgb(x, ws, self.bias, skip, k4, labels, num_regions)
+
+    def forward(self, input, style, mask, skip=None):
+        x = K.nchw_to_nhwc(input)
+        b = x.shape[0]
+        mod = self.conv.modulation
+        if self.mask_op:
+            r = style.shape[1]
+            s = K.modulate_vec(style.reshape(b * r, -1), mod.weight, mod.bias)
+            labels, _ = K.mask_labels(mask)
+            return self.run_nhwc(x, s, labels, r, skip)
+        s = K.modulate_vec(style, mod.weight, mod.bias)
+        return self.run_nhwc(x, s, None, 1, skip)
+
+
+class Generator(nn.Module):
+    """model.py:451-667"""
+
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01,
+                 split_layer_idx=7, remaining_layer_idx=18):
+        super().__init__()
+        self.split_layer_idx = split_layer_idx
+        self.remaining_layer_idx = remaining_layer_idx
+        self.size = size
+        self.style_dim = style_dim
+        layers = [PixelNorm()]
+        for _ in range(n_mlp):
+            layers.append(EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation="fused_lrelu"))
+        self.style = nn.Sequential(*layers)
+        self.channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier,
+                         128: 128 * channel_multiplier, 256: 64 * channel_multiplier,
+                         512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+        self.input = ConstantInput(self.channels[4])
+        self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel,
+                                mask_op=True)
+        self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False, mask_op=True)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.convs = nn.ModuleList()
+        self.upsamples = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = nn.Module()
+        in_channel = self.channels[4]
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer(f"noise_{layer_idx}", torch.randn(1, 1, 2 ** res, 2 ** res))
+        K_ = self.remaining_layer_idx
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            conv_masked = not (i > 2 + K_ // 2)                                   # model.py:537,545
+            rgb_masked = not (K_ != 17 and i >= 2 + K_ // 2)                      # model.py:553
+            self.convs.append(StyledConv(in_channel, out_channel, 3, style_dim, upsample=True,
+                                         blur_kernel=blur_kernel, mask_op=conv_masked))
+            self.convs.append(StyledConv(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel,
+                                         mask_op=conv_masked))
+            self.to_rgbs.append(ToRGB(out_channel, style_dim, mask_op=rgb_masked))
+            in_channel = out_channel
+        self.n_latent = self.log_size * 2 - 2
+
+    def make_noise(self):
+        device = self.input.input.device
+        noises = [torch.randn(1, 1, 4, 4, device=device)]
+        for i in range(3, self.log_size + 1):
+            for _ in range(2):
+                noises.append(torch.randn(1, 1, 2 ** i, 2 ** i, device=device))
+        return noises
+
+    def mean_latent(self, n_latent):
+        latent_in = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style(latent_in).mean(0, keepdim=True)
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    # ------------------------------------------------------------------------------------------
+    def _assemble_latent(self, styles, input_is_latent, inject_index, truncation, truncation_latent):
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]
+        if truncation < 1:
+            styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
+        if len(styles) < 2:
+            if styles[0].ndim < 4:
+                return styles[0].unsqueeze(1).repeat(1, self.n_latent, 1)
+            return styles[0]
+        if inject_index is None:
+            inject_index = random.randint(1, self.n_latent - 1)
+        l1 = styles[0].unsqueeze(1).repeat(1, inject_index, 1)
+        l2 = styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)
+        return torch.cat([l1, l2], 1)
+
+    def forward(self, styles, structure_feats, mask, return_latents=False, inject_index=None, truncation=1,
+                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True,
+                use_structure_code=False):
+        """model.py:576-667.  `styles` = [latent [B,R,n_latent,512]] with input_is_latent=True is the E4S call
+        (networks.py:110-112,175-177).  Returns (image NCHW, latent|None, feats at 16x16 NCHW)."""
+        if use_structure_code:
+            raise NotImplementedError("use_structure_code=True is never used by E4S (networks.py:112,177)")
+        latent = self._assemble_latent(styles, input_is_latent, inject_index, truncation, truncation_latent)
+        if latent.ndim != 4:
+            raise RuntimeError("E4S generator expects a regional latent [B, R, n_latent, 512]")
+        if noise is None:
+            noise = [None] * self.num_layers if randomize_noise else \
+                [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
+        if torch.is_grad_enabled() and (latent.requires_grad or any(
+                n is not None and n.requires_grad for n in noise)):
+            raise NotImplementedError(
+                "autograd through the fused HIP generator (SURVEY.md 8(f) N1, backward kernels) is not built yet; "
+                "call under torch.no_grad() for inference")
+        image, feats = self._fused_forward(latent, mask, noise)
+        return (image, latent, feats) if return_latents else (image, None, feats)
+
+    @torch.no_grad()
+    def _fused_forward(self, latent, mask, noise):
+        lat = latent.detach().to(torch.float32).contiguous()
+        b, r = lat.shape[:2]
+        labels, _flags = K.mask_labels(mask)
+        plans = {}
+
+        def plan_for(ha, wa, nphase):
+            key = (ha, wa, nphase)
+            if key not in plans:
+                plans[key] = K.region_plan(labels, r, ha, wa, nphase)
+            return plans[key]
+
+        def styled(layer, x, idx, nz):
+            mod = layer.conv.modulation
+            s = K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
+            plan = None
+            if layer.mask_op:
+                h, w = x.shape[1:3]
+                plan = plan_for(h, w, 4 if layer.conv.upsample else 1)
+            return layer.run_nhwc(x, s, plan, nz)
+
+        def rgb(layer, x, idx, skip):
+            mod = layer.conv.modulation
+            s = K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
+            return layer.run_nhwc(x, s, labels if layer.mask_op else None, r, skip)
+
+        x = K.const_input(self.input.input, b)
+        x = styled(self.conv1, x, 0, noise[0])
+        skip = rgb(self.to_rgb1, x, 1, None)
+        feats = None
+        i = 1
+        for conv1, conv2, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
+            x = styled(conv1, x, i, noise[i])
+            if i + 2 == self.split_layer_idx:
+                feats = K.nhwc_to_nchw(x)                                          # model.py:642-647
+            x = styled(conv2, x, i + 1, noise[i + 1])
+            skip = rgb(to_rgb, x, i + 2, skip)
+            i += 2
+        return skip, feats
+
+
+# ---- Discriminator (config 5 only; plain torch convs through conv2d_gradfix, HIP blur + bias-act) ----
+class ConvLayer(nn.Sequential):
+    """model.py:670-716"""
+
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=[1, 3, 3, 1], bias=True,
+                 activate=True):
+        layers = []
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            layers.append(Blur(blur_kernel, pad=((p + 1) // 2, p // 2)))
+            stride, self.padding = 2, 0
+        else:
+            stride, self.padding = 1, kernel_size // 2
+        layers.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding, stride=stride,
+                                  bias=bias and not activate))
+        if activate:
+            layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
+        super().__init__(*layers)
+
+
+class ResBlock(nn.Module):
+    """model.py:719-737"""
+
+    def __init__(self, in_channel, out_channel, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channel, in_channel, 3)
+        self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=True)
+        self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
+
+    def forward(self, input):
+        out = self.conv2(self.conv1(input))
+        return (out + self.skip(input)) / math.sqrt(2)
+
+
+class Discriminator(nn.Module):
+    """model.py:740-799"""
+
+    def __init__(self, size, channel_multiplier=2, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
+                    256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+        convs = [ConvLayer(3, channels[size], 1)]
+        log_size = int(math.log(size, 2))
+        in_channel = channels[size]
+        for i in range(log_size, 2, -1):
+            out_channel = channels[2 ** (i - 1)]
+            convs.append(ResBlock(in_channel, out_channel, blur_kernel))
+            in_channel = out_channel
+        self.convs = nn.Sequential(*convs)
+        self.stddev_group = 4
+        self.stddev_feat = 1
+        self.final_conv = ConvLayer(in_channel + 1, channels[4], 3)
+        self.final_linear = nn.Sequential(EqualLinear(channels[4] * 4 * 4, channels[4], activation="fused_lrelu"),
+                                          EqualLinear(channels[4], 1))
+
+    def forward(self, input):
+        out = self.convs(input)
+        batch, channel, height, width = out.shape
+        group = min(batch, self.stddev_group)
+        stddev = out.view(group, -1, self.stddev_feat, channel // self.stddev_feat, height, width)
+        stddev = torch.sqrt(stddev.var(0, unbiased=False) + 1e-8)
+        stddev = stddev.mean([2, 3, 4], keepdims=True).squeeze(2)
+        stddev = stddev.repeat(group, 1, height, width)
+        out = torch.cat([out, stddev], 1)
+        out = self.final_conv(out)
+        return self.final_linear(out.view(batch, -1))

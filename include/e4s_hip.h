@@ -1,0 +1,169 @@
+/* e4s_hip.h -- C-ABI of libe4s_hip.so, the MI355X (gfx950) native library behind the E4S
+ * hot path (Net3 regional encoder + mask-guided StyleGAN2 generator).
+ *
+ * Drop-in boundary: the reference binds its two native ops through pybind11
+ * torch extensions
+ *     fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ *                                   src/models/stylegan2/op/fused_bias_act.cpp:11-21
+ *     upfirdn2d_op.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+ *                                   src/models/stylegan2/op/upfirdn2d.cpp:12-22
+ * and does everything else (modulation, demodulation, the grouped convs, region compose, noise,
+ * ToRGB, the IR-SE encoder, regional pooling, the LocalMLPs) as chains of ATen launches
+ * (src/models/stylegan2/model.py:242-448, src/models/encoders/helpers.py:122-144,
+ * src/models/encoders/psp_encoders.py:264-309, src/models/networks.py:15-39).  This library
+ * replaces both: e4s_fused_bias_act_f32 / e4s_upfirdn2d_f32 are 1:1 replacements of the two
+ * native entry points; the rest are the fused kernels those ATen chains collapse into.
+ *
+ * Conventions: plain C, device pointers + sizes, no torch types.  Every entry point enqueues on
+ * `stream` (a hipStream_t passed as void*; NULL = the null stream) on the CURRENT device, never
+ * allocates, never synchronises, and returns 0 or a hipError_t value (launch errors ARE checked,
+ * unlike the reference, .cu:80).  All tensors are fp32 and contiguous.  Activations inside the
+ * generator/encoder are NHWC ("pixel-major"); the public tensors (images, masks, RGB skips) are
+ * NCHW as in the reference.
+ */
+#ifndef E4S_HIP_H
+#define E4S_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library info ------------------------------------------------------------------------ */
+int e4s_abi_version(void);                 /* bumped on any signature change */
+const char* e4s_build_arch(void);          /* "gfx950" */
+
+/* ---- 1:1 replacements of the reference's native ops ---------------------------------------- */
+
+/* y[i] = act(x[i] + b[(i / step_b) % size_b]) * scale      fused_bias_act_kernel.cu:19-49
+ * act*10+grad: 10/11 linear, 30 lrelu fwd, 31 lrelu grad gated on sign of ref[i], 12/32 -> 0.
+ * b may be NULL (no bias), ref may be NULL unless act*10+grad == 31. */
+int e4s_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* y, int64_t n,
+                           int step_b, int size_b, int act, int grad, float alpha, float scale,
+                           void* stream);
+
+/* Up-FIR-down on x viewed as [major, in_h, in_w, minor]      upfirdn2d_kernel.cu:52-137,140-272
+ * (true convolution: kernel flipped; negative pads crop).  y is [major, out_h, out_w, minor] with
+ * out = (in*up + pad0 + pad1 - k) / down + 1.  Any up/down >= 1 and kernel size <= 16x16
+ * (the reference leaves unmatched modes undefined, .cu:172-175,216). */
+int e4s_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
+                      int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* grad_bias[c] = sum over all i with channel c of g[i]      op/fused_act.py:33-38 */
+int e4s_channel_sum_f32(const float* g, float* out, int64_t n, int step_b, int size_b, void* stream);
+
+/* ---- style prologue (model.py:276-281) ----------------------------------------------------- */
+
+/* out[g, o] = post( sum_i pre(in[g*in_stride + i]) * M[o*K + i] )
+ * mode 0 (modulation, EqualLinear model.py:159-162): post = acc*scale + bias[o]
+ * mode 1 (demodulation, model.py:279-281): pre = x*x, post = scale * rsqrt(scale*scale*acc + 1e-8)
+ *        (M = sum_k W^2 [Cout,Cin]; the conv scale 1/sqrt(9*Cin) is folded into the coefficient) */
+int e4s_rowdot_f32(const float* in, int64_t in_stride, const float* M, const float* bias, float* out,
+                   int G, int O, int K, int mode, float scale, void* stream);
+
+/* wsq[co, ci] = sum_k w[co, ci, k]^2 (w is [Cout, Cin, taps]) */
+int e4s_weight_sqsum_f32(const float* w, float* wsq, int cout, int cin, int taps, void* stream);
+
+/* ws[g, c, ci] = scale * w[c, ci] * s[g, ci]   (ToRGB: demodulate=False, model.py:417) */
+int e4s_rgb_weights_f32(const float* w, const float* s, float* ws, int G, int cin, float scale, void* stream);
+
+/* ---- mask plan (region-select; model.py:386-400 without the 12x redundancy) ---------------- */
+
+/* labels[b, y, x] = argmax_r mask[b, r, y, x]; flags[0] |= 1 if some pixel is not one-hot. */
+int e4s_mask_labels(const float* mask, uint8_t* labels, int* flags, int B, int R, int Hm, int Wm, void* stream);
+
+/* Build the row plan for one layer geometry.  Anchor grid [B, Ha, Wa]; an anchor expands into
+ * nphase (1 or 4) GEMM rows, one per output phase; the row's region is the label of its OUTPUT
+ * pixel (oy = ay*os + py) looked up with legacy-nearest from the [Hm, Wm] label map
+ * (F.interpolate(mode='nearest'), model.py:391).  Rows are grouped by (b, region, phase), each
+ * group padded to a multiple of BM with -1.
+ *   rows  [rows_cap]  anchor ids (b*Ha + ay)*Wa + ax, or -1
+ *   tiles [tiles_cap*4] {row_start, group = b*R + region, phase, nvalid}
+ *   meta  [4] {ntiles, nrows_padded, 0, 0};  work [3*B*R*nphase] ints of scratch
+ * Caps: rows_cap >= B*Ha*Wa*nphase + B*R*nphase*BM, tiles_cap >= rows_cap / BM. */
+int e4s_region_plan(const uint8_t* labels, int B, int R, int Hm, int Wm, int Ha, int Wa, int nphase,
+                    int BM, int* rows, int* tiles, int* meta, int* work, int rows_cap, int tiles_cap,
+                    void* stream);
+
+/* ---- the hot kernel: implicit-GEMM 3x3 / 1x1 convolution on fp32 MFMA ---------------------- */
+
+typedef struct {
+    const float* x;          /* input  NHWC [B, Hi, Wi, Cin] */
+    const float* w;          /* weights [ncls][ntaps][Cout][Cin]  (Cin contiguous) */
+    float* y;                /* output NHWC [B, Ho, Wo, Cout] */
+    const int* rows;         /* plan rows or NULL (natural order) */
+    const int* tiles;        /* plan tiles or NULL */
+    const int* meta;         /* plan meta (device) or NULL */
+    int tiles_cap;           /* grid upper bound in plan mode */
+    int B, Ha, Wa;           /* anchor grid */
+    int Hi, Wi, Ho, Wo, Cin, Cout;
+    int istride;             /* input coord = anchor*istride + tap - 1 (3x3) / anchor*istride (1x1) */
+    int ostride;             /* output coord = anchor*ostride + phase */
+    int ntaps;               /* 9 or 1 */
+    int ncls;                /* 1, or 4 = polyphase up-conv (phase-specific weights) */
+    const float* in_scale;   /* [G][Cin] style modulation s, or NULL */
+    const float* out_scale;  /* [G][Cout] demodulation coefficient (x conv scale), or NULL */
+    int groups_per_batch;    /* R in plan mode; natural mode uses group = b */
+    const float* noise;      /* [Bn,1,Ho,Wo], or NHWC [Bn,Ho,Wo,Cout] when noise_per_channel; or NULL */
+    const float* noise_w;    /* device scalar (NoiseInjection.weight) */
+    int64_t noise_bstride;   /* Ho*Wo (pixels per sample), or 0 when the noise is shared by the batch */
+    int noise_per_channel;   /* scripts/face_edit.py:49-52 passes [1,C,H,W] noise */
+    const float* bias;       /* [Cout] or NULL */
+    const float* slope;      /* [Cout] PReLU slopes (act == 2) */
+    int act;                 /* 0 none, 1 leaky-relu(alpha)*gain, 2 PReLU */
+    float alpha, gain;
+} e4s_conv_params;
+
+/* y = epilogue( sum_{tap,ci} x[anchor*istride + tap - 1, ci] * in_scale[g,ci] * w[cls,tap,co,ci] )
+ * epilogue: v*out_scale[g,co] + noise_w*noise + bias[co], then act.
+ * Replaces ModulatedConv2d.forward + region compose + NoiseInjection + FusedLeakyReLU
+ * (model.py:276-320, 386-404) and the encoder's Conv2d+PReLU (helpers.py:128-137).
+ * Requirements: Cin % 32 == 0, Cout % 32 == 0.  `spatial` selects the halo-tiled loader
+ * (natural order, istride == 1, Ha % 8 == 0, Wa % 16 == 0). */
+int e4s_conv_mfma_f32(const e4s_conv_params* p, int spatial, void* stream);
+
+/* ---- ToRGB (model.py:422-448) -------------------------------------------------------------- */
+/* out[b,c,y,x] = sum_ci x[b,y,x,ci]*ws[g,c,ci] + bias[c] + upfirdn2d(skip, k4, up=2, pad=(2,1))
+ * x NHWC, out/skip NCHW; labels ([B,Hm,Wm] label map) NULL => group = b (unmasked). */
+int e4s_torgb_f32(const float* x, const float* ws, const float* bias, const float* skip, const float* k4,
+                  const uint8_t* labels, int Hm, int Wm, int R, float* out,
+                  int B, int H, int W, int Cin, void* stream);
+
+/* ---- layout helpers ------------------------------------------------------------------------ */
+int e4s_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int H, int W, void* stream);
+int e4s_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, void* stream);
+/* y[b, :, :, :] = x[0, :, :, :] (ConstantInput.repeat, model.py:345-349), NCHW src -> NHWC dst */
+int e4s_const_input_f32(const float* x, float* y, int B, int C, int H, int W, void* stream);
+
+/* ---- regional style encoder (psp_encoders.py:238-309, helpers.py:122-144) ------------------- */
+/* bilinear (align_corners=False, no antialias) NCHW [B,C,Hi,Wi] -> NHWC [B,Ho,Wo,C]; networks.py:131 */
+int e4s_resize_bilinear_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+/* direct 3x3 conv for tiny Cin (input layer 3->64): x NHWC [B,H,W,Cin], w [Cout,Cin,3,3] (reference layout) */
+int e4s_conv3x3_small_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout, void* stream);
+/* InstanceNorm2d statistics (biased var, eps): stats[b, c] = {mean, rstd}; x NHWC [B,HW,C].
+ * pooled (optional) [B,C] = spatial mean of the normalised tensor (what SEModule's avg-pool sees).
+ * ws: scratch, 2*B*C doubles (fp64 partial sums). */
+int e4s_instnorm_stats_f32(const float* x, float* stats, float* pooled, double* ws, int B, int HW, int C,
+                           float eps, void* stream);
+/* y = ((x - mean)*rstd) [* gate[b,c]] [+ res[b, (y*rs)*Wr + x*rs, c]] ; optional PReLU(slope[c]) last.
+ * res is NHWC [B, H*rs, W*rs, C] sampled at stride rs (MaxPool2d(1, stride), helpers.py:125-126). */
+int e4s_instnorm_apply_f32(const float* x, const float* stats, const float* gate, const float* res,
+                           const float* res_stats, const float* slope, float* y,
+                           int B, int H, int W, int C, int rs, void* stream);
+/* SE gate (helpers.py:56-72): gate[b,c] = sigmoid(fc2 . relu(fc1 . pooled[b]))  */
+int e4s_se_gate_f32(const float* pooled, const float* fc1, const float* fc2, float* gate,
+                    int B, int C, int Cr, void* stream);
+/* regional average pooling (psp_encoders.py:264-283): out[b, r, out_off + c] = mean over pixels with
+ * label r of feats[b, p, c]; exact 0 for empty regions.  feats NHWC [B,H,W,C]. */
+int e4s_region_mean_f32(const float* feats, const uint8_t* labels, int Hm, int Wm, float* out,
+                        int B, int H, int W, int C, int R, int out_stride, int out_off, void* stream);
+/* LocalMLP layer (networks.py:15-39): y[b, r, o] = act(sum_i x[b, r, i]*W[r][o, i]*scale + bias[r][o]) [+ add[o]]
+ * W is [R][O][K] (stacked EqualLinear weights); act: 0 none, 1 leaky(alpha). */
+int e4s_grouped_linear_f32(const float* x, const float* W, const float* bias, const float* add, float* y,
+                           int B, int R, int K, int O, float scale, int act, float alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E4S_HIP_H */

@@ -1,0 +1,329 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libe4s_hip.so) against the CPU oracle and the
+golden fixtures produced by the real reference.  Tolerance: BASELINE.json north_star states 1e-3
+max-abs on the 1024^2 outputs; the kernels compute in exact fp32 (v_mfma_f32_32x32x2_f32), so the
+op/layer tests use much tighter bounds (written next to each assert)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from e4s_amd import synth
+from oracle import e4s_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def maxabs(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# operators (1:1 with the reference's native ops)
+# ---------------------------------------------------------------------------------------------
+def test_ops_golden(golden):
+    from e4s_amd.op import fused_leaky_relu, upfirdn2d
+    g = golden("ops.pt")
+    for case in g["kat"] + g["rand"]:
+        if case["op"] == "upfirdn2d":
+            y = upfirdn2d(case["x"].to(DEV), case["k"].to(DEV), up=case["up"], down=case["down"], pad=case["pad"])
+        else:
+            y = fused_leaky_relu(case["x"].to(DEV), case["b"].to(DEV))
+        assert y.shape == case["y"].shape
+        assert maxabs(y, case["y"]) < 2e-6, case["op"]
+
+
+def test_fused_bias_act_all_modes():
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(0)
+    for shape in [(2, 5, 7, 3), (3, 8, 16, 16), (4, 6), (1, 32, 64, 64)]:
+        x = torch.randn(*shape, generator=g)
+        b = torch.randn(shape[1], generator=g)
+        ref = torch.randn(*shape, generator=g)
+        for act, grad in [(1, 0), (1, 1), (1, 2), (3, 0), (3, 1), (3, 2)]:
+            want = orc.fused_bias_act(x, b, ref, act, grad, 0.2, 1.5)
+            got = K.fused_bias_act(x.to(DEV), b.to(DEV), ref.to(DEV), act, grad, 0.2, 1.5)
+            assert maxabs(got, want) < 1e-6, (shape, act, grad)
+        want = orc.fused_bias_act(x, None, ref, 3, 1, 0.2, 2 ** 0.5)
+        got = K.fused_bias_act(x.to(DEV), None, ref.to(DEV), 3, 1, 0.2, 2 ** 0.5)
+        assert maxabs(got, want) < 1e-6
+
+
+def test_ops_backward_matches_oracle_autograd():
+    from e4s_amd.op import fused_leaky_relu, upfirdn2d
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 6, 9, 11, generator=g)
+    b = torch.randn(6, generator=g)
+    k = orc.make_blur_kernel() * 4
+    for fn_dev, fn_ref in [
+        (lambda t, bb: fused_leaky_relu(t, bb), lambda t, bb: orc.fused_leaky_relu(t, bb)),
+        (lambda t, bb: upfirdn2d(t, k.to(DEV), up=2, pad=(2, 1)) * bb.view(1, -1, 1, 1),
+         lambda t, bb: orc.upfirdn2d(t, k, up=2, pad=(2, 1)) * bb.view(1, -1, 1, 1)),
+        (lambda t, bb: upfirdn2d(t, k.to(DEV), down=2, pad=(1, 1)) * bb.view(1, -1, 1, 1),
+         lambda t, bb: orc.upfirdn2d(t, k, down=2, pad=(1, 1)) * bb.view(1, -1, 1, 1)),
+    ]:
+        xd, bd = x.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yd, yr = fn_dev(xd, bd), fn_ref(xr, br)
+        w = torch.randn(yr.shape, generator=g)
+        (yd * w.to(DEV)).sum().backward()
+        (yr * w).sum().backward()
+        assert maxabs(yd, yr) < 1e-5
+        assert maxabs(xd.grad, xr.grad) < 1e-5
+        assert maxabs(bd.grad, br.grad) < 1e-4
+
+
+def test_upfirdn2d_large_matches_oracle():
+    from e4s_amd.op import upfirdn2d
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 4, 257, 257, generator=g)
+    k = orc.make_blur_kernel() * 4
+    assert maxabs(upfirdn2d(x.to(DEV), k.to(DEV), pad=(1, 1)), orc.upfirdn2d(x, k, pad=(1, 1))) < 1e-5
+    x = torch.randn(2, 3, 128, 128, generator=g)
+    assert maxabs(upfirdn2d(x.to(DEV), k.to(DEV), up=2, pad=(2, 1)), orc.upfirdn2d(x, k, up=2, pad=(2, 1))) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# the MFMA conv kernel against plain fp32 convolution
+# ---------------------------------------------------------------------------------------------
+def _pack(w):
+    cout, cin, kh, kw = w.shape
+    return w.permute(2, 3, 0, 1).reshape(1, kh * kw, cout, cin).contiguous()
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,stride,spatial", [
+    (2, 16, 16, 64, 128, 1, True), (2, 16, 16, 64, 128, 1, False), (1, 32, 32, 32, 64, 1, True),
+    (1, 32, 32, 64, 32, 1, True), (1, 32, 32, 64, 32, 1, False), (2, 32, 32, 64, 64, 2, False),
+    (1, 16, 32, 96, 160, 1, True), (1, 64, 64, 128, 256, 2, False),
+])
+def test_conv_mfma_vs_conv2d(b, h, w, cin, cout, stride, spatial):
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    want = F.conv2d(x, wt, stride=stride, padding=1)
+    y = K.conv_mfma(K.nchw_to_nhwc(x.to(DEV)), _pack(wt).to(DEV), cout, istride=stride, spatial=spatial)
+    assert maxabs(K.nhwc_to_nchw(y), want) < 2e-5
+
+
+def test_conv_mfma_1x1_stride2_and_prelu():
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 64, 32, 32, generator=g)
+    wt = torch.randn(128, 64, 1, 1, generator=g) / 8
+    y = K.conv_mfma(K.nchw_to_nhwc(x.to(DEV)), _pack(wt).to(DEV), 128, istride=2, ntaps=1)
+    assert maxabs(K.nhwc_to_nchw(y), F.conv2d(x, wt, stride=2)) < 2e-5
+    w3 = torch.randn(64, 64, 3, 3, generator=g) / 24
+    slope = torch.rand(64, generator=g)
+    y = K.conv_mfma(K.nchw_to_nhwc(x.to(DEV)), _pack(w3).to(DEV), 64, act=2, slope=slope.to(DEV))
+    assert maxabs(K.nhwc_to_nchw(y), F.prelu(F.conv2d(x, w3, padding=1), slope)) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# generator layers against the oracle
+# ---------------------------------------------------------------------------------------------
+def _styled_sd(cin, cout, up, seed):
+    spec = [("conv.weight", (1, cout, cin, 3, 3), "randn"), ("conv.modulation.weight", (cin, 512), "randn"),
+            ("conv.modulation.bias", (cin,), "modbias"), ("noise.weight", (1,), "noisew"),
+            ("activate.bias", (cout,), "bias")]
+    sd = {k: synth.synth_tensor(k, s, kind, seed) for k, s, kind in spec}
+    if up:
+        sd["conv.blur.kernel"] = orc.make_blur_kernel() * 4
+    return sd
+
+
+@pytest.mark.parametrize("cin,cout,res,up", [(512, 512, 16, False), (512, 512, 8, True), (256, 128, 16, True),
+                                              (64, 32, 32, False), (128, 64, 16, True)])
+def test_modulated_conv_vs_oracle(cin, cout, res, up):
+    from e4s_amd.stylegan2 import ModulatedConv2d
+    sd = _styled_sd(cin, cout, up, 11)
+    m = ModulatedConv2d(cin, cout, 3, 512, upsample=up)
+    m.load_state_dict({k[5:]: v for k, v in sd.items() if k.startswith("conv.")})
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, cin, res, res, generator=g)
+    style = torch.randn(2, 512, generator=g)
+    want = orc.modulated_conv2d(x, style, sd["conv.weight"], sd["conv.modulation.weight"],
+                                sd["conv.modulation.bias"], True, up)
+    got = m(x.to(DEV), style.to(DEV))
+    assert got.shape == want.shape
+    assert maxabs(got, want) < 5e-5          # fp32 both sides, different summation order
+
+
+@pytest.mark.parametrize("cin,cout,res,up,cells", [(512, 512, 16, False, 16), (512, 512, 8, True, 4),
+                                                    (256, 256, 32, False, 8), (512, 256, 16, True, 32)])
+def test_styled_conv_masked_vs_oracle(cin, cout, res, up, cells):
+    """Region-select (one gathered GEMM) == the reference's 12 passes x one-hot mask."""
+    from e4s_amd.stylegan2 import StyledConv
+    sd = _styled_sd(cin, cout, up, 12)
+    m = StyledConv(cin, cout, 3, 512, upsample=up, mask_op=True)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(6)
+    b = 2
+    x = torch.randn(b, cin, res, res, generator=g)
+    style = torch.randn(b, 12, 512, generator=g)
+    mask = synth.onehot(synth.synth_labels_blocks(b, 512, cells, seed=7))
+    out_res = res * 2 if up else res
+    noise = torch.randn(b, 1, out_res, out_res, generator=g)
+    want = orc.styled_conv(sd, "", x, style, mask, noise, up, True)
+    got = m(x.to(DEV), style.to(DEV), mask.to(DEV), noise=noise.to(DEV))
+    assert maxabs(got, want) < 5e-5
+
+
+def test_styled_conv_per_channel_noise_and_unmasked():
+    from e4s_amd.stylegan2 import StyledConv
+    sd = _styled_sd(64, 64, False, 13)
+    m = StyledConv(64, 64, 3, 512, mask_op=False)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 64, 32, 32, generator=g)
+    style = torch.randn(2, 512, generator=g)
+    noise = torch.randn(1, 64, 32, 32, generator=g)             # scripts/face_edit.py:49-52
+    want = orc.styled_conv(sd, "", x, style, None, noise, False, False)
+    got = m(x.to(DEV), style.to(DEV), None, noise=noise.to(DEV))
+    assert maxabs(got, want) < 5e-5
+
+
+@pytest.mark.parametrize("cin,res,masked,with_skip", [(512, 8, True, True), (128, 32, False, True),
+                                                       (32, 64, False, True), (512, 4, True, False)])
+def test_torgb_vs_oracle(cin, res, masked, with_skip):
+    from e4s_amd.stylegan2 import ToRGB
+    spec = [("bias", (1, 3, 1, 1), "bias"), ("conv.weight", (1, 3, cin, 1, 1), "randn"),
+            ("conv.modulation.weight", (cin, 512), "randn"), ("conv.modulation.bias", (cin,), "modbias")]
+    sd = {k: synth.synth_tensor(k, s, kind, 3) for k, s, kind in spec}
+    m = ToRGB(cin, 512, upsample=with_skip, mask_op=masked)
+    if with_skip:
+        sd["upsample.kernel"] = orc.make_blur_kernel() * 4
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, cin, res, res, generator=g)
+    style = torch.randn(2, 12, 512, generator=g) if masked else torch.randn(2, 512, generator=g)
+    mask = synth.onehot(synth.synth_labels_blocks(2, 512, 8, seed=4))
+    skip = torch.randn(2, 3, res // 2, res // 2, generator=g) if with_skip else None
+    want = orc.to_rgb(sd, "", x, style, mask, skip, masked)
+    got = m(x.to(DEV), style.to(DEV), mask.to(DEV), None if skip is None else skip.to(DEV))
+    assert maxabs(got, want) < 5e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# encoder pieces against the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,depth,stride,res", [(64, 128, 2, 64), (128, 128, 1, 32), (512, 512, 2, 32)])
+def test_encoder_unit_vs_oracle(cin, depth, stride, res):
+    from e4s_amd.encoders import bottleneck_IR_SE_Ours
+    spec = [("res_layer.1.weight", (depth, cin, 3, 3), "conv"), ("res_layer.2.weight", (depth,), "prelu"),
+            ("res_layer.3.weight", (depth, depth, 3, 3), "conv"),
+            ("res_layer.5.fc1.weight", (depth // 16, depth, 1, 1), "conv"),
+            ("res_layer.5.fc2.weight", (depth, depth // 16, 1, 1), "conv")]
+    if cin != depth:
+        spec.append(("shortcut_layer.0.weight", (depth, cin, 1, 1), "conv"))
+    sd = {k: synth.synth_tensor(k, s, kind, 5) for k, s, kind in spec}
+    m = bottleneck_IR_SE_Ours(cin, depth, stride)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    x = torch.randn(2, cin, res, res, generator=torch.Generator().manual_seed(10)) * 1.7 + 0.3
+    want = orc.encoder_unit(sd, "", x, cin, depth, stride)
+    assert maxabs(m(x.to(DEV)), want) < 5e-5
+
+
+def test_region_mean_exact_zero_for_empty_regions():
+    from e4s_amd.encoders import FSEncoder_PSP
+    with torch.device("meta"):
+        enc = FSEncoder_PSP()
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(2, 256, 64, 64, generator=g)
+    lab = synth.synth_labels_face(2, 512, seed=5)
+    lab[lab == 9] = 1                                           # region 9 (teeth) empty
+    mask = synth.onehot(lab)
+    want = orc.region_mean(feats, mask)
+    got = enc.get_per_comp_styleCode(feats.to(DEV), mask.to(DEV))
+    assert maxabs(got, want) < 1e-5
+    assert float(got[:, 9].abs().max()) == 0.0                  # face_swap.py:132,136 test `sum == 0`
+
+
+# ---------------------------------------------------------------------------------------------
+# Net3 end-to-end against the golden fixtures of the REAL reference
+# ---------------------------------------------------------------------------------------------
+def _net(out_size):
+    from e4s_amd.networks import Net3
+    from e4s_amd.options import make_opts
+    net = Net3(make_opts(out_size=out_size))
+    net.load_state_dict(synth.synth_state_dict(out_size, 13), strict=True)
+    net.latent_avg = synth.synth_latent_avg(out_size).to(DEV)
+    return net.to(DEV).eval()
+
+
+def _swap_inputs(mask_kind):
+    driven = synth.synth_image(1, 1024, tag="driven")
+    target = synth.synth_image(1, 1024, tag="target")
+    mk = synth.synth_labels_face if mask_kind == "face" else (lambda b, s, seed: synth.synth_labels_blocks(b, s, 64, seed=seed))
+    dm, tm, sm = (synth.onehot(mk(1, 512, seed=s)) for s in (1, 2, 3))
+    return driven, target, dm, tm, sm
+
+
+@torch.no_grad()
+def test_net256_swap_vs_golden(golden):
+    from e4s_amd.networks import swap_comp_style_vector
+    g = golden("net256.pt")
+    net = _net(256)
+    driven, target, dm, tm, sm = _swap_inputs("blocks")
+    d_sv, struct = net.get_style_vectors(driven.to(DEV), dm.to(DEV))
+    t_sv, _ = net.get_style_vectors(target.to(DEV), tm.to(DEV))
+    assert tuple(struct.shape) == (1, 512, 16, 16) and float(struct.abs().max()) == 0.0
+    assert maxabs(d_sv, g["driven_sv"]) < 1e-4
+    assert maxabs(t_sv, g["target_sv"]) < 1e-4
+    sv = swap_comp_style_vector(t_sv, d_sv, set(range(12)) - {0, 4, 11, 10})
+    assert maxabs(sv, g["swapped_sv"]) < 1e-4
+    codes = net.cal_style_codes(g["swapped_sv"].to(DEV))
+    assert tuple(codes.shape) == (1, 12, 14, 512)
+    assert maxabs(codes[:, :, :, ::8], g["codes_stride"]) < 1e-4
+    noise = [n.to(DEV) for n in synth.synth_noise(256)]
+    img, minus1, feats = net.gen_img(torch.zeros(1, 512, 32, 32, device=DEV), codes, sm.to(DEV), noise=noise)
+    assert minus1 == -1 and tuple(img.shape) == (1, 3, 256, 256) and tuple(feats.shape) == (1, 512, 16, 16)
+    assert maxabs(feats[:, ::4], g["feats_stride"]) < 1e-3
+    assert maxabs(img, g["img"]) < 1e-3                          # north_star tolerance
+
+
+@torch.no_grad()
+def test_net1024_swap_vs_golden(golden):
+    """BASELINE.json configs[1]: single 1024^2 face swap, against the real reference's output."""
+    from e4s_amd.networks import face_swap_core
+    g = golden("net1024.pt")
+    net = _net(1024)
+    driven, target, dm, tm, sm = _swap_inputs("face")
+    noise = [n.to(DEV) for n in synth.synth_noise(1024)]
+    img = face_swap_core(net, driven.to(DEV), dm.to(DEV), target.to(DEV), tm.to(DEV), sm.to(DEV), noise=noise)
+    assert tuple(img.shape) == (1, 3, 1024, 1024)
+    assert maxabs(img[:, :, ::8, ::8], g["img_stride8"]) < 1e-3
+    c0 = 512 - 64
+    assert maxabs(img[:, :, c0:c0 + 128, c0:c0 + 128], g["img_crop"]) < 1e-3
+    assert maxabs(img.mean((2, 3)), g["img_mean"]) < 1e-4
+    assert maxabs(img.abs().mean((2, 3)), g["img_absmean"]) < 1e-4
+
+
+@torch.no_grad()
+def test_gen1024_properties_batch_and_region_relabel():
+    """Size-independent properties at the full 1024^2 size (no oracle needed):
+    (1) a batch of 2 equals two batches of 1 bit-for-bit per sample (row order inside the gathered GEMM
+        must not matter); (2) relabelling regions (permute mask channels and the style rows the same
+        way) leaves the image unchanged -- region-select depends on the label only through its style."""
+    net = _net(1024)
+    g = torch.Generator().manual_seed(21)
+    codes = (torch.randn(2, 12, 18, 512, generator=g) * 0.3).to(DEV)
+    codes[:, :, 13:] = codes[:, :1, 13:]                         # layers >= K share one code (networks.py:152-154)
+    lab = torch.cat([synth.synth_labels_face(1, 512, seed=8), synth.synth_labels_blocks(1, 512, 32, seed=9)], 0)
+    mask = synth.onehot(lab).to(DEV)
+    noise = [n.to(DEV) for n in synth.synth_noise(1024, batch=2)]
+    img, _, _ = net.gen_img(None, codes, mask, noise=noise)
+    for i in range(2):
+        one, _, _ = net.gen_img(None, codes[i:i + 1], mask[i:i + 1], noise=[n[i:i + 1] for n in noise])
+        assert torch.equal(one[0], img[i])
+    perm = torch.randperm(11, generator=g) + 1                  # keep region 0 (used by unmasked layers) fixed
+    perm = torch.cat([torch.zeros(1, dtype=torch.long), perm])
+    img2, _, _ = net.gen_img(None, codes[:, perm].contiguous(), mask[:, perm].contiguous(), noise=noise)
+    assert torch.equal(img2, img)
+    assert bool(torch.isfinite(img).all())
