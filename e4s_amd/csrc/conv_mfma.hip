@@ -304,7 +304,7 @@ int launch(const e4s_conv_params& p, hipStream_t st) {
         mtiles = p.tiles_cap;
     } else {
         const int64_t anchors = (int64_t)p.B * p.Ha * p.Wa;
-        if (anchors % BM) return (int)hipErrorInvalidValue;
+        if (((int64_t)p.Ha * p.Wa) % BM) return (int)hipErrorInvalidValue;   // a tile never straddles two samples
         tiles_per_cls = (int)(anchors / BM);
         mtiles = tiles_per_cls * p.ncls;
     }

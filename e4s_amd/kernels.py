@@ -187,6 +187,9 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
         anchors = (hi // istride, wi // istride)
     ha, wa = anchors
     ho, wo = ha * ostride, wa * ostride
+    if plan is None and (ha * wa) % BM != 0:
+        # natural-order tiles must not straddle samples: tiny grids go through a trivial one-region plan
+        plan = region_plan(torch.zeros(b, 1, 1, device=x.device, dtype=torch.uint8), 1, ha, wa, ncls)
     y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32)
     p = ConvParams()
     p.x, p.w, p.y = fptr(x), fptr(w), fptr(y)
