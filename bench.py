@@ -55,7 +55,6 @@ def headline_probe(net, batch, mask, reps):
     x = torch.randn(batch, 64, 64, 512, generator=g).to(dev)
     lat = (torch.randn(batch, 12, 18, 512, generator=g) * 0.5).to(dev)
     labels, _ = K.mask_labels(mask)
-    plan = K.region_plan(labels, 12, 64, 64, 1)
     mod = layer.conv.modulation
     s = K.modulate(lat, 8, True, mod.weight, mod.bias)
     pk = layer.conv.packed()
@@ -63,8 +62,8 @@ def headline_probe(net, batch, mask, reps):
     nz = torch.randn(batch, 1, 64, 64, generator=g).to(dev)
 
     def run():
-        return K.conv_mfma(x, pk["w"], 512, plan=plan, in_scale=s, out_scale=d, noise=nz, noise_w=layer.noise.weight,
-                           bias=layer.activate.bias, act=1)
+        return K.conv_mfma(x, pk["w"], 512, labels=labels, num_regions=12, in_scale=s, out_scale=d, noise=nz,
+                           noise_w=layer.noise.weight, bias=layer.activate.bias, act=1)
     for _ in range(3):
         run()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -84,7 +83,7 @@ def headline_probe(net, batch, mask, reps):
             traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": "conv_mfma_kernel<128,128,2,2,gather> ModulatedConv2d(512,512,3)@64x64 x%d img" % batch,
+    return {"bound": "mfma", "kernel": "conv_mfma_kernel<128,128,2,2,spatial> ModulatedConv2d(512,512,3)@64x64 masked, x%d img" % batch,
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic, "avg_launch_ms": round(ms, 4), "flop_per_launch": flops}
 
@@ -92,7 +91,7 @@ def headline_probe(net, batch, mask, reps):
 def cpu_baseline(sd, lat, inputs, hip_img0):
     """One swap (sample 0 of the bench batch) on the host cores with the CPU oracle."""
     from oracle import e4s_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)      # oneDNN at 1024^2 B=1 stops scaling (and oversubscribes) beyond this
     torch.set_num_threads(cores)
     driven, dm, target, tm, sm, noise = [t[:1].cpu() if torch.is_tensor(t) else [n[:1].cpu() for n in t] for t in inputs]
     with torch.no_grad():

@@ -2,9 +2,13 @@
 // (v_mfma_f32_32x32x2_f32: exact f32, 157.3 TFLOP/s chip peak).
 //
 // One kernel serves every contraction on the E4S hot path:
-//   * generator StyledConv, masked   : GEMM rows are OUTPUT PIXELS GATHERED BY REGION (plan mode):
-//     every pixel is computed once, with the style of its own region, instead of the
-//     reference's 12 full passes + mask multiply (model.py:386-400)
+//   * generator StyledConv, masked   : REGION-SELECT AT FRAGMENT LEVEL (spatial mode + label map):
+//     every output pixel is one GEMM row whose A fragment is scaled, on its way into the MFMA, by
+//     the style s[region(pixel)][ci] of that pixel's own region, and whose accumulator is
+//     demodulated with d[region(pixel)][co] -- every pixel is computed once instead of the
+//     reference's 12 full passes + one-hot mask multiply (model.py:386-400), with no padding and
+//     no dependence on the mask geometry.  (A region-gathered row plan, `plan` mode, is kept as a
+//     second, independently tested formulation.)
 //   * generator up-conv              : conv_transpose2d(stride 2) (*) 4x4 blur (model.py:287-300)
 //     folded into 4 phase-specific 3x3 kernels over the input grid (ncls = 4)
 //   * generator StyledConv, unmasked : natural order, halo-tiled loader (SPATIAL)
@@ -32,7 +36,9 @@ struct SmemLayout {
     static constexpr int META_WORDS = 4 * BM;
     static constexpr int A_WORDS = SPATIAL ? HALO * LDA : 2 * BM * LDA;
     static constexpr int B_WORDS = 2 * BN * LDA;
-    static constexpr int BYTES = (META_WORDS + A_WORDS + B_WORDS) * 4;
+    static constexpr int MAXR = 16;                                   // regions per sample (spatial mode)
+    static constexpr int S_WORDS = SPATIAL ? MAXR * LDA : 0;          // style chunk s[r][32] of the current K step
+    static constexpr int BYTES = (META_WORDS + A_WORDS + B_WORDS + S_WORDS) * 4;
 };
 
 template <int BM, int BN, int WM, int WN, bool SPATIAL>
@@ -51,6 +57,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     int* s_yx = s_base + BM;
     float* sA = reinterpret_cast<float*>(s_yx + BM);
     float* sB = sA + L::A_WORDS;
+    float* sS = sB + L::B_WORDS;
+    int* s_grp = s_base;                 // spatial mode: region index of each row (s_base is gather-only)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
         cls = mt / tiles_per_cls;
         tt = mt - cls * tiles_per_cls;
         if (SPATIAL) {
-            const int tx_n = p.Wa / TW, per_img = (p.Ha / TH) * tx_n;
+            const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + TH - 1) / TH) * tx_n;
             tb = tt / per_img;
             const int rem = tt - tb * per_img;
             tyb = rem / tx_n;
@@ -92,6 +100,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
             b = tb;
             ay = tyb * TH + tid / TW;
             ax = txb * TW + tid % TW;
+            valid = ay < p.Ha && ax < p.Wa;
         } else {
             const int anchor = plan ? p.rows[row_start + tid] : tt * BM + tid;
             valid = anchor >= 0;
@@ -110,7 +119,17 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
             else if (p.noise_per_channel) s_nz[tid] = __int_as_float((int)npix);
             else s_nz[tid] = p.noise_w[0] * p.noise[npix];
             const int by = ay * p.istride, bx = ax * p.istride;
-            s_base[tid] = (b * p.Hi + by) * p.Wi + bx;
+            if (SPATIAL) {
+                int r = 0;
+                if (p.labels) {   // legacy-nearest lookup of the OUTPUT pixel (F.interpolate 'nearest', model.py:391)
+                    const int sy = min((int)floorf((float)oy * ((float)p.Hm / (float)p.Ho)), p.Hm - 1);
+                    const int sx = min((int)floorf((float)ox * ((float)p.Wm / (float)p.Wo)), p.Wm - 1);
+                    r = p.labels[((size_t)b * p.Hm + sy) * p.Wm + sx];
+                }
+                s_grp[tid] = r;
+            } else {
+                s_base[tid] = (b * p.Hi + by) * p.Wi + bx;
+            }
             s_yx[tid] = (by << 16) | bx;
         } else {
             s_out[tid] = -1;
@@ -131,7 +150,13 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
             a_yx[j] = s_yx[r0 + 32 * j];
         }
     }
-    const float* sscale = p.in_scale ? p.in_scale + (size_t)g * p.Cin : nullptr;
+    const int R = SPATIAL ? (p.labels ? p.groups_per_batch : 1) : 1;
+    const bool scaled = p.in_scale != nullptr;
+    // gather: tile-uniform group, style folded into the B tile while staging.
+    // spatial: per-row region, style applied to the A fragment; the K-step slice of the table lives in LDS.
+    const float* sscale = (!SPATIAL && scaled) ? p.in_scale + (size_t)g * p.Cin : nullptr;
+    const float* stable = (SPATIAL && scaled) ? p.in_scale + (size_t)tb * R * p.Cin : nullptr;
+    f32x4 ps = {1.f, 1.f, 1.f, 1.f};
 
     f32x4 pa[PA], pb[BR];
     const int ntaps = p.ntaps, nchunk = p.Cin / KC, nstage = nchunk * ntaps;
@@ -170,6 +195,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
             pa[j] = v;
         }
     };
+    auto fetch_s = [&](int c0) {
+        if (stable && tid < R * 8) ps = *reinterpret_cast<const f32x4*>(stable + (size_t)(tid >> 3) * p.Cin + c0 + c4);
+    };
+    auto store_s = [&]() {
+        if (stable && tid < R * 8) *reinterpret_cast<f32x4*>(sS + (tid >> 3) * LDA + c4) = ps;
+    };
     auto store_b = [&](int buf) {
         float* d = sB + buf * (BN * LDA) + r0 * LDA + c4;
 #pragma unroll
@@ -190,11 +221,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     };
 
     // ---- fragment addressing ---------------------------------------------------------
-    int arow[TM], brow[TN];
+    int arow[TM], brow[TN], srow[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int m = (wm * TM + tm) * 32 + li;
         arow[tm] = SPATIAL ? ((m / TW) * HALO_W + (m % TW)) * LDA : m * LDA;
+        srow[tm] = SPATIAL ? s_grp[m] * LDA : 0;
     }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) brow[tn] = ((wn * TN + tn) * 32 + li) * LDA;
@@ -209,9 +241,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
 
     // ---- prologue: stage 0 -----------------------------------------------------------
     fetch_b(0, 0);
-    if (SPATIAL) fetch_a_halo(0); else fetch_a_gather(0, 0);
+    if (SPATIAL) { fetch_a_halo(0); fetch_s(0); } else fetch_a_gather(0, 0);
     store_b(0);
     store_a(0);
+    if (SPATIAL) store_s();
     __syncthreads();
 
     int tap = 0, c0 = 0;
@@ -222,7 +255,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
         const bool new_chunk = (ntap == 0);
         if (more) {
             fetch_b(ntap, nc0);
-            if (SPATIAL) { if (new_chunk) fetch_a_halo(nc0); } else fetch_a_gather(ntap, nc0);
+            if (SPATIAL) { if (new_chunk) { fetch_a_halo(nc0); fetch_s(nc0); } } else fetch_a_gather(ntap, nc0);
         }
         // ---- MFMAs on stage s ----
         {
@@ -236,6 +269,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
                 for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(Ab + arow[tm] + kk * 8 + kh * 4);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(Bb + brow[tn] + kk * 8 + kh * 4);
+                if (SPATIAL && scaled) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) a[tm] *= *reinterpret_cast<const f32x4*>(sS + srow[tm] + kk * 8 + kh * 4);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -249,6 +286,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
             if (SPATIAL && new_chunk) __syncthreads();   // single A halo buffer: everyone done reading it
             store_b((s + 1) & 1);
             if (!SPATIAL || new_chunk) store_a((s + 1) & 1);
+            if (SPATIAL && new_chunk) store_s();
         }
         __syncthreads();
         tap = ntap;
@@ -256,11 +294,21 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     }
 
     // ---- epilogue: demod * acc + noise + bias, activation, scatter to NHWC ------------
+    // spatial mode: the demodulation coefficient depends on the row's region -> table d[r][n] in LDS
+    // (the A region is free: the loop's last barrier has passed)
+    float* sD = sA;
+    if (SPATIAL && p.out_scale) {
+        for (int t = tid; t < R * BN; t += NTHR) {
+            const int r = t / BN, n = t - r * BN;
+            sD[t] = p.out_scale[((size_t)tb * R + r) * p.Cout + n0 + n];
+        }
+        __syncthreads();
+    }
     float osc[TN], bsv[TN], slp[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int col = n0 + (wn * TN + tn) * 32 + li;
-        osc[tn] = p.out_scale ? p.out_scale[(size_t)g * p.Cout + col] : 1.f;
+        osc[tn] = (!SPATIAL && p.out_scale) ? p.out_scale[(size_t)g * p.Cout + col] : 1.f;
         bsv[tn] = p.bias ? p.bias[col] : 0.f;
         slp[tn] = (p.act == 2) ? p.slope[col] : p.alpha;
     }
@@ -268,6 +316,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     const bool do_act = p.act != 0;
     const bool nz_pc = p.noise && p.noise_per_channel;
     const float nzw = nz_pc ? p.noise_w[0] : 0.f;
+    const bool row_scale = SPATIAL && p.out_scale;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -276,12 +325,15 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
             const int off = s_out[row];
             if (off < 0) continue;
             const float nz = s_nz[row];
+            const float* drow = sD + (row_scale ? s_grp[row] * BN : 0);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                const float nzv = nz_pc ? nzw * p.noise[(size_t)__float_as_int(nz) * p.Cout + n0 + (wn * TN + tn) * 32 + li] : nz;
-                float v = acc[tm][tn][r] * osc[tn] + nzv + bsv[tn];
+                const int ncol = (wn * TN + tn) * 32 + li;
+                const float nzv = nz_pc ? nzw * p.noise[(size_t)__float_as_int(nz) * p.Cout + n0 + ncol] : nz;
+                const float sc = row_scale ? drow[ncol] : osc[tn];
+                float v = acc[tm][tn][r] * sc + nzv + bsv[tn];
                 if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
-                p.y[(size_t)off * p.Cout + n0 + (wn * TN + tn) * 32 + li] = v;
+                p.y[(size_t)off * p.Cout + n0 + ncol] = v;
             }
         }
     }
@@ -302,16 +354,30 @@ int launch(const e4s_conv_params& p, hipStream_t st) {
     int mtiles, tiles_per_cls = 0;
     if (p.tiles) {
         mtiles = p.tiles_cap;
+    } else if (SPATIAL) {
+        tiles_per_cls = p.B * ((p.Ha + L::TH - 1) / L::TH) * ((p.Wa + L::TW - 1) / L::TW);
+        mtiles = tiles_per_cls * p.ncls;
     } else {
-        const int64_t anchors = (int64_t)p.B * p.Ha * p.Wa;
         if (((int64_t)p.Ha * p.Wa) % BM) return (int)hipErrorInvalidValue;   // a tile never straddles two samples
-        tiles_per_cls = (int)(anchors / BM);
+        tiles_per_cls = (int)((int64_t)p.B * p.Ha * p.Wa / BM);
         mtiles = tiles_per_cls * p.ncls;
     }
     if (mtiles <= 0) return 0;
     hipLaunchKernelGGL(kern, dim3(mtiles * ntn), dim3(NTHR), L::BYTES, st, p, ntn, tiles_per_cls);
     E4S_CHECK_LAUNCH();
     return 0;
+}
+
+// Column-tile width: the widest BN that still yields >= 2 blocks per CU (256 CUs); small problems
+// (low resolutions, batch 1) take narrower tiles so the serial K loop of one block is shorter.
+int pick_bn(const e4s_conv_params& p, int64_t mtiles) {
+    const int cands[3] = {128, 64, 32};
+    for (int i = 0; i < 3; ++i) {
+        const int bn = cands[i];
+        if (p.Cout % bn) continue;
+        if (mtiles * (p.Cout / bn) >= 512 || bn == 32) return bn;
+    }
+    return 32;
 }
 
 }  // namespace
@@ -323,12 +389,18 @@ extern "C" int e4s_conv_mfma_f32(const e4s_conv_params* pp, int spatial, void* s
         return (int)hipErrorInvalidValue;
     if (p.Hi >= 32767 || p.Wi >= 32767) return (int)hipErrorInvalidValue;
     if (spatial) {
-        if (p.tiles || p.istride != 1 || p.ntaps != 9 || p.Ha % 8 || p.Wa % 16) return (int)hipErrorInvalidValue;
-        if (p.Cout % 128 == 0) return launch<128, 128, 2, 2, true>(p, st);
-        if (p.Cout % 64 == 0) return launch<128, 64, 2, 2, true>(p, st);
+        if (p.tiles || p.istride != 1 || p.ntaps != 9) return (int)hipErrorInvalidValue;
+        if (p.labels && (p.groups_per_batch < 1 || p.groups_per_batch > 16)) return (int)hipErrorInvalidValue;
+        const int64_t mt = (int64_t)p.B * ((p.Ha + 7) / 8) * ((p.Wa + 15) / 16) * p.ncls;
+        const int bn = pick_bn(p, mt);
+        if (bn == 128) return launch<128, 128, 2, 2, true>(p, st);
+        if (bn == 64) return launch<128, 64, 2, 2, true>(p, st);
         return launch<128, 32, 4, 1, true>(p, st);
     }
-    if (p.Cout % 128 == 0) return launch<128, 128, 2, 2, false>(p, st);
-    if (p.Cout % 64 == 0) return launch<128, 64, 2, 2, false>(p, st);
+    if (p.labels) return (int)hipErrorInvalidValue;     // per-row regions exist only in spatial mode
+    const int64_t mt = p.tiles ? p.tiles_cap : (int64_t)p.B * p.Ha * p.Wa / 128 * p.ncls;
+    const int bn = pick_bn(p, mt);
+    if (bn == 128) return launch<128, 128, 2, 2, false>(p, st);
+    if (bn == 64) return launch<128, 64, 2, 2, false>(p, st);
     return launch<128, 32, 4, 1, false>(p, st);
 }

@@ -178,7 +178,7 @@ def region_plan(labels, num_regions, ha, wa, nphase):
 # ---- the conv --------------------------------------------------------------------------------
 def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, in_scale=None, out_scale=None,
               noise=None, noise_w=None, noise_per_channel=False, bias=None, slope=None, act=0, alpha=0.2,
-              gain=LRELU_GAIN, spatial=None, anchors=None):
+              gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1):
     """x NHWC [B,Hi,Wi,Cin]; w [ncls, ntaps, Cout, Cin] -> y NHWC [B,Ho,Wo,Cout].
     anchors = (Ha, Wa); defaults: up-conv (ncls=4) anchors = input grid, output 2x;
     strided conv anchors = output grid."""
@@ -187,7 +187,11 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
         anchors = (hi // istride, wi // istride)
     ha, wa = anchors
     ho, wo = ha * ostride, wa * ostride
-    if plan is None and (ha * wa) % BM != 0:
+    if spatial is None:
+        spatial = plan is None and istride == 1 and ntaps == 9
+    if labels is not None and not spatial:
+        raise RuntimeError("per-pixel region labels need the spatial (halo-tiled) mode")
+    if plan is None and not spatial and (ha * wa) % BM != 0:
         # natural-order tiles must not straddle samples: tiny grids go through a trivial one-region plan
         plan = region_plan(torch.zeros(b, 1, 1, device=x.device, dtype=torch.uint8), 1, ha, wa, ncls)
     y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32)
@@ -199,7 +203,11 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     else:
         p.rows = p.tiles = p.meta = None
         p.tiles_cap = 0
-        p.groups_per_batch = 1
+        p.groups_per_batch = num_regions if labels is not None else 1
+    if labels is not None:
+        p.labels, p.Hm, p.Wm = ptr(labels), labels.shape[1], labels.shape[2]
+    else:
+        p.labels, p.Hm, p.Wm = None, 0, 0
     p.B, p.Ha, p.Wa = b, ha, wa
     p.Hi, p.Wi, p.Ho, p.Wo, p.Cin, p.Cout = hi, wi, ho, wo, cin, cout
     p.istride, p.ostride, p.ntaps, p.ncls = istride, ostride, ntaps, ncls
@@ -214,8 +222,6 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
         p.noise_per_channel = 0
     p.bias, p.slope = fptr(bias), fptr(slope)
     p.act, p.alpha, p.gain = act, alpha, gain
-    if spatial is None:
-        spatial = plan is None and istride == 1 and ntaps == 9 and ha % 8 == 0 and wa % 16 == 0
     call("e4s_conv_mfma_f32", ctypes.byref(p), 1 if spatial else 0, stream())
     return y
 

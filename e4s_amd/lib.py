@@ -29,6 +29,7 @@ class ConvParams(ctypes.Structure):
         ("Hi", c_i), ("Wi", c_i), ("Ho", c_i), ("Wo", c_i), ("Cin", c_i), ("Cout", c_i),
         ("istride", c_i), ("ostride", c_i), ("ntaps", c_i), ("ncls", c_i),
         ("in_scale", c_p), ("out_scale", c_p), ("groups_per_batch", c_i),
+        ("labels", c_p), ("Hm", c_i), ("Wm", c_i),
         ("noise", c_p), ("noise_w", c_p), ("noise_bstride", c_l), ("noise_per_channel", c_i),
         ("bias", c_p), ("slope", c_p), ("act", c_i), ("alpha", c_f), ("gain", c_f),
     ]

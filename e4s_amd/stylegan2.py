@@ -263,22 +263,25 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
         self.mask_op = mask_op
 
-    def run_nhwc(self, x, s, plan, noise):
-        """x NHWC, s [G,Cin] modulation; plan: RowPlan (masked) or None.  Returns NHWC output after
-        noise + bias + leaky-ReLU*sqrt(2)."""
+    def run_nhwc(self, x, s, noise, labels=None, num_regions=1, plan=None):
+        """x NHWC, s [G,Cin] modulation (G = B*R when masked).  Masked layers pass the label map
+        (region-select inside the GEMM) or, alternatively, a gathered RowPlan.  Returns NHWC output
+        after noise + bias + leaky-ReLU*sqrt(2)."""
         conv = self.conv
         pk = conv.packed()
         b, h, w, _ = x.shape
         ho, wo = (2 * h, 2 * w) if conv.upsample else (h, w)
         d = K.demod_coefs(s, pk["wsq"], conv.scale)
         nz, per_ch = _prep_noise(noise, b, ho, wo, x.device)
-        return K.conv_mfma(x, pk["w"], conv.out_channel, plan=plan, ncls=4 if conv.upsample else 1,
+        return K.conv_mfma(x, pk["w"], conv.out_channel, plan=plan, labels=None if plan is not None else labels,
+                           num_regions=num_regions, ncls=4 if conv.upsample else 1,
                            ostride=2 if conv.upsample else 1, in_scale=s, out_scale=d, noise=nz,
                            noise_w=self.noise.weight, noise_per_channel=per_ch, bias=self.activate.bias, act=1,
                            alpha=self.activate.negative_slope, gain=self.activate.scale)
 
-    def forward(self, input, style, mask, noise=None):
-        """Drop-in NCHW forward.  style [B,R,512] + one-hot mask when mask_op else [B,512]."""
+    def forward(self, input, style, mask, noise=None, use_plan=False):
+        """Drop-in NCHW forward.  style [B,R,512] + one-hot mask when mask_op else [B,512].
+        use_plan=True selects the region-gathered row plan instead of in-GEMM region-select."""
         x = K.nchw_to_nhwc(input)
         b, h, w, _ = x.shape
         mod = self.conv.modulation
@@ -286,11 +289,10 @@ class StyledConv(nn.Module):
             r = style.shape[1]
             s = K.modulate_vec(style.reshape(b * r, -1), mod.weight, mod.bias)
             labels, _ = K.mask_labels(mask)
-            plan = K.region_plan(labels, r, h, w, 4 if self.conv.upsample else 1)
-        else:
-            s = K.modulate_vec(style, mod.weight, mod.bias)
-            plan = None
-        return K.nhwc_to_nchw(self.run_nhwc(x, s, plan, noise))
+            plan = K.region_plan(labels, r, h, w, 4 if self.conv.upsample else 1) if use_plan else None
+            return K.nhwc_to_nchw(self.run_nhwc(x, s, noise, labels, r, plan))
+        s = K.modulate_vec(style, mod.weight, mod.bias)
+        return K.nhwc_to_nchw(self.run_nhwc(x, s, noise))
 
 
 class ToRGB(nn.Module):
@@ -424,22 +426,11 @@ class Generator(nn.Module):
         lat = latent.detach().to(torch.float32).contiguous()
         b, r = lat.shape[:2]
         labels, _flags = K.mask_labels(mask)
-        plans = {}
-
-        def plan_for(ha, wa, nphase):
-            key = (ha, wa, nphase)
-            if key not in plans:
-                plans[key] = K.region_plan(labels, r, ha, wa, nphase)
-            return plans[key]
 
         def styled(layer, x, idx, nz):
             mod = layer.conv.modulation
             s = K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
-            plan = None
-            if layer.mask_op:
-                h, w = x.shape[1:3]
-                plan = plan_for(h, w, 4 if layer.conv.upsample else 1)
-            return layer.run_nhwc(x, s, plan, nz)
+            return layer.run_nhwc(x, s, nz, labels if layer.mask_op else None, r)
 
         def rgb(layer, x, idx, skip):
             mod = layer.conv.modulation

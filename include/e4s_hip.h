@@ -104,7 +104,10 @@ typedef struct {
     int ncls;                /* 1, or 4 = polyphase up-conv (phase-specific weights) */
     const float* in_scale;   /* [G][Cin] style modulation s, or NULL */
     const float* out_scale;  /* [G][Cout] demodulation coefficient (x conv scale), or NULL */
-    int groups_per_batch;    /* R in plan mode; natural mode uses group = b */
+    int groups_per_batch;    /* R: regions per sample (plan mode and labelled spatial mode) */
+    const uint8_t* labels;   /* spatial mode: label map [B,Hm,Wm]; the row's group is b*R + label(output pixel),
+                                in_scale/out_scale are [B*R][C].  NULL: group = b (tables [B][C]) */
+    int Hm, Wm;
     const float* noise;      /* [Bn,1,Ho,Wo], or NHWC [Bn,Ho,Wo,Cout] when noise_per_channel; or NULL */
     const float* noise_w;    /* device scalar (NoiseInjection.weight) */
     int64_t noise_bstride;   /* Ho*Wo (pixels per sample), or 0 when the noise is shared by the batch */

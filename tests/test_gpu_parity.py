@@ -96,6 +96,7 @@ def _pack(w):
     (2, 16, 16, 64, 128, 1, True), (2, 16, 16, 64, 128, 1, False), (1, 32, 32, 32, 64, 1, True),
     (1, 32, 32, 64, 32, 1, True), (1, 32, 32, 64, 32, 1, False), (2, 32, 32, 64, 64, 2, False),
     (1, 16, 32, 96, 160, 1, True), (1, 64, 64, 128, 256, 2, False),
+    (2, 12, 20, 64, 64, 1, True), (3, 4, 4, 64, 128, 1, True), (1, 8, 8, 32, 32, 1, True),   # partial halo tiles
 ])
 def test_conv_mfma_vs_conv2d(b, h, w, cin, cout, stride, spatial):
     from e4s_amd import kernels as K
@@ -151,10 +152,13 @@ def test_modulated_conv_vs_oracle(cin, cout, res, up):
     assert maxabs(got, want) < 5e-5          # fp32 both sides, different summation order
 
 
+@pytest.mark.parametrize("use_plan", [False, True])
 @pytest.mark.parametrize("cin,cout,res,up,cells", [(512, 512, 16, False, 16), (512, 512, 8, True, 4),
-                                                    (256, 256, 32, False, 8), (512, 256, 16, True, 32)])
-def test_styled_conv_masked_vs_oracle(cin, cout, res, up, cells):
-    """Region-select (one gathered GEMM) == the reference's 12 passes x one-hot mask."""
+                                                    (256, 256, 32, False, 8), (512, 256, 16, True, 32),
+                                                    (512, 512, 4, False, 64), (512, 512, 4, True, 64)])
+def test_styled_conv_masked_vs_oracle(cin, cout, res, up, cells, use_plan):
+    """Region-select (in-GEMM per-pixel style, or the gathered row plan) == the reference's 12 passes x
+    one-hot mask."""
     from e4s_amd.stylegan2 import StyledConv
     sd = _styled_sd(cin, cout, up, 12)
     m = StyledConv(cin, cout, 3, 512, upsample=up, mask_op=True)
@@ -168,7 +172,7 @@ def test_styled_conv_masked_vs_oracle(cin, cout, res, up, cells):
     out_res = res * 2 if up else res
     noise = torch.randn(b, 1, out_res, out_res, generator=g)
     want = orc.styled_conv(sd, "", x, style, mask, noise, up, True)
-    got = m(x.to(DEV), style.to(DEV), mask.to(DEV), noise=noise.to(DEV))
+    got = m(x.to(DEV), style.to(DEV), mask.to(DEV), noise=noise.to(DEV), use_plan=use_plan)
     assert maxabs(got, want) < 5e-5
 
 
