@@ -144,12 +144,12 @@ def main():
         print(json.dumps(headline_probe(net, B, inputs[4], args.probe_reps)))
         return
 
-    gathered = torch.empty(world * B, 3, SIZE, SIZE, device=dev) if world > 1 else None
+    from e4s_amd import shard
 
     def step():
         img = face_swap_core(net, *inputs[:5], noise=inputs[5])
         if world > 1:
-            dist.all_gather_into_tensor(gathered, img)
+            shard.gather_outputs(img, world * B)      # RCCL all_gather_into_tensor of [B,3,1024,1024] per rank
         return img
 
     def fence():

@@ -1,0 +1,68 @@
+"""Image-parallel sharding of batched face swaps across the GPUs of one node (BASELINE.json configs[3]).
+
+The path shards by independent images: every rank holds the full (replicated) Net3, computes a
+contiguous slice of the batch with no exchange, and the only collective is one all-gather of the
+[B/N, 3, H, W] outputs (RCCL over xGMI; `torch.distributed` backend "nccl" on ROCm).  The reference has
+no counterpart (its only collective is DDP's gradient all-reduce, src/training/coach.py:46-85).
+One process per GPU; on CPU the same code runs over gloo (tests/test_shard_gloo.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, world, rank):
+    """Contiguous balanced split of n items: the first n % world ranks get one extra."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(tensors, world, rank):
+    """Slice every [N, ...] tensor (or list of them) to this rank's shard."""
+    n = None
+    for t in tensors:
+        if torch.is_tensor(t):
+            n = t.shape[0]
+            break
+    lo, hi = shard_range(n, world, rank)
+
+    def cut(t):
+        if torch.is_tensor(t):
+            return t[lo:hi].contiguous() if t.shape[0] == n else t
+        if isinstance(t, (list, tuple)):
+            return [cut(u) for u in t]
+        return t
+    return [cut(t) for t in tensors], (lo, hi)
+
+
+def gather_outputs(local, n_total, group=None):
+    """All-gather ragged shards [b_r, ...] into [n_total, ...] in rank order (every rank gets the result)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    rank = dist.get_rank(group)
+    base, extra = divmod(n_total, world)
+    if extra == 0:
+        out = local.new_empty((n_total,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    cap = base + 1                                   # pad ragged shards to a common size, trim after
+    padded = local.new_zeros((cap,) + tuple(local.shape[1:]))
+    padded[: local.shape[0]] = local
+    buf = local.new_empty((world * cap,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, world, r)
+        parts.append(buf[r * cap: r * cap + (hi - lo)])
+    return torch.cat(parts, 0)
+
+
+def run_sharded(fn, tensors, group=None):
+    """out = gather(fn(*shard(tensors))).  `fn` maps a shard of the inputs to [b_local, ...] outputs
+    (e.g. functools.partial(e4s_amd.networks.face_swap_core, net))."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = next(t.shape[0] for t in tensors if torch.is_tensor(t))
+    shard, _ = shard_batch(tensors, world, rank)
+    return gather_outputs(fn(*shard), n, group)

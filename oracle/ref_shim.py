@@ -46,7 +46,11 @@ def reference_modules():
     # our repo also has a top-level ``src`` shim package; make sure the reference's wins here
     for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
         del sys.modules[k]
-    sys.path.insert(0, REF_ROOT)
+    # the reference's `src` is a namespace package (no __init__.py); a regular `src` package anywhere on
+    # sys.path (this repo's shim) would win over it, so hide such entries while importing
+    saved_path = list(sys.path)
+    sys.path[:] = [REF_ROOT] + [p for p in saved_path
+                                if not os.path.isfile(os.path.join(p or os.getcwd(), "src", "__init__.py"))]
     src = os.path.join(REF_ROOT, "src")
     fa = _load("ref_gpen_fused_act", os.path.join(src, "pretrained/gpen/face_model/op/fused_act.py"))
     up = _load("ref_gpen_upfirdn2d", os.path.join(src, "pretrained/gpen/face_model/op/upfirdn2d.py"))
@@ -80,7 +84,10 @@ def reference_modules():
     ns = types.SimpleNamespace(Net3=Net3, Generator=Generator, ModulatedConv2d=ModulatedConv2d,
                                StyledConv=StyledConv, ToRGB=ToRGB,
                                fused_leaky_relu=op.fused_leaky_relu, upfirdn2d=op.upfirdn2d)
-    sys.path.remove(REF_ROOT)
+    sys.path[:] = saved_path
+    # leave the reference modules reachable only through `ns`; later `import src...` gets this repo's shim
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
     _CACHE["ns"] = ns
     return ns
 

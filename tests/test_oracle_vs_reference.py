@@ -1,0 +1,46 @@
+"""CPU, build container only (needs /root/reference): layer-level checks of the oracle restatement against
+the REAL reference modules on shapes the golden fixtures do not cover."""
+import pytest
+import torch
+
+from e4s_amd import synth
+from oracle import e4s_oracle as orc
+from oracle import ref_shim
+
+pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="reference tree not mounted")
+
+
+@pytest.mark.parametrize("cin,cout,up", [(16, 24, False), (16, 8, True)])
+@torch.no_grad()
+def test_styled_conv_masked_matches_reference_module(cin, cout, up):
+    ns = ref_shim.reference_modules()
+    m = ns.StyledConv(cin, cout, 3, 512, upsample=up, mask_op=True)
+    g = torch.Generator().manual_seed(0)
+    for p in m.parameters():
+        p.copy_(torch.randn(p.shape, generator=g) * 0.5 + (1.0 if p.ndim == 1 and p.numel() == cin else 0.0))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, cin, 8, 8, generator=g)
+    style = torch.randn(2, 12, 512, generator=g)
+    mask = synth.onehot(synth.synth_labels_blocks(2, 64, 8, seed=1))
+    res = 16 if up else 8
+    noise = torch.randn(2, 1, res, res, generator=g)
+    want = m(x, style, mask, noise=noise)
+    got = orc.styled_conv(sd, "", x, style, mask, noise, up, True)
+    assert float((got - want).abs().max()) < 1e-5
+
+
+@torch.no_grad()
+def test_torgb_matches_reference_module():
+    ns = ref_shim.reference_modules()
+    m = ns.ToRGB(16, 512, mask_op=True)
+    g = torch.Generator().manual_seed(1)
+    for p in m.parameters():
+        p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 16, 8, 8, generator=g)
+    style = torch.randn(2, 12, 512, generator=g)
+    mask = synth.onehot(synth.synth_labels_blocks(2, 64, 8, seed=2))
+    skip = torch.randn(2, 3, 4, 4, generator=g)
+    want = m(x, style, mask, skip)
+    got = orc.to_rgb(sd, "", x, style, mask, skip, True)
+    assert float((got - want).abs().max()) < 1e-5
