@@ -137,12 +137,13 @@ def swap_comp_style_vector(style_vectors1, style_vectors2, comp_indices, belowFa
     """scripts/face_swap.py:117-146, applied per sample so that batches work.
     style_vectors1 = target, style_vectors2 = source/driven."""
     out = style_vectors1.clone()
-    idx = torch.as_tensor(sorted(comp_indices), device=out.device, dtype=torch.long)
+    idx = sorted(comp_indices)
     out[:, idx] = style_vectors2[:, idx]
-    no_ear = (style_vectors2[:, 7].sum(1) == 0)
-    out[no_ear, 7] = (style_vectors1[no_ear, 7] + style_vectors2[no_ear, 7]) / 2
-    no_teeth = (style_vectors2[:, 9].sum(1) == 0)
-    out[no_teeth, 9] = style_vectors1[no_teeth, 9]
+    # torch.where instead of boolean indexing: no host sync, HIP-graph capturable
+    no_ear = (style_vectors2[:, 7].sum(1, keepdim=True) == 0)
+    out[:, 7] = torch.where(no_ear, (style_vectors1[:, 7] + style_vectors2[:, 7]) / 2, out[:, 7])
+    no_teeth = (style_vectors2[:, 9].sum(1, keepdim=True) == 0)
+    out[:, 9] = torch.where(no_teeth, style_vectors1[:, 9], out[:, 9])
     if belowFace_interpolation:
         out[:, 8] = (style_vectors1[:, 8] + style_vectors2[:, 8]) / 2
     return out
@@ -160,3 +161,50 @@ def face_swap_core(net, driven, driven_mask, target, target_mask, swapped_mask, 
     codes = net.cal_style_codes(swapped)
     img, _, _ = net.gen_img(None, codes, swapped_mask, randomize_noise=randomize_noise, noise=noise)
     return img
+
+
+class GraphedFaceSwap:
+    """`face_swap_core` for fixed shapes captured once into a HIP graph and replayed.
+
+    One swap is ~700 short kernel launches; at batch 1 the Python/ctypes enqueue cost (not the GPU) sets
+    the latency.  Capture removes it: inputs are copied into static device buffers, the whole schedule
+    (encoder x2, style swap, MLPs, generator) replays as one graph launch.  Weight re-packing caches must
+    be warm, so the first call runs eagerly twice before capturing."""
+
+    def __init__(self, net, batch, img_size=1024, mask_size=512, noise_batch=None):
+        dev = next(net.parameters()).device
+        self.net, self.batch = net, batch
+        r = net.opts.num_seg_cls
+        self.static = [torch.zeros(batch, 3, img_size, img_size, device=dev),
+                       torch.zeros(batch, r, mask_size, mask_size, device=dev),
+                       torch.zeros(batch, 3, img_size, img_size, device=dev),
+                       torch.zeros(batch, r, mask_size, mask_size, device=dev),
+                       torch.zeros(batch, r, mask_size, mask_size, device=dev)]
+        for m in self.static[1::2] + [self.static[4]]:
+            m[:, 0] = 1.0                                      # a valid one-hot mask for the warm-up runs
+        nb = batch if noise_batch is None else noise_batch
+        self.noise = [torch.zeros(nb, 1, n.shape[2], n.shape[3], device=dev) for n in net.G.make_noise()]
+        self.graph = None
+        self.out = None
+
+    def _load(self, driven, dm, target, tm, sm, noise):
+        for dst, src in zip(self.static, (driven, dm, target, tm, sm)):
+            dst.copy_(src)
+        for dst, src in zip(self.noise, noise):
+            dst.copy_(src)
+
+    def __call__(self, driven, dm, target, tm, sm, noise):
+        self._load(driven, dm, target, tm, sm, noise)
+        if self.graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    face_swap_core(self.net, *self.static, noise=self.noise)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = face_swap_core(self.net, *self.static, noise=self.noise)
+        self.graph.replay()
+        return self.out
