@@ -58,7 +58,67 @@ __global__ void rgb_weights_kernel(const float* __restrict__ w, const float* __r
     ws[i] = scale * w[c * cin + ci] * s[(size_t)g * cin + ci];
 }
 
+// Polyphase re-packing of an up-sampling 3x3 weight: conv_transpose2d(stride 2) followed by the 4x4 blur
+// (model.py:287-300) == for output phase (py,px) a 3x3 correlation over the input grid with
+//   out[ph][ey*3+ex][co][ci] = E[py - 2(ey-1)][px - 2(ex-1)],  E[ty][tx] = sum_j kflip[jy][jx] W[ty+jy-1][tx+jx-1]
+__global__ void polyphase_weights_kernel(const float* __restrict__ w, const float* __restrict__ k4,
+                                         float* __restrict__ out, int cout, int cin) {
+    const int64_t n = (int64_t)cout * cin;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float wv[9], kf[16];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = w[i * 9 + t];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) kf[t] = k4[15 - t];                       // flipped: upfirdn2d is a true convolution
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+#pragma unroll
+        for (int ey = 0; ey < 3; ++ey) {
+#pragma unroll
+            for (int ex = 0; ex < 3; ++ex) {
+                const int ty = py - 2 * (ey - 1), tx = px - 2 * (ex - 1);
+                float acc = 0.f;
+#pragma unroll
+                for (int jy = 0; jy < 4; ++jy) {
+                    const int ky = ty + jy - 1;
+                    if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        const int kx = tx + jx - 1;
+                        if (kx < 0 || kx > 2) continue;
+                        acc += kf[jy * 4 + jx] * wv[ky * 3 + kx];
+                    }
+                }
+                out[((int64_t)(ph * 9 + ey * 3 + ex)) * n + i] = acc;
+            }
+        }
+    }
+}
+
+// [Cout,Cin,kh*kw] -> [kh*kw][Cout][Cin]
+__global__ void pack_taps_kernel(const float* __restrict__ w, float* __restrict__ out, int64_t n, int taps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int t = 0; t < taps; ++t) out[(int64_t)t * n + i] = w[i * taps + t];
+}
+
 }  // namespace
+
+extern "C" int e4s_polyphase_weights_f32(const float* w, const float* k4, float* out, int cout, int cin, void* stream) {
+    const int64_t n = (int64_t)cout * cin;
+    hipLaunchKernelGGL(polyphase_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, k4, out, cout, cin);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_pack_taps_f32(const float* w, float* out, int cout, int cin, int taps, void* stream) {
+    const int64_t n = (int64_t)cout * cin;
+    hipLaunchKernelGGL(pack_taps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, out, n, taps);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int e4s_rowdot_f32(const float* in, int64_t in_stride, const float* M, const float* bias, float* out,
                               int G, int O, int K, int mode, float scale, void* stream) {

@@ -32,8 +32,7 @@ def _pack3x3(conv):
     key = (w.data_ptr(), w._version)
     if getattr(conv, "_e4s_pack", None) is None or conv._e4s_pack[0] != key:
         with torch.no_grad():
-            cout, cin, kh, kw = w.shape
-            conv._e4s_pack = (key, w.detach().float().permute(2, 3, 0, 1).reshape(1, kh * kw, cout, cin).contiguous())
+            conv._e4s_pack = (key, K.pack_taps(w.detach().float().contiguous()))
     return conv._e4s_pack[1]
 
 

@@ -135,6 +135,25 @@ def weight_sqsum(w):
     return out
 
 
+def pack_taps(w):
+    """w [Cout,Cin,kh,kw] -> [1, kh*kw, Cout, Cin] (the conv kernel's B operand layout)."""
+    w = _f32(w)
+    cout, cin = w.shape[:2]
+    taps = w.shape[2] * w.shape[3]
+    out = torch.empty(1, taps, cout, cin, device=w.device, dtype=torch.float32)
+    call("e4s_pack_taps_f32", fptr(w), fptr(out), cout, cin, taps, stream())
+    return out
+
+
+def polyphase_weights(w, blur_kernel):
+    """w [Cout,Cin,3,3] + 4x4 blur -> [4, 9, Cout, Cin] phase kernels of the fused transposed conv + blur."""
+    w = _f32(w)
+    cout, cin = w.shape[:2]
+    out = torch.empty(4, 9, cout, cin, device=w.device, dtype=torch.float32)
+    call("e4s_polyphase_weights_f32", fptr(w), fptr(_f32(blur_kernel)), fptr(out), cout, cin, stream())
+    return out
+
+
 def rgb_weights(w, s, scale):
     """ws[g,c,ci] = scale*w[c,ci]*s[g,ci]; w [3,Cin]."""
     g, cin = s.shape

@@ -189,9 +189,10 @@ class ModulatedConv2d(nn.Module):
             if k == 1:
                 pack["w"] = w.reshape(1, 1, cout, cin).contiguous()
             elif not self.upsample:
-                pack["w"] = w.permute(2, 3, 0, 1).reshape(1, k * k, cout, cin).contiguous()
+                pack["w"] = K.pack_taps(w.contiguous())
             else:
-                pack["w"] = polyphase_upconv_weights(w, self.blur.kernel.detach().float())
+                # same math as polyphase_upconv_weights() below (the CPU-tested statement of it)
+                pack["w"] = K.polyphase_weights(w.contiguous(), self.blur.kernel.detach().float())
             pack["wsq"] = K.weight_sqsum(w.contiguous()) if self.demodulate else None
         self._pack = pack
         return pack

@@ -65,6 +65,13 @@ int e4s_rowdot_f32(const float* in, int64_t in_stride, const float* M, const flo
 /* wsq[co, ci] = sum_k w[co, ci, k]^2 (w is [Cout, Cin, taps]) */
 int e4s_weight_sqsum_f32(const float* w, float* wsq, int cout, int cin, int taps, void* stream);
 
+/* Weight re-packing for e4s_conv_mfma_f32 (done once per weight version, cached by the host):
+ *   e4s_pack_taps_f32:         w [Cout,Cin,taps] -> out [taps][Cout][Cin]
+ *   e4s_polyphase_weights_f32: up-sampling conv: w [Cout,Cin,3,3] and the 4x4 blur kernel k4
+ *     (conv_transpose2d stride 2 + Blur pad (1,1), model.py:287-300) -> out [4 phases][9][Cout][Cin] */
+int e4s_pack_taps_f32(const float* w, float* out, int cout, int cin, int taps, void* stream);
+int e4s_polyphase_weights_f32(const float* w, const float* k4, float* out, int cout, int cin, void* stream);
+
 /* ws[g, c, ci] = scale * w[c, ci] * s[g, ci]   (ToRGB: demodulate=False, model.py:417) */
 int e4s_rgb_weights_f32(const float* w, const float* s, float* ws, int G, int cin, float scale, void* stream);
 

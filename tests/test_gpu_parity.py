@@ -331,3 +331,14 @@ def test_gen1024_properties_batch_and_region_relabel():
     img2, _, _ = net.gen_img(None, codes[:, perm].contiguous(), mask[:, perm].contiguous(), noise=noise)
     assert torch.equal(img2, img)
     assert bool(torch.isfinite(img).all())
+
+
+def test_weight_repacking_kernels():
+    """e4s_polyphase_weights_f32 / e4s_pack_taps_f32 against their CPU-tested torch statements."""
+    from e4s_amd import kernels as K
+    from e4s_amd.stylegan2 import polyphase_upconv_weights
+    g = torch.Generator().manual_seed(31)
+    w = torch.randn(40, 24, 3, 3, generator=g)
+    blur = orc.make_blur_kernel() * 4
+    assert maxabs(K.polyphase_weights(w.to(DEV), blur.to(DEV)), polyphase_upconv_weights(w, blur)) < 1e-6
+    assert torch.equal(K.pack_taps(w.to(DEV)).cpu(), _pack(w))
