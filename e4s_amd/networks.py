@@ -133,12 +133,20 @@ class Net3(nn.Module):
         return images, feats
 
 
+_SWAP_SEL = {}
+
+
 def swap_comp_style_vector(style_vectors1, style_vectors2, comp_indices, belowFace_interpolation=False):
     """scripts/face_swap.py:117-146, applied per sample so that batches work.
     style_vectors1 = target, style_vectors2 = source/driven."""
-    out = style_vectors1.clone()
-    idx = sorted(comp_indices)
-    out[:, idx] = style_vectors2[:, idx]
+    r = style_vectors1.shape[1]
+    key = (style_vectors1.device, r, tuple(sorted(comp_indices)))
+    sel = _SWAP_SEL.get(key)
+    if sel is None:                    # built once, eagerly (an H2D copy is not capturable in a HIP graph)
+        sel = torch.zeros(1, r, 1, dtype=torch.bool)
+        sel[0, list(key[2]), 0] = True
+        sel = _SWAP_SEL[key] = sel.to(style_vectors1.device)
+    out = torch.where(sel, style_vectors2, style_vectors1)
     # torch.where instead of boolean indexing: no host sync, HIP-graph capturable
     no_ear = (style_vectors2[:, 7].sum(1, keepdim=True) == 0)
     out[:, 7] = torch.where(no_ear, (style_vectors1[:, 7] + style_vectors2[:, 7]) / 2, out[:, 7])
