@@ -30,22 +30,27 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ x, float* __res
            ly * (hx * p[(int64_t)y1 * Wi + x0] + lx * p[(int64_t)y1 * Wi + x1]);
 }
 
-// ---- stem conv: 3x3, pad 1, tiny Cin (3) -> Cout; one thread per (pixel, cout) ------------------
+// ---- stem conv: 3x3, pad 1, tiny Cin (3) -> Cout.  Thread = (pixel, 4 consecutive couts): 16 lanes write
+// one pixel's 64 channels as a contiguous 256 B, weights [tap][ci][cout] broadcast-read from LDS -------------
 __global__ void conv3x3_small_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                      int B, int H, int W, int Cin, int Cout) {
-    extern __shared__ float sw[];   // [Cout][Cin*9]
+    extern __shared__ float sw[];   // [9][Cin][Cout]
     const int nw = Cout * Cin * 9;
-    for (int t = threadIdx.x; t < nw; t += blockDim.x) sw[t] = w[t];
+    for (int t = threadIdx.x; t < nw; t += blockDim.x) {
+        const int k = t % 9, ci = (t / 9) % Cin, co = t / (9 * Cin);        // w is [Cout][Cin][3][3]
+        sw[(k * Cin + ci) * Cout + co] = w[t];
+    }
     __syncthreads();
-    const int64_t n = (int64_t)B * H * W * Cout;
+    const int cg = Cout / 4;
+    const int64_t n = (int64_t)B * H * W * cg;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int co = (int)(i % Cout);
-    int64_t r = i / Cout;
+    const int c4 = (int)(i % cg) * 4;
+    int64_t r = i / cg;
     const int ox = (int)(r % W); r /= W;
     const int oy = (int)(r % H);
     const int b = (int)(r / H);
-    float acc = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = oy + ky - 1;
         if (iy < 0 || iy >= H) continue;
@@ -53,10 +58,11 @@ __global__ void conv3x3_small_kernel(const float* __restrict__ x, const float* _
             const int ix = ox + kx - 1;
             if (ix < 0 || ix >= W) continue;
             const float* xp = x + (((int64_t)b * H + iy) * W + ix) * Cin;
-            for (int ci = 0; ci < Cin; ++ci) acc += xp[ci] * sw[(co * Cin + ci) * 9 + ky * 3 + kx];
+            const float* wp = sw + ((ky * 3 + kx) * Cin) * Cout + c4;
+            for (int ci = 0; ci < Cin; ++ci) acc += xp[ci] * *reinterpret_cast<const f32x4*>(wp + ci * Cout);
         }
     }
-    y[i] = acc;
+    *reinterpret_cast<f32x4*>(y + i * 4) = acc;
 }
 
 // ---- InstanceNorm statistics: single pass, fp64 partial sums (no cancellation in E[x^2]-mean^2),
@@ -180,19 +186,20 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
 // quarter of the pixels and keeps R running sums in LDS columns it alone touches ------------------
 __global__ void region_mean_kernel(const float* __restrict__ feats, const uint8_t* __restrict__ labels, int Hm, int Wm,
                                    float* __restrict__ out, int H, int W, int C, int R, int out_stride, int out_off) {
-    extern __shared__ float sm[];          // sums[4][R][64], cnt[R] (as float)
+    extern __shared__ float sm[];          // sums[NPG][R][64], cnt[R]
+    constexpr int NPG = 16;                // pixel groups per block (1024 threads)
     const int slabs = C / 64;
     const int b = blockIdx.x / slabs, slab = blockIdx.x % slabs;
     const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
     float* sums = sm;
-    int* cnt = reinterpret_cast<int*>(sm + 4 * R * 64);
-    for (int t = threadIdx.x; t < 4 * R * 64; t += blockDim.x) sums[t] = 0.f;
+    int* cnt = reinterpret_cast<int*>(sm + NPG * R * 64);
+    for (int t = threadIdx.x; t < NPG * R * 64; t += blockDim.x) sums[t] = 0.f;
     for (int t = threadIdx.x; t < R; t += blockDim.x) cnt[t] = 0;
     __syncthreads();
     const int HW = H * W;
     const float* fb = feats + (int64_t)b * HW * C + slab * 64 + cl;
     float* mine = sums + (pg * R) * 64 + cl;
-    for (int p = pg; p < HW; p += 4) {
+    for (int p = pg; p < HW; p += NPG) {
         const int yy = p / W, xx = p - yy * W;
         const int lab = labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
         mine[lab * 64] += fb[(int64_t)p * C];
@@ -201,8 +208,8 @@ __global__ void region_mean_kernel(const float* __restrict__ feats, const uint8_
     __syncthreads();
     for (int t = threadIdx.x; t < R * 64; t += blockDim.x) {
         const int r = t / 64, c = t % 64;
-        const float s = sums[(0 * R + r) * 64 + c] + sums[(1 * R + r) * 64 + c] + sums[(2 * R + r) * 64 + c] +
-                        sums[(3 * R + r) * 64 + c];
+        float s = 0.f;
+        for (int j = 0; j < NPG; ++j) s += sums[(j * R + r) * 64 + c];
         const int n = cnt[r];
         out[((int64_t)b * R + r) * out_stride + out_off + slab * 64 + c] = n > 0 ? s / (float)n : 0.f;
     }
@@ -258,7 +265,8 @@ extern "C" int e4s_resize_bilinear_f32(const float* x, float* y, int B, int C, i
 }
 
 extern "C" int e4s_conv3x3_small_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout, void* stream) {
-    const int64_t n = (int64_t)B * H * W * Cout;
+    if (Cout % 4) return (int)hipErrorInvalidValue;
+    const int64_t n = (int64_t)B * H * W * (Cout / 4);
     if (n <= 0) return 0;
     const size_t smem = (size_t)Cout * Cin * 9 * sizeof(float);
     if (smem > 48 * 1024) return (int)hipErrorInvalidValue;
@@ -305,8 +313,8 @@ extern "C" int e4s_se_gate_f32(const float* pooled, const float* fc1, const floa
 extern "C" int e4s_region_mean_f32(const float* feats, const uint8_t* labels, int Hm, int Wm, float* out, int B, int H,
                                    int W, int C, int R, int out_stride, int out_off, void* stream) {
     if (C % 64 || R > 64) return (int)hipErrorInvalidValue;
-    const size_t smem = (size_t)(4 * R * 64) * sizeof(float) + (size_t)R * sizeof(int);
-    hipLaunchKernelGGL(region_mean_kernel, dim3(B * (C / 64)), dim3(256), smem, as_stream(stream), feats, labels, Hm, Wm, out, H, W, C, R, out_stride, out_off);
+    const size_t smem = (size_t)(16 * R * 64) * sizeof(float) + (size_t)R * sizeof(int);
+    hipLaunchKernelGGL(region_mean_kernel, dim3(B * (C / 64)), dim3(1024), smem, as_stream(stream), feats, labels, Hm, Wm, out, H, W, C, R, out_stride, out_off);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -8,7 +8,8 @@
 
 namespace {
 
-// one wave per output o; the wave keeps M[o, :] in registers and sweeps the groups
+// one wave per (output o, chunk of 8 groups): the wave reads M[o, :] once and reuses it for its groups
+constexpr int GCHUNK = 8;
 template <int MODE>
 __global__ void rowdot_kernel(const float* __restrict__ in, int64_t in_stride, const float* __restrict__ M,
                               const float* __restrict__ bias, float* __restrict__ out, int G, int O, int K,
@@ -16,22 +17,32 @@ __global__ void rowdot_kernel(const float* __restrict__ in, int64_t in_stride, c
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (o >= O) return;
+    const int g0 = blockIdx.y * GCHUNK;
     const float* mrow = M + (size_t)o * K;
-    for (int g = 0; g < G; ++g) {
-        const float* v = in + (size_t)g * in_stride;
-        float acc = 0.f;
-        for (int i = lane * 4; i < K; i += 256) {
-            const f32x4 m = *reinterpret_cast<const f32x4*>(mrow + i);
-            f32x4 x = *reinterpret_cast<const f32x4*>(v + i);
-            if (MODE == 1) x *= x;
-            acc += m[0] * x[0] + m[1] * x[1] + m[2] * x[2] + m[3] * x[3];
+    float acc[GCHUNK];
+#pragma unroll
+    for (int j = 0; j < GCHUNK; ++j) acc[j] = 0.f;
+    for (int i = lane * 4; i < K; i += 256) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mrow + i);
+#pragma unroll
+        for (int j = 0; j < GCHUNK; ++j) {
+            if (g0 + j < G) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(in + (size_t)(g0 + j) * in_stride + i);
+                if (MODE == 1) x *= x;
+                acc[j] += m[0] * x[0] + m[1] * x[1] + m[2] * x[2] + m[3] * x[3];
+            }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            float r;
-            if (MODE == 0) r = acc * scale + (bias ? bias[o] : 0.f);
-            else r = scale * rsqrtf(scale * scale * acc + 1e-8f);
-            out[(size_t)g * O + o] = r;
+    }
+#pragma unroll
+    for (int j = 0; j < GCHUNK; ++j) {
+        if (g0 + j < G) {
+            const float a = wave_sum(acc[j]);
+            if (lane == 0) {
+                float r;
+                if (MODE == 0) r = a * scale + (bias ? bias[o] : 0.f);
+                else r = scale * rsqrtf(scale * scale * a + 1e-8f);
+                out[(size_t)(g0 + j) * O + o] = r;
+            }
         }
     }
 }
@@ -125,7 +136,7 @@ extern "C" int e4s_rowdot_f32(const float* in, int64_t in_stride, const float* M
     if (K % 4 || (mode != 0 && mode != 1)) return (int)hipErrorInvalidValue;
     if (G <= 0 || O <= 0) return 0;
     const int waves = 4;
-    dim3 grid((O + waves - 1) / waves), block(64 * waves);
+    dim3 grid((O + waves - 1) / waves, (G + GCHUNK - 1) / GCHUNK), block(64 * waves);
     if (mode == 0)
         hipLaunchKernelGGL(rowdot_kernel<0>, grid, block, 0, as_stream(stream), in, in_stride, M, bias, out, G, O, K, scale);
     else

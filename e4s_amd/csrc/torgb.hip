@@ -80,6 +80,76 @@ __global__ void torgb_kernel(const float* __restrict__ x, const float* __restric
     }
 }
 
+// Unmasked ToRGB at the high resolutions (Cin <= 128, 256^2..1024^2): pure HBM streaming.
+// A block walks 256-pixel groups; 32-channel slabs are read fully coalesced (8 lanes x 16 B = one 128-B line
+// per pixel), transposed through LDS (rows padded to 36 floats), then ONE lane owns ONE pixel: 3 dot products
+// against the style-scaled weights (broadcast LDS reads), the 4-tap polyphase upsample of the skip, and stores
+// that are contiguous across lanes in each NCHW colour plane.
+__global__ __launch_bounds__(256) void torgb_pixel_kernel(const float* __restrict__ x, const float* __restrict__ ws,
+                                                          const float* __restrict__ bias, const float* __restrict__ skip,
+                                                          const float* __restrict__ k4, float* __restrict__ out,
+                                                          int B, int H, int W, int Cin) {
+    __shared__ __attribute__((aligned(16))) float sx[256 * 36];
+    __shared__ __attribute__((aligned(16))) float sw[3 * 128];
+    __shared__ float skf[16];
+    const int tid = threadIdx.x;
+    const int64_t HW = (int64_t)H * W, npix = (int64_t)B * HW;
+    if (tid < 16) skf[tid] = k4 ? k4[15 - tid] : 0.f;
+    const int c4 = (tid & 7) * 4, prow = tid >> 3;           // staging role: 32 pixel rows x 8 chunks per pass
+    int cur_b = -1;
+    for (int64_t p0 = (int64_t)blockIdx.x * 256; p0 < npix; p0 += (int64_t)gridDim.x * 256) {
+        const int b = (int)(p0 / HW);                         // HW % 256 == 0: a group never straddles samples
+        if (b != cur_b) {
+            __syncthreads();
+            for (int t = tid; t < 3 * Cin; t += 256) sw[t] = ws[(size_t)b * 3 * Cin + t];
+            cur_b = b;
+        }
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int c0 = 0; c0 < Cin; c0 += 32) {
+            __syncthreads();                                  // previous slab fully consumed
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pl = prow + 32 * j;
+                *reinterpret_cast<f32x4*>(sx + pl * 36 + c4) =
+                    *reinterpret_cast<const f32x4*>(x + (p0 + pl) * Cin + c0 + c4);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sx + tid * 36 + q * 4);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(sw + c0 + q * 4);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(sw + Cin + c0 + q * 4);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(sw + 2 * Cin + c0 + q * 4);
+                a0 += v[0] * w0[0] + v[1] * w0[1] + v[2] * w0[2] + v[3] * w0[3];
+                a1 += v[0] * w1[0] + v[1] * w1[1] + v[2] * w1[2] + v[3] * w1[3];
+                a2 += v[0] * w2[0] + v[1] * w2[1] + v[2] * w2[2] + v[3] * w2[3];
+            }
+        }
+        const int rem = (int)(p0 - (int64_t)b * HW) + tid;
+        const int yy = rem / W, xx = rem - yy * W;
+        float o[3] = {a0 + bias[0], a1 + bias[1], a2 + bias[2]};
+        if (skip) {
+            const int Hs = H >> 1, Ws = W >> 1;
+#pragma unroll
+            for (int jy = 0; jy < 4; ++jy) {
+                const int qy = yy + jy - 2;
+                if (qy < 0 || (qy & 1) || (qy >> 1) >= Hs) continue;
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    const int qx = xx + jx - 2;
+                    if (qx < 0 || (qx & 1) || (qx >> 1) >= Ws) continue;
+                    const float kv = skf[jy * 4 + jx];
+                    const int64_t so = (int64_t)(qy >> 1) * Ws + (qx >> 1);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) o[ch] += skip[((int64_t)b * 3 + ch) * Hs * Ws + so] * kv;
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) out[((int64_t)b * 3 + ch) * HW + rem] = o[ch];
+    }
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int64_t HW, int64_t n,
                                     int src_bstride_zero) {
     // 32x32 LDS transpose per (b): tile over (c, p)
@@ -136,6 +206,13 @@ extern "C" int e4s_torgb_f32(const float* x, const float* ws, const float* bias,
     const int64_t npix = (int64_t)B * H * W;
     if (npix <= 0) return 0;
     hipStream_t st = as_stream(stream);
+    if (!labels && Cin <= 128 && Cin % 32 == 0 && ((int64_t)H * W) % 256 == 0) {
+        int64_t nb = npix / 256;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(torgb_pixel_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ws, bias, skip, k4, out, B, H, W, Cin);
+        E4S_CHECK_LAUNCH();
+        return 0;
+    }
     const int lp = Cin >= 256 ? 64 : (Cin >= 128 ? 32 : (Cin >= 64 ? 16 : 8));
     const int ppw = 64 / lp;
     int64_t blocks = (npix + (int64_t)ppw * 4 - 1) / ((int64_t)ppw * 4);
