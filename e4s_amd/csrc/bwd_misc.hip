@@ -1,0 +1,157 @@
+// HBM-bound pieces of the generator backward: segmented (per-region) reductions for the
+// demodulation and ToRGB-weight gradients, and the ToRGB input gradient.  All on NHWC activations.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+    const float scale = (float)in / (float)out;
+    const int s = (int)floorf((float)dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
+
+// dd[b,r,co] = (1/d[b,r,co]) * sum_{p in r} gz[p,co] * (z[p,co] - nw*noise[p] - bias[co]),  z = lrelu^-1(y)/gain
+// (out_pre = d * c  =>  dL/dd = sum gz * c = sum gz * out_pre / d).  Block = (b, 64-channel slab, pixel split).
+constexpr int NPG = 4;
+__global__ void demod_grad_kernel(const float* __restrict__ gz, const float* __restrict__ y,
+                                  const float* __restrict__ noise, const float* __restrict__ noise_w,
+                                  int64_t noise_bstride, const float* __restrict__ bias, float alpha, float gain,
+                                  const uint8_t* __restrict__ labels, int Hm, int Wm, int R,
+                                  float* __restrict__ dd, int H, int W, int C, int nsplit) {
+    extern __shared__ float sums[];        // [NPG][R][64]
+    const int slabs = C / 64;
+    const int split = blockIdx.x % nsplit;
+    const int slab = (blockIdx.x / nsplit) % slabs;
+    const int b = blockIdx.x / (nsplit * slabs);
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < NPG * R * 64; t += blockDim.x) sums[t] = 0.f;
+    __syncthreads();
+    const int HW = H * W, c = slab * 64 + cl;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p0 = split * per, p1 = min(p0 + per, HW);
+    const float nw = noise ? noise_w[0] : 0.f, bs = bias ? bias[c] : 0.f;
+    const float inv_pos = 1.f / gain, inv_neg = 1.f / (gain * alpha);
+    float* mine = sums + (pg * R) * 64 + cl;
+    for (int p = p0 + pg; p < p1; p += NPG) {
+        const int yy = p / W, xx = p - yy * W;
+        int lab = 0;
+        if (labels) lab = labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
+        const int64_t idx = ((int64_t)b * HW + p) * C + c;
+        const float yv = y[idx];
+        const float z = yv > 0.f ? yv * inv_pos : yv * inv_neg;
+        const float nz = noise ? nw * noise[(int64_t)b * noise_bstride + p] : 0.f;
+        mine[lab * 64] += gz[idx] * (z - nz - bs);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < R * 64; t += blockDim.x) {
+        const int r = t / 64, cc = t % 64;
+        float s = 0.f;
+        for (int j = 0; j < NPG; ++j) s += sums[(j * R + r) * 64 + cc];
+        if (s != 0.f) atomicAdd(&dd[((int64_t)b * R + r) * C + slab * 64 + cc], s);
+    }
+}
+
+// dws[b*R+r, c, ci] += sum_{p in r} drgb[b,c,p] * x[p,ci]
+__global__ void torgb_bwd_w_kernel(const float* __restrict__ drgb, const float* __restrict__ x,
+                                   const uint8_t* __restrict__ labels, int Hm, int Wm, int R,
+                                   float* __restrict__ dws, int H, int W, int C, int nsplit) {
+    extern __shared__ float sums[];        // [NPG][R][3][64]
+    const int slabs = C / 64;
+    const int split = blockIdx.x % nsplit;
+    const int slab = (blockIdx.x / nsplit) % slabs;
+    const int b = blockIdx.x / (nsplit * slabs);
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < NPG * R * 3 * 64; t += blockDim.x) sums[t] = 0.f;
+    __syncthreads();
+    const int HW = H * W, c = slab * 64 + cl;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p0 = split * per, p1 = min(p0 + per, HW);
+    float* mine = sums + (pg * R) * 3 * 64 + cl;
+    for (int p = p0 + pg; p < p1; p += NPG) {
+        const int yy = p / W, xx = p - yy * W;
+        int lab = 0;
+        if (labels) lab = labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
+        const float xv = x[((int64_t)b * HW + p) * C + c];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) mine[(lab * 3 + ch) * 64] += drgb[((int64_t)b * 3 + ch) * HW + p] * xv;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < R * 3 * 64; t += blockDim.x) {
+        const int cc = t % 64, ch = (t / 64) % 3, r = t / 192;
+        float s = 0.f;
+        for (int j = 0; j < NPG; ++j) s += sums[((j * R + r) * 3 + ch) * 64 + cc];
+        if (s != 0.f) atomicAdd(&dws[(((int64_t)b * R + r) * 3 + ch) * C + slab * 64 + cc], s);
+    }
+}
+
+// dx[p, ci] (+)= sum_c drgb[b,c,p] * ws[g(p), c, ci]
+__global__ void torgb_bwd_x_kernel(const float* __restrict__ drgb, const float* __restrict__ ws,
+                                   const uint8_t* __restrict__ labels, int Hm, int Wm, int R, float* __restrict__ dx,
+                                   int B, int H, int W, int C, int accumulate) {
+    const int C4 = C / 4;
+    const int64_t HW = (int64_t)H * W, n = (int64_t)B * HW * C4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C4) * 4;
+    const int64_t pix = i / C4;
+    const int b = (int)(pix / HW);
+    const int rem = (int)(pix - (int64_t)b * HW);
+    int g = b;
+    if (labels) {
+        const int yy = rem / W, xx = rem - yy * W;
+        g = b * R + labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
+    }
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) o = *reinterpret_cast<const f32x4*>(dx + i * 4);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float gch = drgb[((int64_t)b * 3 + ch) * HW + rem];
+        o += gch * *reinterpret_cast<const f32x4*>(ws + ((size_t)g * 3 + ch) * C + c);
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+}
+
+}  // namespace
+
+extern "C" int e4s_demod_grad_f32(const float* gz, const float* y, const float* noise, const float* noise_w,
+                                  int64_t noise_bstride, const float* bias, float alpha, float gain,
+                                  const uint8_t* labels, int Hm, int Wm, int R, float* dd, int B, int H, int W, int C,
+                                  void* stream) {
+    if (C % 64 || R < 1 || R > 16) return (int)hipErrorInvalidValue;
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(dd, 0, sizeof(float) * (size_t)B * R * C, st);
+    if (e != hipSuccess) return (int)e;
+    int nsplit = 1024 / (B * (C / 64));
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > (H * W) / 64) nsplit = (H * W) / 64 > 0 ? (H * W) / 64 : 1;
+    hipLaunchKernelGGL(demod_grad_kernel, dim3(B * (C / 64) * nsplit), dim3(64 * NPG), sizeof(float) * NPG * R * 64, st,
+                       gz, y, noise, noise_w, noise_bstride, bias, alpha, gain, labels, Hm, Wm, R, dd, H, W, C, nsplit);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_torgb_bwd_w_f32(const float* drgb, const float* x, const uint8_t* labels, int Hm, int Wm, int R,
+                                   float* dws, int B, int H, int W, int C, void* stream) {
+    if (C % 64 || R < 1 || R > 16) return (int)hipErrorInvalidValue;
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(dws, 0, sizeof(float) * (size_t)B * R * 3 * C, st);
+    if (e != hipSuccess) return (int)e;
+    int nsplit = 1024 / (B * (C / 64));
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > (H * W) / 64) nsplit = (H * W) / 64 > 0 ? (H * W) / 64 : 1;
+    hipLaunchKernelGGL(torgb_bwd_w_kernel, dim3(B * (C / 64) * nsplit), dim3(64 * NPG), sizeof(float) * NPG * R * 3 * 64,
+                       st, drgb, x, labels, Hm, Wm, R, dws, H, W, C, nsplit);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_torgb_bwd_x_f32(const float* drgb, const float* ws, const uint8_t* labels, int Hm, int Wm, int R,
+                                   float* dx, int B, int H, int W, int C, int accumulate, void* stream) {
+    if (C % 4) return (int)hipErrorInvalidValue;
+    const int64_t n = (int64_t)B * H * W * (C / 4);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(torgb_bwd_x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), drgb, ws,
+                       labels, Hm, Wm, R, dx, B, H, W, C, accumulate);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,255 @@
+// Backward of the region-select modulated convolution on fp32 MFMA.
+//
+// Forward (conv_mfma.hip, spatial mode):  out_pre[p,co] = d[r(p),co] * sum_{tap,ci} W[co,tap,ci] s[r(p),ci] x[p+tap-1, ci]
+// Given gz = dL/d(out_pre) (NHWC) this kernel produces, in ONE pass over the same MACs as the forward,
+//   dx[q,ci]  = sum_tap' s[r(p),ci] * T[q,tap',ci],   T[q,tap',ci] = sum_co Wt[tap',ci,co] * d[r(p),co] * gz[p,co],
+//               p = the output pixel that input pixel q feeds through tap' (p = q + tap' - 1 with the flipped taps;
+//               for the polyphase up-conv p = 2*(q + tap' - 1) + phase)
+//   ds[b,r,ci] += sum_{q,tap' : r(p) = r} x[q,ci] * T[q,tap',ci]          (grad of the loss w.r.t. the modulation s)
+// The style scale depends on the region of the *tap-shifted* pixel p and on the output column ci, so it cannot be
+// folded into either GEMM operand: each (phase, tap') group accumulates into a temporary MFMA accumulator T which
+// is then scaled by s[r(p)][ci] into the final accumulator -- the same T, multiplied by x, feeds the ds reduction
+// (LDS atomics per tile, one global atomic per (region, ci) per tile).  The demodulation d[r(p)][co] is applied to the
+// A fragment on its way into the MFMA, exactly like s in the forward kernel.
+// GEMM view: rows = input pixels q (8x16 tiles), N = Cin (64 per block), K = (phase, tap', Cout); per stage one
+// (tap', 32-channel) slice of gz (128 rows) and of Wt (64 rows) is staged global->VGPR->LDS, double buffered.
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 32, LDA = 36, NTHR = 256;
+constexpr int BM = 128, BN = 64, TH = 8, TW = 16, MAXR = 16;
+constexpr int TM = 2, TN = 1, WN = 2;          // 4 waves as 2 (M) x 2 (N); wave tile 64 x 32
+
+struct BwdSmem {
+    int out_off[BM];                 // dx pixel index of each row, -1 if outside
+    int yx[BM];                      // (qy << 16) | qx
+    unsigned char grp[36][BM];       // region of the tap-shifted pixel per (phase*9+tap', row); 255 = outside
+    float sS[MAXR * BN];             // s[r][n0 + n]
+    float dS[MAXR * BN];             // ds partial sums of this tile
+    float sD[2][MAXR * LDA];         // d[r][k0 .. k0+32) of the current stage
+    float A[2][BM * LDA];
+    float B[2][BN * LDA];
+};
+
+__global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_params p, const int ntn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    BwdSmem& sm = *reinterpret_cast<BwdSmem*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = logical / ntn, nt = logical - mt * ntn;
+    const int n0 = nt * BN;
+    const int tx_n = (p.Wx + TW - 1) / TW, per_img = ((p.Hx + TH - 1) / TH) * tx_n;
+    const int tb = mt / per_img;
+    const int rem0 = mt - tb * per_img;
+    const int tyb = rem0 / tx_n, txb = rem0 - tyb * tx_n;
+    const int os = (p.ncls == 4) ? 2 : 1;
+    const int R = p.labels ? p.R : 1;
+    const int ngroups = p.ncls * 9;
+
+    // ---- per-row metadata -------------------------------------------------------------
+    if (tid < BM) {
+        const int qy = tyb * TH + tid / TW, qx = txb * TW + tid % TW;
+        const bool valid = qy < p.Hx && qx < p.Wx;
+        sm.out_off[tid] = valid ? (tb * p.Hx + qy) * p.Wx + qx : -1;
+        sm.yx[tid] = (qy << 16) | qx;
+    }
+    for (int t = tid; t < ngroups * BM; t += NTHR) {
+        const int grp = t / BM, row = t - grp * BM;
+        const int ph = grp / 9, tp = grp - ph * 9;
+        const int qy = tyb * TH + row / TW + tp / 3 - 1, qx = txb * TW + row % TW + tp % 3 - 1;
+        unsigned char r = 255;
+        if ((unsigned)qy < (unsigned)p.Hx && (unsigned)qx < (unsigned)p.Wx) {
+            r = 0;
+            if (p.labels) {
+                const int oy = qy * os + (ph >> 1), ox = qx * os + (ph & 1);
+                const int sy = min((int)floorf((float)oy * ((float)p.Hm / (float)p.Hy)), p.Hm - 1);
+                const int sx = min((int)floorf((float)ox * ((float)p.Wm / (float)p.Wy)), p.Wm - 1);
+                r = p.labels[((size_t)tb * p.Hm + sy) * p.Wm + sx];
+            }
+        }
+        sm.grp[grp][row] = r;
+    }
+    for (int t = tid; t < R * BN; t += NTHR) {
+        const int r = t / BN, n = t - r * BN;
+        sm.sS[t] = p.s ? p.s[((size_t)tb * R + r) * p.Cx + n0 + n] : 1.f;
+        sm.dS[t] = 0.f;
+    }
+    __syncthreads();
+
+    const int c4 = (tid & 7) * 4, r0 = tid >> 3;
+    int a_yx[BM / 32];
+#pragma unroll
+    for (int j = 0; j < BM / 32; ++j) a_yx[j] = sm.yx[r0 + 32 * j];
+    const float* dtab = p.d ? p.d + (size_t)tb * R * p.Cy : nullptr;
+
+    f32x4 pa[BM / 32], pb[BN / 32], pd = {1.f, 1.f, 1.f, 1.f};
+    const int nchunk = p.Cy / KC;
+
+    auto fetch = [&](int grp, int c0) {
+        const int ph = grp / 9, tp = grp - ph * 9;
+        const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+        const float* wp = p.wt + ((size_t)grp * p.Cx + n0) * p.Cy + c0 + c4;
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(r0 + 32 * j) * p.Cy);
+#pragma unroll
+        for (int j = 0; j < BM / 32; ++j) {
+            const int qy = (a_yx[j] >> 16) + dy, qx = (a_yx[j] & 0xffff) + dx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)qy < (unsigned)p.Hx && (unsigned)qx < (unsigned)p.Wx) {
+                const int oy = qy * os + (ph >> 1), ox = qx * os + (ph & 1);
+                v = *reinterpret_cast<const f32x4*>(p.gz + ((size_t)(tb * p.Hy + oy) * p.Wy + ox) * p.Cy + c0 + c4);
+            }
+            pa[j] = v;
+        }
+        if (dtab && tid < R * 8) pd = *reinterpret_cast<const f32x4*>(dtab + (size_t)(tid >> 3) * p.Cy + c0 + c4);
+    };
+    auto store = [&](int buf) {
+        float* da = sm.A[buf] + r0 * LDA + c4;
+#pragma unroll
+        for (int j = 0; j < BM / 32; ++j) *reinterpret_cast<f32x4*>(da + 32 * j * LDA) = pa[j];
+        float* db = sm.B[buf] + r0 * LDA + c4;
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) *reinterpret_cast<f32x4*>(db + 32 * j * LDA) = pb[j];
+        if (dtab && tid < R * 8) *reinterpret_cast<f32x4*>(sm.sD[buf] + (tid >> 3) * LDA + c4) = pd;
+    };
+
+    int arow[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) arow[tm] = (wm * TM + tm) * 32 + li;
+    const int brow = (wn * 32 + li) * LDA;
+
+    f32x16 acc[TM], tmp[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+
+    fetch(0, 0);
+    store(0);
+    __syncthreads();
+
+    int s = 0;
+    for (int grp = 0; grp < ngroups; ++grp) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmp[tm][r] = 0.f;
+        int srow[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int g = sm.grp[grp][arow[tm]];
+            srow[tm] = (g == 255 ? 0 : g) * LDA;
+        }
+        for (int ch = 0; ch < nchunk; ++ch, ++s) {
+            int ngrp = grp, nch = ch + 1;
+            if (nch == nchunk) { nch = 0; ++ngrp; }
+            const bool more = ngrp < ngroups;
+            if (more) fetch(ngrp, nch * KC);
+            {
+                const int buf = s & 1;
+                const float* Ab = sm.A[buf];
+                const float* Bb = sm.B[buf];
+                const float* Db = sm.sD[buf];
+#pragma unroll
+                for (int kk = 0; kk < KC / 8; ++kk) {
+                    f32x4 a[TM];
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        a[tm] = *reinterpret_cast<const f32x4*>(Ab + arow[tm] * LDA + kk * 8 + kh * 4);
+                        if (dtab) a[tm] *= *reinterpret_cast<const f32x4*>(Db + srow[tm] + kk * 8 + kh * 4);
+                    }
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(Bb + brow + kk * 8 + kh * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+                            tmp[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[e], tmp[tm], 0, 0, 0);
+                }
+            }
+            if (more) store((s + 1) & 1);
+            __syncthreads();
+        }
+        // ---- tap-group epilogue: final += s[r(p)][ci] * T ;  ds[r(p)][ci] += x[q,ci] * T ----------------------
+        const int ncol = wn * 32 + li;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int g = sm.grp[grp][row];
+                if (g == 255) continue;                      // tap outside the image: T is exactly 0
+                const float t = tmp[tm][r];
+                acc[tm][r] += sm.sS[g * BN + ncol] * t;
+                if (p.ds) {
+                    const int off = sm.out_off[row];
+                    if (off >= 0) atomicAdd(&sm.dS[g * BN + ncol], p.x[(size_t)off * p.Cx + n0 + ncol] * t);
+                }
+            }
+        }
+    }
+
+    // ---- store dx, flush ds -----------------------------------------------------------------------
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int off = sm.out_off[row];
+            if (off >= 0) p.dx[(size_t)off * p.Cx + n0 + wn * 32 + li] = acc[tm][r];
+        }
+    }
+    if (p.ds) {
+        __syncthreads();
+        for (int t = tid; t < R * BN; t += NTHR) {
+            const float v = sm.dS[t];
+            if (v != 0.f) atomicAdd(&p.ds[((size_t)tb * R + t / BN) * p.Cx + n0 + (t % BN)], v);
+        }
+    }
+}
+
+// [ncls][9][Cout][Cin] (forward layout) -> [ncls][9][Cin][Cout] with the taps flipped (tap' = 8 - tap)
+__global__ void pack_bwd_kernel(const float* __restrict__ w, float* __restrict__ wt, int ncls, int cout, int cin) {
+    const int64_t n = (int64_t)ncls * 9 * cout * cin;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int co = (int)(i % cout);
+    int64_t r = i / cout;
+    const int ci = (int)(r % cin); r /= cin;
+    const int tp = (int)(r % 9);
+    const int cls = (int)(r / 9);
+    wt[i] = w[(((int64_t)cls * 9 + (8 - tp)) * cout + co) * cin + ci];
+}
+
+}  // namespace
+
+extern "C" int e4s_conv_bwd_mfma_f32(const e4s_conv_bwd_params* pp, void* stream) {
+    const e4s_conv_bwd_params& p = *pp;
+    if (p.Cx % BN || p.Cy % KC || (p.ncls != 1 && p.ncls != 4)) return (int)hipErrorInvalidValue;
+    if (p.labels && (p.R < 1 || p.R > MAXR)) return (int)hipErrorInvalidValue;
+    if (p.Hy != p.Hx * (p.ncls == 4 ? 2 : 1) || p.Wy != p.Wx * (p.ncls == 4 ? 2 : 1)) return (int)hipErrorInvalidValue;
+    if (p.ds && !p.x) return (int)hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BwdSmem));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int ntn = p.Cx / BN;
+    const int mtiles = p.B * ((p.Hx + TH - 1) / TH) * ((p.Wx + TW - 1) / TW);
+    if (mtiles <= 0) return 0;
+    hipLaunchKernelGGL(conv_bwd_kernel, dim3(mtiles * ntn), dim3(NTHR), sizeof(BwdSmem), as_stream(stream), p, ntn);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_pack_taps_bwd_f32(const float* w, float* wt, int ncls, int cout, int cin, void* stream) {
+    const int64_t n = (int64_t)ncls * 9 * cout * cin;
+    hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, wt, ncls, cout, cin);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}

@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import lib
-from .lib import ConvParams, c_p, call, fptr, ptr, stream
+from .lib import ConvBwdParams, ConvParams, c_p, call, fptr, ptr, stream
 
 BM = 128          # GEMM row tile of e4s_conv_mfma_f32
 LRELU_GAIN = math.sqrt(2.0)
@@ -314,3 +314,63 @@ def grouped_linear(x, w, bias, add, scale, act=0, alpha=0.01):
     call("e4s_grouped_linear_f32", fptr(x), fptr(w), fptr(bias), fptr(add), fptr(y), b, r, k, o, float(scale),
          act, float(alpha), stream())
     return y
+
+
+# ---- backward (generator) --------------------------------------------------------------------
+def pack_taps_bwd(w_fwd):
+    """forward-packed [ncls,9,Cout,Cin] -> backward layout [ncls,9,Cin,Cout] (taps flipped)."""
+    ncls, taps, cout, cin = w_fwd.shape
+    assert taps == 9
+    wt = torch.empty(ncls, 9, cin, cout, device=w_fwd.device, dtype=torch.float32)
+    call("e4s_pack_taps_bwd_f32", fptr(w_fwd), fptr(wt), ncls, cout, cin, stream())
+    return wt
+
+
+def conv_bwd(gz, wt, x, s, d, labels, num_regions, ncls, want_ds=True):
+    """gz NHWC [B,Hy,Wy,Cy]; wt [ncls,9,Cx,Cy]; x NHWC [B,Hx,Wx,Cx] -> (dx like x, ds [G,Cx] or None)."""
+    b, hy, wy, cy = gz.shape
+    _, hx, wx, cx = x.shape
+    dx = torch.empty_like(x)
+    g = s.shape[0]
+    ds = torch.zeros(g, cx, device=x.device, dtype=torch.float32) if want_ds else None
+    p = ConvBwdParams()
+    p.gz, p.wt, p.dx, p.x, p.ds, p.s, p.d = fptr(gz), fptr(wt), fptr(dx), fptr(x), fptr(ds), fptr(s), fptr(d)
+    if labels is not None:
+        p.labels, p.Hm, p.Wm, p.R = ptr(labels), labels.shape[1], labels.shape[2], num_regions
+    else:
+        p.labels, p.Hm, p.Wm, p.R = None, 0, 0, 1
+    p.B, p.Hx, p.Wx, p.Cx, p.Hy, p.Wy, p.Cy, p.ncls = b, hx, wx, cx, hy, wy, cy, ncls
+    call("e4s_conv_bwd_mfma_f32", ctypes.byref(p), stream())
+    return dx, ds
+
+
+def demod_grad(gz, y, noise, noise_w, bias, alpha, gain, labels, num_regions):
+    """dL/dd [G, C] for out_pre = d * c (see e4s_demod_grad_f32); the caller divides by d."""
+    b, h, w, c = gz.shape
+    r = num_regions if labels is not None else 1
+    dd = torch.empty(b * r, c, device=gz.device, dtype=torch.float32)
+    hm = wm = 0
+    if labels is not None:
+        hm, wm = labels.shape[1:]
+    nb = 0
+    if noise is not None:
+        nb = h * w if noise.shape[0] > 1 else 0
+    call("e4s_demod_grad_f32", fptr(gz), fptr(y), fptr(noise), fptr(noise_w) if noise is not None else None, nb,
+         fptr(bias), float(alpha), float(gain), ptr(labels), hm, wm, r, fptr(dd), b, h, w, c, stream())
+    return dd
+
+
+def torgb_bwd(drgb, x, ws, labels, num_regions, dx_acc=None):
+    """drgb NCHW [B,3,H,W]; x NHWC; ws [G,3,C] -> (dx NHWC (accumulated into dx_acc if given), dws [G,3,C])."""
+    b, h, w, c = x.shape
+    r = num_regions if labels is not None else 1
+    hm = wm = 0
+    if labels is not None:
+        hm, wm = labels.shape[1:]
+    dws = torch.empty(b * r, 3, c, device=x.device, dtype=torch.float32)
+    drgb = _f32(drgb)
+    call("e4s_torgb_bwd_w_f32", fptr(drgb), fptr(x), ptr(labels), hm, wm, r, fptr(dws), b, h, w, c, stream())
+    acc = 1 if dx_acc is not None else 0
+    dx = dx_acc if dx_acc is not None else torch.empty_like(x)
+    call("e4s_torgb_bwd_x_f32", fptr(drgb), fptr(ws), ptr(labels), hm, wm, r, fptr(dx), b, h, w, c, acc, stream())
+    return dx, dws

@@ -35,6 +35,16 @@ class ConvParams(ctypes.Structure):
     ]
 
 
+class ConvBwdParams(ctypes.Structure):
+    """Mirror of ``e4s_conv_bwd_params`` (include/e4s_hip.h)."""
+    _fields_ = [
+        ("gz", c_p), ("wt", c_p), ("dx", c_p), ("x", c_p), ("ds", c_p), ("s", c_p), ("d", c_p), ("labels", c_p),
+        ("Hm", c_i), ("Wm", c_i), ("R", c_i),
+        ("B", c_i), ("Hx", c_i), ("Wx", c_i), ("Cx", c_i), ("Hy", c_i), ("Wy", c_i), ("Cy", c_i),
+        ("ncls", c_i),
+    ]
+
+
 # name -> argtypes (all return int except the two info calls); keep in sync with include/e4s_hip.h
 SIGNATURES = {
     "e4s_fused_bias_act_f32": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_p],
@@ -48,6 +58,11 @@ SIGNATURES = {
     "e4s_mask_labels": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_region_plan": [c_p] + [c_i] * 8 + [c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "e4s_conv_mfma_f32": [ctypes.POINTER(ConvParams), c_i, c_p],
+    "e4s_conv_bwd_mfma_f32": [ctypes.POINTER(ConvBwdParams), c_p],
+    "e4s_pack_taps_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "e4s_demod_grad_f32": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_torgb_bwd_w_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_torgb_bwd_x_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_torgb_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_nchw_to_nhwc_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_nhwc_to_nchw_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],

@@ -95,23 +95,26 @@ class Net3(nn.Module):
 
     def cal_style_codes(self, style_vectors):
         """networks.py:135-158 -> [B,R,n_latent,512]."""
-        self._require_no_grad(style_vectors)
         if not self.opts.start_from_latent_avg or self.opts.learn_in_w:
             raise NotImplementedError("only start_from_latent_avg=True, learn_in_w=False (the shipped configs)")
-        with torch.no_grad():
-            K_ = self.remaining_layer_idx
-            nw = K_ if K_ != 17 else 18
-            w0, b0, w2, b2 = self._mlp_weights()
-            sv = style_vectors.detach().to(torch.float32).contiguous()
-            b, r, _ = sv.shape
-            lat = self.latent_avg.to(device=sv.device, dtype=torch.float32)
-            h = K.grouped_linear(sv, w0, b0, None, 1.0 / math.sqrt(w0.shape[2]), act=1, alpha=0.01)
-            add = lat[:nw].reshape(-1).contiguous()
-            codes = K.grouped_linear(h, w2, b2, add, 1.0 / math.sqrt(w2.shape[2])).view(b, r, nw, 512)
-            if K_ != 17:
-                rest = lat[K_:].view(1, 1, -1, 512).expand(b, r, -1, -1)
-                codes = torch.cat([codes, rest], dim=2)
-            return codes
+        if torch.is_grad_enabled() and style_vectors.requires_grad and not getattr(self, "_warned_mlp_grad", False) \
+                and any(p.requires_grad for m in self.MLPs for p in m.parameters()):
+            import warnings
+            warnings.warn("e4s_amd: gradients flow to the style vectors only (what scripts/optimization.py steps); "
+                          "LocalMLP weight gradients (config 5) are not computed yet")
+            self._warned_mlp_grad = True
+        K_ = self.remaining_layer_idx
+        nw = K_ if K_ != 17 else 18
+        w0, b0, w2, b2 = self._mlp_weights()
+        b, r, _ = style_vectors.shape
+        lat = self.latent_avg.to(device=style_vectors.device, dtype=torch.float32)
+        add = lat[:nw].reshape(-1).contiguous()
+        from .autograd import StyleCodesFn
+        codes = StyleCodesFn.apply(style_vectors, w0, b0, w2, b2, add).view(b, r, nw, 512)
+        if K_ != 17:
+            rest = lat[K_:].view(1, 1, -1, 512).expand(b, r, -1, -1)
+            codes = torch.cat([codes, rest], dim=2)
+        return codes
 
     def gen_img(self, struc_codes, style_codes, mask, randomize_noise=True, noise=None, return_latents=False):
         """networks.py:160-182 -> (images, latent | -1, feats16)."""

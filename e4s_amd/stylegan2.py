@@ -264,7 +264,7 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
         self.mask_op = mask_op
 
-    def run_nhwc(self, x, s, noise, labels=None, num_regions=1, plan=None):
+    def run_nhwc(self, x, s, noise, labels=None, num_regions=1, plan=None, rec=None):
         """x NHWC, s [G,Cin] modulation (G = B*R when masked).  Masked layers pass the label map
         (region-select inside the GEMM) or, alternatively, a gathered RowPlan.  Returns NHWC output
         after noise + bias + leaky-ReLU*sqrt(2)."""
@@ -274,6 +274,10 @@ class StyledConv(nn.Module):
         ho, wo = (2 * h, 2 * w) if conv.upsample else (h, w)
         d = K.demod_coefs(s, pk["wsq"], conv.scale)
         nz, per_ch = _prep_noise(noise, b, ho, wo, x.device)
+        if rec is not None:
+            if per_ch:
+                raise NotImplementedError("backward with per-channel noise maps")
+            rec.update(d=d, noise=nz)
         return K.conv_mfma(x, pk["w"], conv.out_channel, plan=plan, labels=None if plan is not None else labels,
                            num_regions=num_regions, ncls=4 if conv.upsample else 1,
                            ostride=2 if conv.upsample else 1, in_scale=s, out_scale=d, noise=nz,
@@ -307,9 +311,11 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
         self.mask_op = mask_op
 
-    def run_nhwc(self, x, s, labels, num_regions, skip):
+    def run_nhwc(self, x, s, labels, num_regions, skip, rec=None):
         pk = self.conv.packed()
         ws = K.rgb_weights(pk["w"].view(3, -1), s, self.conv.scale)
+        if rec is not None:
+            rec.update(ws=ws)
         k4 = self.upsample.kernel if skip is not None else None
         return K.torgb(x, ws, self.bias, skip, k4, labels, num_regions)
 
@@ -414,16 +420,21 @@ class Generator(nn.Module):
         if noise is None:
             noise = [None] * self.num_layers if randomize_noise else \
                 [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
-        if torch.is_grad_enabled() and (latent.requires_grad or any(
-                n is not None and n.requires_grad for n in noise)):
-            raise NotImplementedError(
-                "autograd through the fused HIP generator (SURVEY.md 8(f) N1, backward kernels) is not built yet; "
-                "call under torch.no_grad() for inference")
-        image, feats = self._fused_forward(latent, mask, noise)
+        if torch.is_grad_enabled() and any(n is not None and n.requires_grad for n in noise):
+            raise NotImplementedError("gradients w.r.t. the injected noise maps are not implemented")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("weight gradients of the fused generator (config 5, train_G=True) are not "
+                                      "built yet; freeze G (Net3 opts.train_G=False) or use torch.no_grad()")
+        if torch.is_grad_enabled() and latent.requires_grad:
+            from .autograd import GeneratorFn
+            image, feats = GeneratorFn.apply(self, latent, mask, noise)
+        else:
+            image, feats = self._fused_forward(latent, mask, noise)
         return (image, latent, feats) if return_latents else (image, None, feats)
 
     @torch.no_grad()
-    def _fused_forward(self, latent, mask, noise):
+    def _fused_forward(self, latent, mask, noise, tape=None):
+        """`tape` (a list) records per layer what the backward needs (e4s_amd/autograd.py)."""
         lat = latent.detach().to(torch.float32).contiguous()
         b, r = lat.shape[:2]
         labels, _flags = K.mask_labels(mask)
@@ -431,12 +442,24 @@ class Generator(nn.Module):
         def styled(layer, x, idx, nz):
             mod = layer.conv.modulation
             s = K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
-            return layer.run_nhwc(x, s, nz, labels if layer.mask_op else None, r)
+            rec = {} if tape is not None else None
+            y = layer.run_nhwc(x, s, nz, labels if layer.mask_op else None, r, rec=rec)
+            if tape is not None:
+                rec.update(kind="conv", layer=layer, idx=idx, masked=layer.mask_op, x=x, y=y, s=s,
+                           labels=labels if layer.mask_op else None)
+                tape.append(rec)
+            return y
 
         def rgb(layer, x, idx, skip):
             mod = layer.conv.modulation
             s = K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
-            return layer.run_nhwc(x, s, labels if layer.mask_op else None, r, skip)
+            rec = {} if tape is not None else None
+            out = layer.run_nhwc(x, s, labels if layer.mask_op else None, r, skip, rec=rec)
+            if tape is not None:
+                rec.update(kind="rgb", layer=layer, idx=idx, masked=layer.mask_op, x=x, has_skip=skip is not None, out=out,
+                           labels=labels if layer.mask_op else None)
+                tape.append(rec)
+            return out
 
         x = K.const_input(self.input.input, b)
         x = styled(self.conv1, x, 0, noise[0])
@@ -447,6 +470,8 @@ class Generator(nn.Module):
             x = styled(conv1, x, i, noise[i])
             if i + 2 == self.split_layer_idx:
                 feats = K.nhwc_to_nchw(x)                                          # model.py:642-647
+                if tape is not None:
+                    tape[-1]["is_feats"] = True
             x = styled(conv2, x, i + 1, noise[i + 1])
             skip = rgb(to_rgb, x, i + 2, skip)
             i += 2

@@ -133,6 +133,38 @@ typedef struct {
  * (natural order, istride == 1, Ha % 8 == 0, Wa % 16 == 0). */
 int e4s_conv_mfma_f32(const e4s_conv_params* p, int spatial, void* stream);
 
+/* ---- backward of the fused generator (configs 3 and 5) -------------------- */
+typedef struct {
+    const float* gz;         /* dL/d(out_pre), NHWC [B, Hy, Wy, Cy]  (Cy = forward Cout) */
+    const float* wt;         /* e4s_pack_taps_bwd_f32 layout [ncls][9][Cx][Cy] */
+    float* dx;               /* out: NHWC [B, Hx, Wx, Cx]  (Cx = forward Cin) */
+    const float* x;          /* forward input, NHWC [B, Hx, Wx, Cx] (needed for ds) */
+    float* ds;               /* out (atomically accumulated, zero it first): [G][Cx] grad w.r.t. the modulation s; or NULL */
+    const float* s;          /* [G][Cx] forward modulation, or NULL (= 1) */
+    const float* d;          /* [G][Cy] forward demodulation coefficient (x conv scale), or NULL (= 1) */
+    const uint8_t* labels;   /* [B,Hm,Wm] label map; group = b*R + label(output pixel); NULL: group = b */
+    int Hm, Wm, R;
+    int B, Hx, Wx, Cx, Hy, Wy, Cy;
+    int ncls;                /* 1: 3x3 stride-1 conv; 4: polyphase up-conv (Hy = 2*Hx) */
+} e4s_conv_bwd_params;
+
+/* dx[q,ci] = sum_{tap} s[r(p),ci] * sum_co wt[tap,ci,co] * d[r(p),co] * gz[p,co]   (p = pixel fed by q through tap)
+ * ds[g,ci] += sum_{q,tap: r(p)=g} x[q,ci] * (sum_co wt*d*gz)      -- one fp32-MFMA pass, Cx % 64 == 0, Cy % 32 == 0 */
+int e4s_conv_bwd_mfma_f32(const e4s_conv_bwd_params* p, void* stream);
+/* forward-packed weights [ncls][9][Cout][Cin] -> backward layout [ncls][9][Cin][Cout], taps flipped */
+int e4s_pack_taps_bwd_f32(const float* w, float* wt, int ncls, int cout, int cin, void* stream);
+/* dd[b,r,co] = sum_{p in r} gz[p,co] * (lrelu^-1(y[p,co])/gain - noise_w*noise[p] - bias[co])   (= d * dL/dd; the
+ * caller divides by d); dd is overwritten */
+int e4s_demod_grad_f32(const float* gz, const float* y, const float* noise, const float* noise_w,
+                       int64_t noise_bstride, const float* bias, float alpha, float gain,
+                       const uint8_t* labels, int Hm, int Wm, int R, float* dd, int B, int H, int W, int C,
+                       void* stream);
+/* ToRGB backward: dws[g,c,ci] = sum_{p in g} drgb[b,c,p]*x[p,ci] (overwritten); dx[p,ci] (+)= sum_c drgb*ws[g(p),c,ci] */
+int e4s_torgb_bwd_w_f32(const float* drgb, const float* x, const uint8_t* labels, int Hm, int Wm, int R,
+                        float* dws, int B, int H, int W, int C, void* stream);
+int e4s_torgb_bwd_x_f32(const float* drgb, const float* ws, const uint8_t* labels, int Hm, int Wm, int R,
+                        float* dx, int B, int H, int W, int C, int accumulate, void* stream);
+
 /* ---- ToRGB (model.py:422-448) -------------------------------------------------------------- */
 /* out[b,c,y,x] = sum_ci x[b,y,x,ci]*ws[g,c,ci] + bias[c] + upfirdn2d(skip, k4, up=2, pad=(2,1))
  * x NHWC, out/skip NCHW; labels ([B,Hm,Wm] label map) NULL => group = b (unmasked). */
