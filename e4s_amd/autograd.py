@@ -14,6 +14,24 @@ import torch
 from . import kernels as K
 
 
+def styled_conv_backward(rec, dy, num_regions):
+    """Backward of one fused StyledConv launch.  rec: the forward tape record (layer, x, y, s, d, noise, labels);
+    dy: dL/dy NHWC.  Returns (dL/dx NHWC, dL/ds [G,Cin] including the path through the demodulation d(s))."""
+    layer = rec["layer"]
+    conv, act = layer.conv, layer.activate
+    y, s, d, labels = rec["y"], rec["s"], rec["d"], rec["labels"]
+    gz = K.fused_bias_act(dy, None, y, 3, 1, act.negative_slope, act.scale)     # lrelu'(y) * sqrt(2) * dy
+    dd = K.demod_grad(gz, y, rec["noise"], layer.noise.weight, act.bias, act.negative_slope, act.scale, labels,
+                      num_regions) / d                                          # dL/dd  (out_pre = d * c)
+    pk = conv.packed()
+    if "wt" not in pk:
+        pk["wt"] = K.pack_taps_bwd(pk["w"])
+    dx, ds = K.conv_bwd(gz, pk["wt"], rec["x"], s, d, labels, num_regions, 4 if conv.upsample else 1)
+    # d = scale * rsqrt(scale^2 sum_ci s^2 Wsq + eps)  =>  dd/ds_ci = -d^3 s_ci Wsq[co,ci]
+    ds = ds - s * ((dd * d * d * d) @ pk["wsq"])
+    return dx, ds
+
+
 class GeneratorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gen, latent, mask, noise):
@@ -60,21 +78,10 @@ class GeneratorFn(torch.autograd.Function):
                     dskip = None
                 continue
             # styled conv
-            conv = layer.conv
-            y = rec["y"]
             if rec.get("is_feats") and dfeats is not None:
-                dact = dact + K.nchw_to_nhwc(dfeats.contiguous()) if dact is not None else K.nchw_to_nhwc(dfeats.contiguous())
-            gz = K.fused_bias_act(dact, None, y, 3, 1, layer.activate.negative_slope, layer.activate.scale)
-            labels = rec["labels"]
-            dd = K.demod_grad(gz, y, rec["noise"], layer.noise.weight, layer.activate.bias,
-                              layer.activate.negative_slope, layer.activate.scale, labels, r)
-            s, d = rec["s"], rec["d"]
-            dd = dd / d
-            pk = conv.packed()
-            if "wt" not in pk:
-                pk["wt"] = K.pack_taps_bwd(pk["w"])
-            dact, ds = K.conv_bwd(gz, pk["wt"], rec["x"], s, d, labels, r, 4 if conv.upsample else 1)
-            ds = ds - s * ((dd * d * d * d) @ pk["wsq"])
+                df = K.nchw_to_nhwc(dfeats.contiguous())
+                dact = df if dact is None else dact + df
+            dact, ds = styled_conv_backward(rec, dact, r)
             add_style_grad(rec, ds)
         return None, dlat, None, None
 

@@ -40,6 +40,7 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
     """
     n, c, h, w = x.shape
     kh, kw = kernel.shape
+    kernel = kernel.to(x.dtype)
     p0, p1 = pad
     y = x.reshape(n * c, 1, h, w)
     if up > 1:

@@ -373,13 +373,26 @@ def test_generator_backward_vs_oracle_autograd(size, K, cells):
     img, _, feats = gen([lat_d], None, mask.to(DEV), input_is_latent=True, noise=[n.to(DEV) for n in noise])
     ((img * w_img.to(DEV)).sum() + (feats * w_ft.to(DEV)).sum()).backward()
 
-    lat_r = lat.clone().requires_grad_(True)
-    sd_g = {"G." + k: v for k, v in sd.items()}
-    img_r, feats_r = orc.generator_forward(sd_g, lat_r, mask, noise, size, K)
-    ((img_r * w_img).sum() + (feats_r * w_ft).sum()).backward()
-    assert maxabs(img, img_r) < 1e-4
-    scale = float(lat_r.grad.abs().max())
-    assert maxabs(lat_d.grad, lat_r.grad) < 2e-4 * scale, (maxabs(lat_d.grad, lat_r.grad), scale)
+    # Oracle autograd twice: fp32 (what the reference computes) and fp64 (ground truth).  The latent gradient is a
+    # sum over all pixels/channels with heavy cancellation, so fp32 implementations differ by accumulation noise that
+    # grows with resolution; the HIP path must be as close to the fp64 truth as the fp32 reference itself is
+    # (within 3x), and within 2e-4 of the gradient scale where that noise is negligible.
+    grads = {}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        lat_r = lat.detach().clone().to(dt).requires_grad_(True)
+        sd_g = {"G." + k: v.to(dt) for k, v in sd.items()}
+        img_r, feats_r = orc.generator_forward(sd_g, lat_r, mask.to(dt), [n.to(dt) for n in noise], size, K)
+        ((img_r * w_img.to(dt)).sum() + (feats_r * w_ft.to(dt)).sum()).backward()
+        grads[name] = lat_r.grad
+        if name == "f32":
+            assert maxabs(img, img_r) < 1e-4
+    scale = float(grads["f64"].abs().max())
+    ref_noise = maxabs(grads["f32"], grads["f64"])
+    err = maxabs(lat_d.grad, grads["f64"])
+    assert err < max(3.0 * ref_noise, 2e-4 * scale), (err, ref_noise, scale)
+    # unmasked layers only read region 0 (model.py:655-657): no gradient may leak to the other regions' rows
+    if K < gen.n_latent:
+        assert float(lat_d.grad[:, 1:, K + 1:].abs().max()) == 0.0
 
 
 def test_style_codes_backward_vs_oracle_autograd():
@@ -427,3 +440,45 @@ def test_optimization_step_runs_and_descends():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("cin,cout,res,up,masked", [(64, 64, 16, False, True), (64, 64, 16, True, True),
+                                                     (128, 64, 32, False, False), (64, 64, 24, True, False),
+                                                     (512, 512, 8, False, True)])
+def test_styled_conv_backward_vs_oracle_f64(cin, cout, res, up, masked):
+    """One fused StyledConv: dL/dx (per-pixel, tight) and dL/dstyle against the oracle's fp64 autograd."""
+    from e4s_amd import kernels as K
+    from e4s_amd.autograd import styled_conv_backward
+    from e4s_amd.stylegan2 import StyledConv
+    sd = _styled_sd(cin, cout, up, 21)
+    m = StyledConv(cin, cout, 3, 512, upsample=up, mask_op=masked)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(50)
+    b, r = 2, 12
+    x = torch.randn(b, cin, res, res, generator=g)
+    style = torch.randn(b, r, 512, generator=g) if masked else torch.randn(b, 512, generator=g)
+    mask = synth.onehot(synth.synth_labels_blocks(b, 512, 16, seed=5))
+    ores = res * 2 if up else res
+    noise = torch.randn(b, 1, ores, ores, generator=g)
+    wgt = torch.randn(b, cout, ores, ores, generator=g)
+
+    xd = K.nchw_to_nhwc(x.to(DEV))
+    mod = m.conv.modulation
+    s = K.modulate_vec(style.reshape(-1, 512).to(DEV), mod.weight, mod.bias)
+    labels = K.mask_labels(mask.to(DEV))[0] if masked else None
+    rec = {}
+    y = m.run_nhwc(xd, s, noise.to(DEV), labels, r, rec=rec)
+    rec.update(layer=m, x=xd, y=y, s=s, labels=labels)
+    dx, ds = styled_conv_backward(rec, K.nchw_to_nhwc(wgt.to(DEV)), r)
+    dstyle = (ds @ mod.weight.detach()) * mod.scale
+
+    f64 = torch.float64
+    sd64 = {k: v.to(f64) for k, v in sd.items()}
+    xr = x.to(f64).requires_grad_(True)
+    sr = style.to(f64).requires_grad_(True)
+    yr = orc.styled_conv(sd64, "", xr, sr, mask.to(f64), noise.to(f64), up, masked)
+    (yr * wgt.to(f64)).sum().backward()
+    assert maxabs(K.nhwc_to_nchw(y), yr) < 5e-5
+    assert maxabs(K.nhwc_to_nchw(dx), xr.grad) < 1e-4 * float(xr.grad.abs().max())
+    assert maxabs(dstyle.view_as(sr), sr.grad) < 2e-4 * float(sr.grad.abs().max())
