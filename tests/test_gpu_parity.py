@@ -482,3 +482,50 @@ def test_styled_conv_backward_vs_oracle_f64(cin, cout, res, up, masked):
     assert maxabs(K.nhwc_to_nchw(y), yr) < 5e-5
     assert maxabs(K.nhwc_to_nchw(dx), xr.grad) < 1e-4 * float(xr.grad.abs().max())
     assert maxabs(dstyle.view_as(sr), sr.grad) < 2e-4 * float(sr.grad.abs().max())
+
+
+@pytest.mark.parametrize("cin,res,masked,with_skip", [(512, 8, True, True), (128, 32, False, True), (512, 4, True, False)])
+def test_torgb_backward_vs_oracle_f64(cin, res, masked, with_skip):
+    """ToRGB inside the fused generator: gradients w.r.t. activation, style and skip against fp64 autograd."""
+    from e4s_amd import kernels as K
+    from e4s_amd.stylegan2 import ToRGB
+    spec = [("bias", (1, 3, 1, 1), "bias"), ("conv.weight", (1, 3, cin, 1, 1), "randn"),
+            ("conv.modulation.weight", (cin, 512), "randn"), ("conv.modulation.bias", (cin,), "modbias")]
+    sd = {k: synth.synth_tensor(k, s, kind, 3) for k, s, kind in spec}
+    m = ToRGB(cin, 512, upsample=with_skip, mask_op=masked)
+    if with_skip:
+        sd["upsample.kernel"] = orc.make_blur_kernel() * 4
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(51)
+    b, r = 2, 12
+    x = torch.randn(b, cin, res, res, generator=g)
+    style = torch.randn(b, r, 512, generator=g) if masked else torch.randn(b, 512, generator=g)
+    mask = synth.onehot(synth.synth_labels_blocks(b, 512, 8, seed=6))
+    skip = torch.randn(b, 3, res // 2, res // 2, generator=g) if with_skip else None
+    wgt = torch.randn(b, 3, res, res, generator=g)
+
+    xd = K.nchw_to_nhwc(x.to(DEV))
+    mod = m.conv.modulation
+    s = K.modulate_vec(style.reshape(-1, 512).to(DEV), mod.weight, mod.bias)
+    labels = K.mask_labels(mask.to(DEV))[0] if masked else None
+    rec = {}
+    out = m.run_nhwc(xd, s, labels, r, None if skip is None else skip.to(DEV), rec=rec)
+    dx, dws = K.torgb_bwd(wgt.to(DEV), xd, rec["ws"], labels, r)
+    ds = m.conv.scale * (dws * m.conv.weight.detach()[0, :, :, 0, 0].unsqueeze(0)).sum(1)
+    dstyle = (ds @ mod.weight.detach()) * mod.scale
+
+    f64 = torch.float64
+    sd64 = {k: v.to(f64) for k, v in sd.items()}
+    xr, sr = x.to(f64).requires_grad_(True), style.to(f64).requires_grad_(True)
+    kr = None if skip is None else skip.to(f64).requires_grad_(True)
+    outr = orc.to_rgb(sd64, "", xr, sr, mask.to(f64), kr, masked)
+    (outr * wgt.to(f64)).sum().backward()
+    assert maxabs(out, outr) < 5e-5
+    assert maxabs(K.nhwc_to_nchw(dx), xr.grad) < 1e-4 * float(xr.grad.abs().max())
+    assert maxabs(dstyle.view_as(sr), sr.grad) < 2e-4 * float(sr.grad.abs().max())
+    if with_skip:
+        n, c, h, w = wgt.shape
+        dsk = K.upfirdn2d_raw(wgt.to(DEV).reshape(n * c, h, w, 1), torch.flip(m.upsample.kernel, [0, 1]), 1, 1, 2, 2,
+                              1, 1, 1, 1).view(n, c, h // 2, w // 2)
+        assert maxabs(dsk, kr.grad) < 1e-4 * float(kr.grad.abs().max())
