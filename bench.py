@@ -88,6 +88,38 @@ def headline_probe(net, batch, mask, reps):
             "traffic": traffic, "avg_launch_ms": round(ms, 4), "flop_per_launch": flops}
 
 
+def optimisation_leg(net, one, steps):
+    """BASELINE.json configs[2] in miniature (scripts/optimization.py:209-232): Adam(lr=1e-2) on the [1,12,1280]
+    regional style vectors through cal_style_codes -> gen_img (fresh noise every step, as the script does) with an
+    MSE loss against the target; the LPIPS/ID/parsing loss networks are out of scope."""
+    import warnings
+    driven, dm, target, tm, sm, _noise = one
+    for p in net.parameters():
+        p.requires_grad = False
+    with torch.no_grad():
+        sv, _ = net.get_style_vectors(target, tm)
+    latent = sv.clone().requires_grad_(True)
+    opt = torch.optim.Adam([latent], lr=1e-2)
+
+    def one_step():
+        opt.zero_grad()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            codes = net.cal_style_codes(latent)
+        img, _, _ = net.gen_img(None, codes, tm, randomize_noise=True)
+        loss = torch.nn.functional.mse_loss(img, target)
+        loss.backward()
+        opt.step()
+    for _ in range(2):
+        one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    return round((time.perf_counter() - t0) / steps * 1e3, 3)
+
+
 def cpu_baseline(sd, lat, inputs, hip_img0):
     """One swap (sample 0 of the bench batch) on the host cores with the CPU oracle."""
     from oracle import e4s_oracle as orc
@@ -114,6 +146,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the ~700 launches per step eagerly instead of "
                                                             "replaying one captured HIP graph")
+    ap.add_argument("--opt-steps", type=int, default=5, help="configs[2] leg: time this many W+ optimisation steps "
+                                                             "(cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam)")
     ap.add_argument("--probe-only", action="store_true", help="run only the headline-kernel probe (for rocprofv3)")
     ap.add_argument("--probe-reps", type=int, default=20)
     args = ap.parse_args()
@@ -201,6 +235,8 @@ def main():
         torch.cuda.synchronize()
         out["latency_b1_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
         out["roofline"] = headline_probe(net, B, inputs[4], args.probe_reps)
+        if args.opt_steps > 0:
+            out["config3_opt_step_ms"] = optimisation_leg(net, one, args.opt_steps)
         if not args.no_cpu_baseline:
             cb, err = cpu_baseline(sd, lat, inputs, img1[0:1])
             out["cpu_baseline"] = cb
