@@ -19,14 +19,16 @@ __global__ void demod_grad_kernel(const float* __restrict__ gz, const float* __r
                                   const uint8_t* __restrict__ labels, int Hm, int Wm, int R,
                                   float* __restrict__ dd, int H, int W, int C, int nsplit) {
     extern __shared__ float sums[];        // [NPG][R][64]
-    const int slabs = C / 64;
+    const int cw = C >= 64 ? 64 : C;       // channels per slab (C = 32 at the 1024^2 layers)
+    const int slabs = C / cw;
     const int split = blockIdx.x % nsplit;
     const int slab = (blockIdx.x / nsplit) % slabs;
     const int b = blockIdx.x / (nsplit * slabs);
     const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
     for (int t = threadIdx.x; t < NPG * R * 64; t += blockDim.x) sums[t] = 0.f;
     __syncthreads();
-    const int HW = H * W, c = slab * 64 + cl;
+    const bool live = cl < cw;
+    const int HW = H * W, c = slab * cw + (live ? cl : 0);
     const int per = (HW + nsplit - 1) / nsplit;
     const int p0 = split * per, p1 = min(p0 + per, HW);
     const float nw = noise ? noise_w[0] : 0.f, bs = bias ? bias[c] : 0.f;
@@ -40,14 +42,15 @@ __global__ void demod_grad_kernel(const float* __restrict__ gz, const float* __r
         const float yv = y[idx];
         const float z = yv > 0.f ? yv * inv_pos : yv * inv_neg;
         const float nz = noise ? nw * noise[(int64_t)b * noise_bstride + p] : 0.f;
-        mine[lab * 64] += gz[idx] * (z - nz - bs);
+        if (live) mine[lab * 64] += gz[idx] * (z - nz - bs);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < R * 64; t += blockDim.x) {
         const int r = t / 64, cc = t % 64;
+        if (cc >= cw) continue;
         float s = 0.f;
         for (int j = 0; j < NPG; ++j) s += sums[(j * R + r) * 64 + cc];
-        if (s != 0.f) atomicAdd(&dd[((int64_t)b * R + r) * C + slab * 64 + cc], s);
+        if (s != 0.f) atomicAdd(&dd[((int64_t)b * R + r) * C + slab * cw + cc], s);
     }
 }
 
@@ -56,14 +59,16 @@ __global__ void torgb_bwd_w_kernel(const float* __restrict__ drgb, const float* 
                                    const uint8_t* __restrict__ labels, int Hm, int Wm, int R,
                                    float* __restrict__ dws, int H, int W, int C, int nsplit) {
     extern __shared__ float sums[];        // [NPG][R][3][64]
-    const int slabs = C / 64;
+    const int cw = C >= 64 ? 64 : C;
+    const int slabs = C / cw;
     const int split = blockIdx.x % nsplit;
     const int slab = (blockIdx.x / nsplit) % slabs;
     const int b = blockIdx.x / (nsplit * slabs);
     const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
     for (int t = threadIdx.x; t < NPG * R * 3 * 64; t += blockDim.x) sums[t] = 0.f;
     __syncthreads();
-    const int HW = H * W, c = slab * 64 + cl;
+    const bool live = cl < cw;
+    const int HW = H * W, c = slab * cw + (live ? cl : 0);
     const int per = (HW + nsplit - 1) / nsplit;
     const int p0 = split * per, p1 = min(p0 + per, HW);
     float* mine = sums + (pg * R) * 3 * 64 + cl;
@@ -73,14 +78,16 @@ __global__ void torgb_bwd_w_kernel(const float* __restrict__ drgb, const float* 
         if (labels) lab = labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
         const float xv = x[((int64_t)b * HW + p) * C + c];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) mine[(lab * 3 + ch) * 64] += drgb[((int64_t)b * 3 + ch) * HW + p] * xv;
+        for (int ch = 0; ch < 3; ++ch)
+            if (live) mine[(lab * 3 + ch) * 64] += drgb[((int64_t)b * 3 + ch) * HW + p] * xv;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < R * 3 * 64; t += blockDim.x) {
         const int cc = t % 64, ch = (t / 64) % 3, r = t / 192;
+        if (cc >= cw) continue;
         float s = 0.f;
         for (int j = 0; j < NPG; ++j) s += sums[((j * R + r) * 3 + ch) * 64 + cc];
-        if (s != 0.f) atomicAdd(&dws[(((int64_t)b * R + r) * 3 + ch) * C + slab * 64 + cc], s);
+        if (s != 0.f) atomicAdd(&dws[(((int64_t)b * R + r) * 3 + ch) * C + slab * cw + cc], s);
     }
 }
 
@@ -117,14 +124,15 @@ extern "C" int e4s_demod_grad_f32(const float* gz, const float* y, const float* 
                                   int64_t noise_bstride, const float* bias, float alpha, float gain,
                                   const uint8_t* labels, int Hm, int Wm, int R, float* dd, int B, int H, int W, int C,
                                   void* stream) {
-    if (C % 64 || R < 1 || R > 16) return (int)hipErrorInvalidValue;
+    if (C % 32 || (C > 64 && C % 64) || R < 1 || R > 16) return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
     hipError_t e = hipMemsetAsync(dd, 0, sizeof(float) * (size_t)B * R * C, st);
     if (e != hipSuccess) return (int)e;
-    int nsplit = 1024 / (B * (C / 64));
+    const int slabs = C >= 64 ? C / 64 : 1;
+    int nsplit = 1024 / (B * slabs);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > (H * W) / 64) nsplit = (H * W) / 64 > 0 ? (H * W) / 64 : 1;
-    hipLaunchKernelGGL(demod_grad_kernel, dim3(B * (C / 64) * nsplit), dim3(64 * NPG), sizeof(float) * NPG * R * 64, st,
+    hipLaunchKernelGGL(demod_grad_kernel, dim3(B * slabs * nsplit), dim3(64 * NPG), sizeof(float) * NPG * R * 64, st,
                        gz, y, noise, noise_w, noise_bstride, bias, alpha, gain, labels, Hm, Wm, R, dd, H, W, C, nsplit);
     E4S_CHECK_LAUNCH();
     return 0;
@@ -132,14 +140,15 @@ extern "C" int e4s_demod_grad_f32(const float* gz, const float* y, const float* 
 
 extern "C" int e4s_torgb_bwd_w_f32(const float* drgb, const float* x, const uint8_t* labels, int Hm, int Wm, int R,
                                    float* dws, int B, int H, int W, int C, void* stream) {
-    if (C % 64 || R < 1 || R > 16) return (int)hipErrorInvalidValue;
+    if (C % 32 || (C > 64 && C % 64) || R < 1 || R > 16) return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
     hipError_t e = hipMemsetAsync(dws, 0, sizeof(float) * (size_t)B * R * 3 * C, st);
     if (e != hipSuccess) return (int)e;
-    int nsplit = 1024 / (B * (C / 64));
+    const int slabs = C >= 64 ? C / 64 : 1;
+    int nsplit = 1024 / (B * slabs);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > (H * W) / 64) nsplit = (H * W) / 64 > 0 ? (H * W) / 64 : 1;
-    hipLaunchKernelGGL(torgb_bwd_w_kernel, dim3(B * (C / 64) * nsplit), dim3(64 * NPG), sizeof(float) * NPG * R * 3 * 64,
+    hipLaunchKernelGGL(torgb_bwd_w_kernel, dim3(B * slabs * nsplit), dim3(64 * NPG), sizeof(float) * NPG * R * 3 * 64,
                        st, drgb, x, labels, Hm, Wm, R, dws, H, W, C, nsplit);
     E4S_CHECK_LAUNCH();
     return 0;

@@ -18,9 +18,10 @@
 namespace {
 
 constexpr int KC = 32, LDA = 36, NTHR = 256;
-constexpr int BM = 128, BN = 64, TH = 8, TW = 16, MAXR = 16;
-constexpr int TM = 2, TN = 1, WN = 2;          // 4 waves as 2 (M) x 2 (N); wave tile 64 x 32
+constexpr int BM = 128, TH = 8, TW = 16, MAXR = 16;
+// BN = 64: 4 waves as 2 (M) x 2 (N), wave tile 64 x 32 (TM = 2);  BN = 32 (Cin = 32 layers): 4 x 1, wave tile 32 x 32
 
+template <int BN>
 struct BwdSmem {
     int out_off[BM];                 // dx pixel index of each row, -1 if outside
     int yx[BM];                      // (qy << 16) | qx
@@ -32,9 +33,11 @@ struct BwdSmem {
     float B[2][BN * LDA];
 };
 
+template <int BN>
 __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_params p, const int ntn) {
+    constexpr int WN = BN / 32, WM = 4 / WN, TM = BM / (WM * 32);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    BwdSmem& sm = *reinterpret_cast<BwdSmem*>(smem_raw);
+    BwdSmem<BN>& sm = *reinterpret_cast<BwdSmem<BN>*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -224,27 +227,33 @@ __global__ void pack_bwd_kernel(const float* __restrict__ w, float* __restrict__
     wt[i] = w[(((int64_t)cls * 9 + (8 - tp)) * cout + co) * cin + ci];
 }
 
-}  // namespace
-
-extern "C" int e4s_conv_bwd_mfma_f32(const e4s_conv_bwd_params* pp, void* stream) {
-    const e4s_conv_bwd_params& p = *pp;
-    if (p.Cx % BN || p.Cy % KC || (p.ncls != 1 && p.ncls != 4)) return (int)hipErrorInvalidValue;
-    if (p.labels && (p.R < 1 || p.R > MAXR)) return (int)hipErrorInvalidValue;
-    if (p.Hy != p.Hx * (p.ncls == 4 ? 2 : 1) || p.Wy != p.Wx * (p.ncls == 4 ? 2 : 1)) return (int)hipErrorInvalidValue;
-    if (p.ds && !p.x) return (int)hipErrorInvalidValue;
+template <int BN>
+int launch_bwd(const e4s_conv_bwd_params& p, int mtiles, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BwdSmem));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BwdSmem<BN>));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int ntn = p.Cx / BN;
-    const int mtiles = p.B * ((p.Hx + TH - 1) / TH) * ((p.Wx + TW - 1) / TW);
-    if (mtiles <= 0) return 0;
-    hipLaunchKernelGGL(conv_bwd_kernel, dim3(mtiles * ntn), dim3(NTHR), sizeof(BwdSmem), as_stream(stream), p, ntn);
+    hipLaunchKernelGGL(conv_bwd_kernel<BN>, dim3(mtiles * ntn), dim3(NTHR), sizeof(BwdSmem<BN>), st, p, ntn);
     E4S_CHECK_LAUNCH();
     return 0;
+}
+
+}  // namespace
+
+extern "C" int e4s_conv_bwd_mfma_f32(const e4s_conv_bwd_params* pp, void* stream) {
+    const e4s_conv_bwd_params& p = *pp;
+    if (p.Cx % 32 || p.Cy % KC || (p.ncls != 1 && p.ncls != 4)) return (int)hipErrorInvalidValue;
+    if (p.labels && (p.R < 1 || p.R > MAXR)) return (int)hipErrorInvalidValue;
+    if (p.Hy != p.Hx * (p.ncls == 4 ? 2 : 1) || p.Wy != p.Wx * (p.ncls == 4 ? 2 : 1)) return (int)hipErrorInvalidValue;
+    if (p.ds && !p.x) return (int)hipErrorInvalidValue;
+    const int mtiles = p.B * ((p.Hx + TH - 1) / TH) * ((p.Wx + TW - 1) / TW);
+    if (mtiles <= 0) return 0;
+    if (p.Cx % 64 == 0) return launch_bwd<64>(p, mtiles, as_stream(stream));
+    return launch_bwd<32>(p, mtiles, as_stream(stream));
 }
 
 extern "C" int e4s_pack_taps_bwd_f32(const float* w, float* wt, int ncls, int cout, int cin, void* stream) {

@@ -446,7 +446,8 @@ def test_optimization_step_runs_and_descends():
 
 @pytest.mark.parametrize("cin,cout,res,up,masked", [(64, 64, 16, False, True), (64, 64, 16, True, True),
                                                      (128, 64, 32, False, False), (64, 64, 24, True, False),
-                                                     (512, 512, 8, False, True)])
+                                                     (512, 512, 8, False, True), (32, 32, 32, False, False),
+                                                     (64, 32, 16, True, False)])
 def test_styled_conv_backward_vs_oracle_f64(cin, cout, res, up, masked):
     """One fused StyledConv: dL/dx (per-pixel, tight) and dL/dstyle against the oracle's fp64 autograd."""
     from e4s_amd import kernels as K
@@ -486,7 +487,8 @@ def test_styled_conv_backward_vs_oracle_f64(cin, cout, res, up, masked):
     assert maxabs(dstyle.view_as(sr), sr.grad) < 2e-4 * float(sr.grad.abs().max())
 
 
-@pytest.mark.parametrize("cin,res,masked,with_skip", [(512, 8, True, True), (128, 32, False, True), (512, 4, True, False)])
+@pytest.mark.parametrize("cin,res,masked,with_skip", [(512, 8, True, True), (128, 32, False, True), (512, 4, True, False),
+                                                       (32, 32, False, True)])
 def test_torgb_backward_vs_oracle_f64(cin, res, masked, with_skip):
     """ToRGB inside the fused generator: gradients w.r.t. activation, style and skip against fp64 autograd."""
     from e4s_amd import kernels as K
