@@ -148,6 +148,7 @@ def main():
                                                             "replaying one captured HIP graph")
     ap.add_argument("--opt-steps", type=int, default=5, help="configs[2] leg: time this many W+ optimisation steps "
                                                              "(cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam)")
+    ap.add_argument("--steps-only", action="store_true", help="only the timed steps (clean rocprofv3 kernel traces)")
     ap.add_argument("--probe-only", action="store_true", help="run only the headline-kernel probe (for rocprofv3)")
     ap.add_argument("--probe-reps", type=int, default=20)
     args = ap.parse_args()
@@ -219,7 +220,7 @@ def main():
                                   "mask-guided StyleGAN2 generator K=13), BASELINE.json configs[3] shard: "
                                   f"{B} swaps per GPU per step", "per_gpu_batch": B, "global_batch": B * world,
                       "out_size": SIZE, "hip_graph": not args.no_graph, "parallelism": f"image-parallel x{world}" + (", RCCL all_gather of outputs" if world > 1 else "")}}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.steps_only:
         # configs[1]: single-swap latency
         one = [t[:1].contiguous() if torch.is_tensor(t) else [n[:1].contiguous() for n in t] for t in inputs]
         swap1 = (lambda *a, noise: face_swap_core(net, *a, noise=noise)) if args.no_graph else None

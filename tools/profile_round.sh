@@ -12,7 +12,7 @@ RAW=/tmp/e4s_prof
 mkdir -p "$OUT" "$RAW"
 run() { name=$1; shift; timeout 300 rocprofv3 "$@" > "$RAW/$name.log" 2>&1; echo "$name rc=$?"; }
 run probe --kernel-trace --stats -f csv -d $RAW/probe -o probe -- python bench.py --probe-only --probe-reps 50
-run bench --kernel-trace --stats -f csv -d $RAW/bench -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph
+run bench --kernel-trace --stats -f csv -d $RAW/bench -o bench -- python bench.py --steps 4 --warmup 1 --steps-only --no-graph
 run fetch --kernel-trace --pmc FETCH_SIZE -f csv -d $RAW/fetch -o fetch -- python bench.py --probe-only --probe-reps 10
 run write --kernel-trace --pmc WRITE_SIZE -f csv -d $RAW/write -o write -- python bench.py --probe-only --probe-reps 10
 run sq --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -f csv -d $RAW/sq -o sq -- python bench.py --probe-only --probe-reps 10
