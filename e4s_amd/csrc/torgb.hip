@@ -150,6 +150,47 @@ __global__ __launch_bounds__(256) void torgb_pixel_kernel(const float* __restric
     }
 }
 
+// Soft-mask fallback (reference formulation, model.py:391-398): out (+)= y * nearest(mask)[:, r].
+// channels_last = 1: y/out are NHWC [B,H,W,C];  0: NCHW [B,C,H,W].
+__global__ void mask_mul_add_kernel(const float* __restrict__ y, const float* __restrict__ mask, float* __restrict__ out,
+                                    int r, int B, int H, int W, int C, int R, int Hm, int Wm, int channels_last,
+                                    int accumulate) {
+    const int64_t n = (int64_t)B * H * W * C;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int b, yy, xx;
+    if (channels_last) {
+        int64_t p = i / C;
+        xx = (int)(p % W); p /= W;
+        yy = (int)(p % H);
+        b = (int)(p / H);
+    } else {
+        int64_t p = i;
+        xx = (int)(p % W); p /= W;
+        yy = (int)(p % H); p /= H;
+        b = (int)(p / C);
+    }
+    const float m = mask[(((int64_t)b * R + r) * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
+    const float v = y[i] * m;
+    out[i] = accumulate ? out[i] + v : v;
+}
+
+// NoiseInjection + FusedLeakyReLU on an NHWC tensor (only the soft-mask fallback needs it as a separate pass;
+// the fused path does this in the conv epilogue): y = lrelu(x + nw*noise[b,p] + bias[c]) * gain
+__global__ void noise_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                      const float* __restrict__ noise_w, int64_t noise_bstride,
+                                      const float* __restrict__ bias, float* __restrict__ y, int64_t HW, int C,
+                                      int64_t n, float alpha, float gain) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    const int64_t b = pix / HW, p = pix - b * HW;
+    float v = x[i] + (bias ? bias[c] : 0.f);
+    if (noise) v += noise_w[0] * noise[b * noise_bstride + p];
+    y[i] = (v > 0.f ? v : v * alpha) * gain;
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int64_t HW, int64_t n,
                                     int src_bstride_zero) {
     // 32x32 LDS transpose per (b): tile over (c, p)
@@ -251,6 +292,27 @@ extern "C" int e4s_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int 
     const int64_t blocks = (int64_t)B * ((C + 31) / 32) * ((HW + 31) / 32);
     if (blocks <= 0) return 0;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, y, C, HW);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_mask_mul_add_f32(const float* y, const float* mask, float* out, int r, int B, int H, int W, int C,
+                                    int R, int Hm, int Wm, int channels_last, int accumulate, void* stream) {
+    const int64_t n = (int64_t)B * H * W * C;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mask_mul_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), y, mask,
+                       out, r, B, H, W, C, R, Hm, Wm, channels_last, accumulate);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_noise_bias_act_nhwc_f32(const float* x, const float* noise, const float* noise_w,
+                                           int64_t noise_bstride, const float* bias, float* y, int B, int HW, int C,
+                                           float alpha, float gain, void* stream) {
+    const int64_t n = (int64_t)B * HW * C;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(noise_bias_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, noise,
+                       noise_w, noise_bstride, bias, y, (int64_t)HW, C, n, alpha, gain);
     E4S_CHECK_LAUNCH();
     return 0;
 }

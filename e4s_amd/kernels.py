@@ -257,6 +257,30 @@ def torgb(x, ws, bias, skip, k4, labels, num_regions):
     return out
 
 
+def mask_mul_add(y, mask, r, out, channels_last):
+    """out (+)= y * nearest(mask)[:, r]  (soft-mask fallback); out=None allocates (overwrite)."""
+    if channels_last:
+        b, h, w, c = y.shape
+    else:
+        b, c, h, w = y.shape
+    acc = 1 if out is not None else 0
+    if out is None:
+        out = torch.empty_like(y)
+    mask = _f32(mask)
+    call("e4s_mask_mul_add_f32", fptr(y), fptr(mask), fptr(out), r, b, h, w, c, mask.shape[1], mask.shape[2],
+         mask.shape[3], 1 if channels_last else 0, acc, stream())
+    return out
+
+
+def noise_bias_act_nhwc(x, noise, noise_w, bias, alpha, gain):
+    b, h, w, c = x.shape
+    y = torch.empty_like(x)
+    nb = 0 if noise is None or noise.shape[0] == 1 else h * w
+    call("e4s_noise_bias_act_nhwc_f32", fptr(x), fptr(noise), fptr(noise_w) if noise is not None else None, nb,
+         fptr(bias), fptr(y), b, h * w, c, float(alpha), float(gain), stream())
+    return y
+
+
 # ---- encoder ---------------------------------------------------------------------------------
 def resize_bilinear_to_nhwc(x, ho, wo):
     x = _f32(x)

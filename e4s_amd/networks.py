@@ -87,7 +87,10 @@ class Net3(nn.Module):
         ([B,R,1280], zeros [B,512,16,16])."""
         self._require_no_grad(img)
         with torch.no_grad():
-            labels, _ = K.mask_labels(mask)
+            labels, flags = K.mask_labels(mask)
+            if self.G.strict_mask and not torch.cuda.is_current_stream_capturing() and bool(flags.item()):
+                raise NotImplementedError("get_style_vectors needs a one-hot parsing mask (labelMap2OneHot); the "
+                                          "regional pooling of soft masks is not implemented")
             x256 = K.resize_bilinear_to_nhwc(img, 256, 256)                  # F.interpolate(...,'bilinear') :131
             codes, last = self.encoder.encode_nhwc(x256, labels, mask.shape[1])
             b, h, w, c = last.shape

@@ -284,6 +284,28 @@ class StyledConv(nn.Module):
                            noise_w=self.noise.weight, noise_per_channel=per_ch, bias=self.activate.bias, act=1,
                            alpha=self.activate.negative_slope, gain=self.activate.scale)
 
+    def run_nhwc_soft(self, x, s, noise, mask):
+        """Soft (non one-hot) masks: the reference's own formulation, sum_r conv(x, style_r) * nearest(mask)_r
+        (model.py:386-400), as R natural-order launches + a masked accumulate.  s: [B*R, Cin]."""
+        conv = self.conv
+        pk = conv.packed()
+        b, h, w, _ = x.shape
+        r = mask.shape[1]
+        ho, wo = (2 * h, 2 * w) if conv.upsample else (h, w)
+        d = K.demod_coefs(s, pk["wsq"], conv.scale)
+        s3, d3 = s.view(b, r, -1), d.view(b, r, -1)
+        acc = None
+        for i in range(r):
+            y = K.conv_mfma(x, pk["w"], conv.out_channel, ncls=4 if conv.upsample else 1,
+                            ostride=2 if conv.upsample else 1, in_scale=s3[:, i].contiguous(),
+                            out_scale=d3[:, i].contiguous())
+            acc = K.mask_mul_add(y, mask, i, acc, True)
+        nz, per_ch = _prep_noise(noise, b, ho, wo, x.device)
+        if per_ch:
+            raise NotImplementedError("per-channel noise with soft masks")
+        return K.noise_bias_act_nhwc(acc, nz, self.noise.weight, self.activate.bias, self.activate.negative_slope,
+                                     self.activate.scale)
+
     def forward(self, input, style, mask, noise=None, use_plan=False):
         """Drop-in NCHW forward.  style [B,R,512] + one-hot mask when mask_op else [B,512].
         use_plan=True selects the region-gathered row plan instead of in-GEMM region-select."""
@@ -318,6 +340,22 @@ class ToRGB(nn.Module):
             rec.update(ws=ws)
         k4 = self.upsample.kernel if skip is not None else None
         return K.torgb(x, ws, self.bias, skip, k4, labels, num_regions)
+
+    def run_nhwc_soft(self, x, s, mask, skip):
+        """Soft masks: sum_r torgb(x, style_r) * nearest(mask)_r + bias + upsample(skip) (model.py:426-448)."""
+        pk = self.conv.packed()
+        b = x.shape[0]
+        r = mask.shape[1]
+        ws = K.rgb_weights(pk["w"].view(3, -1), s, self.conv.scale).view(b, r, 3, -1)
+        zero3 = torch.zeros(3, device=x.device)
+        acc = None
+        for i in range(r):
+            y = K.torgb(x, ws[:, i].contiguous(), zero3, None, None, None, 1)
+            acc = K.mask_mul_add(y, mask, i, acc, False)
+        zw = torch.zeros(b, 3, x.shape[3], device=x.device)
+        k4 = self.upsample.kernel if skip is not None else None
+        tail = K.torgb(x, zw, self.bias, skip, k4, None, 1)          # bias + FIR-upsampled skip
+        return acc + tail
 
     def forward(self, input, style, mask, skip=None):
         x = K.nchw_to_nhwc(input)
@@ -375,6 +413,9 @@ class Generator(nn.Module):
             self.to_rgbs.append(ToRGB(out_channel, style_dim, mask_op=rgb_masked))
             in_channel = out_channel
         self.n_latent = self.log_size * 2 - 2
+        # one-hot masks (labelMap2OneHot) take the region-select fast path; with strict_mask the mask is verified on
+        # every eager call (one host sync) and soft masks fall back to the reference's R-pass formulation.
+        self.strict_mask = True
 
     def make_noise(self):
         device = self.input.input.device
@@ -437,11 +478,18 @@ class Generator(nn.Module):
         """`tape` (a list) records per layer what the backward needs (e4s_amd/autograd.py)."""
         lat = latent.detach().to(torch.float32).contiguous()
         b, r = lat.shape[:2]
-        labels, _flags = K.mask_labels(mask)
+        labels, flags = K.mask_labels(mask)
+        soft = False
+        if self.strict_mask and not torch.cuda.is_current_stream_capturing():
+            soft = bool(flags.item())          # one host sync; skipped while a HIP graph is being captured
+        if soft and tape is not None:
+            raise NotImplementedError("backward with soft (non one-hot) masks")
 
         def styled(layer, x, idx, nz):
             mod = layer.conv.modulation
             s = K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
+            if soft and layer.mask_op:
+                return layer.run_nhwc_soft(x, s, nz, mask)
             rec = {} if tape is not None else None
             y = layer.run_nhwc(x, s, nz, labels if layer.mask_op else None, r, rec=rec)
             if tape is not None:
@@ -453,6 +501,8 @@ class Generator(nn.Module):
         def rgb(layer, x, idx, skip):
             mod = layer.conv.modulation
             s = K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
+            if soft and layer.mask_op:
+                return layer.run_nhwc_soft(x, s, mask, skip)
             rec = {} if tape is not None else None
             out = layer.run_nhwc(x, s, labels if layer.mask_op else None, r, skip, rec=rec)
             if tape is not None:

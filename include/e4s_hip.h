@@ -172,6 +172,17 @@ int e4s_torgb_f32(const float* x, const float* ws, const float* bias, const floa
                   const uint8_t* labels, int Hm, int Wm, int R, float* out,
                   int B, int H, int W, int Cin, void* stream);
 
+/* Soft-mask fallback (reference formulation, model.py:391-398): out (+)= y * nearest(mask)[:, r]; mask [B,R,Hm,Wm];
+ * y/out NHWC [B,H,W,C] (channels_last = 1) or NCHW [B,C,H,W] (0). */
+int e4s_mask_mul_add_f32(const float* y, const float* mask, float* out, int r, int B, int H, int W, int C,
+                         int R, int Hm, int Wm, int channels_last, int accumulate, void* stream);
+
+/* y = lrelu(x + noise_w*noise[b,p] + bias[c]) * gain on NHWC x [B,HW,C] (NoiseInjection + FusedLeakyReLU as a
+ * separate pass; only the soft-mask fallback needs it, the fused path does it in the conv epilogue). */
+int e4s_noise_bias_act_nhwc_f32(const float* x, const float* noise, const float* noise_w, int64_t noise_bstride,
+                                const float* bias, float* y, int B, int HW, int C, float alpha, float gain,
+                                void* stream);
+
 /* ---- layout helpers ------------------------------------------------------------------------ */
 int e4s_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int H, int W, void* stream);
 int e4s_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, void* stream);

@@ -533,3 +533,34 @@ def test_torgb_backward_vs_oracle_f64(cin, res, masked, with_skip):
         dsk = K.upfirdn2d_raw(wgt.to(DEV).reshape(n * c, h, w, 1), torch.flip(m.upsample.kernel, [0, 1]), 1, 1, 2, 2,
                               1, 1, 1, 1).view(n, c, h // 2, w // 2)
         assert maxabs(dsk, kr.grad) < 1e-4 * float(kr.grad.abs().max())
+
+
+@torch.no_grad()
+def test_soft_mask_fallback_and_net3_forward():
+    """(1) a soft (non one-hot) mask takes the reference's R-pass formulation and still matches the oracle;
+    (2) Net3.forward == get_style_vectors -> cal_style_codes -> gen_img (networks.py:85-119)."""
+    from e4s_amd.stylegan2 import Generator
+    size, K_ = 32, 13
+    sd = _gen_sd(size)
+    gen = Generator(size, 512, 8, split_layer_idx=5, remaining_layer_idx=K_)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    g = torch.Generator().manual_seed(60)
+    lat = torch.randn(2, 12, gen.n_latent, 512, generator=g) * 0.5
+    soft = torch.softmax(torch.randn(2, 12, 64, 64, generator=g) * 3, dim=1)
+    noise = synth.synth_noise(size, seed=3, batch=2)
+    img, _, feats = gen([lat.to(DEV)], None, soft.to(DEV), input_is_latent=True, noise=[n.to(DEV) for n in noise])
+    img_r, feats_r = orc.generator_forward({"G." + k: v for k, v in sd.items()}, lat, soft, noise, size, K_)
+    assert maxabs(img, img_r) < 1e-4 and maxabs(feats, feats_r) < 1e-4
+
+    net = _net(256)
+    x = synth.synth_image(1, 1024, tag="fwd").to(DEV)
+    mask = synth.onehot(synth.synth_labels_face(1, 512, seed=7)).to(DEV)
+    imgs, feats16, latent = net(x, mask, randomize_noise=False, return_latents=True)
+    sv, _ = net.get_style_vectors(x, mask)
+    codes = net.cal_style_codes(sv)
+    stored = [getattr(net.G.noises, f"noise_{i}") for i in range(net.G.num_layers)]
+    img2, _, feats2 = net.gen_img(None, codes, mask, noise=stored)
+    assert torch.equal(imgs, img2) and torch.equal(latent, codes) and torch.equal(feats16, feats2)
+    with pytest.raises(NotImplementedError):
+        net.get_style_vectors(x, torch.softmax(torch.randn(1, 12, 512, 512, device=DEV), 1))
