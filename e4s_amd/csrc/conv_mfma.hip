@@ -41,17 +41,13 @@ struct SmemLayout {
     static constexpr int BYTES = (META_WORDS + A_WORDS + B_WORDS + S_WORDS) * 4;
 };
 
-// KS = 2: "in-block split-K" for launches that cannot fill the chip (batch 1, low resolutions): the block has 8
-// waves, waves 4-7 take the second half of every K step and the two partial accumulators are added through LDS
-// before the epilogue -- two waves per SIMD hide each other's barrier / load latency where a second block cannot.
-template <int BM, int BN, int WM, int WN, bool SPATIAL, int KS>
-__global__ __launch_bounds__(NTHR * KS, 2) void conv_mfma_kernel(const e4s_conv_params p, const int ntn,
-                                                                 const int tiles_per_cls) {
+template <int BM, int BN, int WM, int WN, bool SPATIAL>
+__global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_params p, const int ntn,
+                                                            const int tiles_per_cls) {
     using L = SmemLayout<BM, BN, SPATIAL>;
-    constexpr int NT = NTHR * KS, RS = 32 * KS;          // threads per block; staging row stride
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int TH = L::TH, TW = L::TW, HALO_W = L::HALO_W, HALO = L::HALO;
-    constexpr int AR = BM / RS, BR = (BN + RS - 1) / RS, HR = (HALO + RS - 1) / RS;
+    constexpr int AR = BM / 32, BR = BN / 32, HR = (HALO + 31) / 32;
     constexpr int PA = SPATIAL ? HR : AR;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -67,8 +63,7 @@ __global__ __launch_bounds__(NTHR * KS, 2) void conv_mfma_kernel(const e4s_conv_
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
-    const int khalf = wave >> 2, wave4 = wave & 3;        // khalf != 0 only when KS == 2
-    const int wm = wave4 / WN, wn = wave4 % WN;
+    const int wm = wave / WN, wn = wave % WN;
 
     // ---- which tile ------------------------------------------------------------------
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -151,8 +146,8 @@ __global__ __launch_bounds__(NTHR * KS, 2) void conv_mfma_kernel(const e4s_conv_
     if (!SPATIAL) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
-            a_base[j] = s_base[r0 + RS * j];
-            a_yx[j] = s_yx[r0 + RS * j];
+            a_base[j] = s_base[r0 + 32 * j];
+            a_yx[j] = s_yx[r0 + 32 * j];
         }
     }
     const int R = SPATIAL ? (p.labels ? p.groups_per_batch : 1) : 1;
@@ -169,8 +164,7 @@ __global__ __launch_bounds__(NTHR * KS, 2) void conv_mfma_kernel(const e4s_conv_
     auto fetch_b = [&](int tap, int c0) {
         const float* wp = p.w + ((size_t)(cls * ntaps + tap) * p.Cout + n0) * p.Cin + c0 + c4;
 #pragma unroll
-        for (int j = 0; j < BR; ++j)
-            if (BN % RS == 0 || r0 + RS * j < BN) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(r0 + RS * j) * p.Cin);
+        for (int j = 0; j < BR; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(r0 + 32 * j) * p.Cin);
         if (sscale) {
             const f32x4 sv = *reinterpret_cast<const f32x4*>(sscale + c0 + c4);
 #pragma unroll
@@ -192,7 +186,7 @@ __global__ __launch_bounds__(NTHR * KS, 2) void conv_mfma_kernel(const e4s_conv_
     auto fetch_a_halo = [&](int c0) {
 #pragma unroll
         for (int j = 0; j < HR; ++j) {
-            const int h = r0 + RS * j;
+            const int h = r0 + 32 * j;
             const int hy = h / HALO_W, hx = h - hy * HALO_W;
             const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -210,20 +204,19 @@ __global__ __launch_bounds__(NTHR * KS, 2) void conv_mfma_kernel(const e4s_conv_
     auto store_b = [&](int buf) {
         float* d = sB + buf * (BN * LDA) + r0 * LDA + c4;
 #pragma unroll
-        for (int j = 0; j < BR; ++j)
-            if (BN % RS == 0 || r0 + RS * j < BN) *reinterpret_cast<f32x4*>(d + RS * j * LDA) = pb[j];
+        for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(d + 32 * j * LDA) = pb[j];
     };
     auto store_a = [&](int buf) {
         if (SPATIAL) {
 #pragma unroll
             for (int j = 0; j < HR; ++j) {
-                const int h = r0 + RS * j;
+                const int h = r0 + 32 * j;
                 if (h < HALO) *reinterpret_cast<f32x4*>(sA + h * LDA + c4) = pa[j];
             }
         } else {
             float* d = sA + buf * (BM * LDA) + r0 * LDA + c4;
 #pragma unroll
-            for (int j = 0; j < AR; ++j) *reinterpret_cast<f32x4*>(d + RS * j * LDA) = pa[j];
+            for (int j = 0; j < AR; ++j) *reinterpret_cast<f32x4*>(d + 32 * j * LDA) = pa[j];
         }
     };
 
@@ -270,8 +263,7 @@ __global__ __launch_bounds__(NTHR * KS, 2) void conv_mfma_kernel(const e4s_conv_
             const float* Ab = SPATIAL ? sA + ((tap / 3) * HALO_W + (tap % 3)) * LDA : sA + buf * (BM * LDA);
             const float* Bb = sB + buf * (BN * LDA);
 #pragma unroll
-            for (int kq = 0; kq < KC / 8 / KS; ++kq) {
-                const int kk = khalf * (KC / 8 / KS) + kq;
+            for (int kk = 0; kk < KC / 8; ++kk) {
                 f32x4 a[TM], b[TN];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(Ab + arow[tm] + kk * 8 + kh * 4);
@@ -306,34 +298,10 @@ __global__ __launch_bounds__(NTHR * KS, 2) void conv_mfma_kernel(const e4s_conv_
     // (the A region is free: the loop's last barrier has passed)
     float* sD = sA;
     if (SPATIAL && p.out_scale) {
-        for (int t = tid; t < R * BN; t += NT) {
+        for (int t = tid; t < R * BN; t += NTHR) {
             const int r = t / BN, n = t - r * BN;
             sD[t] = p.out_scale[((size_t)tb * R + r) * p.Cout + n0 + n];
         }
-    }
-    if (KS == 2) {
-        // add the second K half (waves 4-7) into the first through LDS (A/B buffers are free now; sD sits in the
-        // first MAXR*BN words): red[wave4][block][reg][lane]
-        float* red = sA + L::MAXR * BN;
-        if (khalf == 1) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        red[((wave4 * TM * TN + tm * TN + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
-        }
-        __syncthreads();
-        if (khalf == 1) return;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[tm][tn][r] += red[((wave4 * TM * TN + tm * TN + tn) * 16 + r) * 64 + lane];
-    } else if (SPATIAL && p.out_scale) {
         __syncthreads();
     }
     float osc[TN], bsv[TN], slp[TN];
@@ -371,12 +339,10 @@ __global__ __launch_bounds__(NTHR * KS, 2) void conv_mfma_kernel(const e4s_conv_
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool SPATIAL, int KS = 1>
+template <int BM, int BN, int WM, int WN, bool SPATIAL>
 int launch(const e4s_conv_params& p, hipStream_t st) {
     using L = SmemLayout<BM, BN, SPATIAL>;
-    static_assert(KS == 1 || L::MAXR * BN + 4 * (BM / (WM * 32)) * (BN / (WN * 32)) * 16 * 64 <= L::A_WORDS + L::B_WORDS,
-                  "split-K reduction buffer must fit in the A/B staging area");
-    auto kern = conv_mfma_kernel<BM, BN, WM, WN, SPATIAL, KS>;
+    auto kern = conv_mfma_kernel<BM, BN, WM, WN, SPATIAL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -397,7 +363,7 @@ int launch(const e4s_conv_params& p, hipStream_t st) {
         mtiles = tiles_per_cls * p.ncls;
     }
     if (mtiles <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(mtiles * ntn), dim3(NTHR * KS), L::BYTES, st, p, ntn, tiles_per_cls);
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntn), dim3(NTHR), L::BYTES, st, p, ntn, tiles_per_cls);
     E4S_CHECK_LAUNCH();
     return 0;
 }
@@ -427,16 +393,14 @@ extern "C" int e4s_conv_mfma_f32(const e4s_conv_params* pp, int spatial, void* s
         if (p.labels && (p.groups_per_batch < 1 || p.groups_per_batch > 16)) return (int)hipErrorInvalidValue;
         const int64_t mt = (int64_t)p.B * ((p.Ha + 7) / 8) * ((p.Wa + 15) / 16) * p.ncls;
         const int bn = pick_bn(p, mt);
-        const bool starved = mt * (p.Cout / bn) < 512;          // < 2 blocks per CU: use 8-wave split-K blocks
         if (bn == 128) return launch<128, 128, 2, 2, true>(p, st);
-        if (bn == 64) return starved ? launch<128, 64, 2, 2, true, 2>(p, st) : launch<128, 64, 2, 2, true>(p, st);
-        return starved ? launch<128, 32, 4, 1, true, 2>(p, st) : launch<128, 32, 4, 1, true>(p, st);
+        if (bn == 64) return launch<128, 64, 2, 2, true>(p, st);
+        return launch<128, 32, 4, 1, true>(p, st);
     }
     if (p.labels) return (int)hipErrorInvalidValue;     // per-row regions exist only in spatial mode
     const int64_t mt = p.tiles ? p.tiles_cap : (int64_t)p.B * p.Ha * p.Wa / 128 * p.ncls;
     const int bn = pick_bn(p, mt);
-    const bool starved = mt * (p.Cout / bn) < 512;
     if (bn == 128) return launch<128, 128, 2, 2, false>(p, st);
-    if (bn == 64) return starved ? launch<128, 64, 2, 2, false, 2>(p, st) : launch<128, 64, 2, 2, false>(p, st);
-    return starved ? launch<128, 32, 4, 1, false, 2>(p, st) : launch<128, 32, 4, 1, false>(p, st);
+    if (bn == 64) return launch<128, 64, 2, 2, false>(p, st);
+    return launch<128, 32, 4, 1, false>(p, st);
 }
