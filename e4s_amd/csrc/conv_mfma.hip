@@ -41,7 +41,7 @@ struct SmemLayout {
     static constexpr int BYTES = (META_WORDS + A_WORDS + B_WORDS + S_WORDS) * 4;
 };
 
-template <int BM, int BN, int WM, int WN, bool SPATIAL>
+template <int BM, int BN, int WM, int WN, bool SPATIAL, int PF>
 __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_params p, const int ntn,
                                                             const int tiles_per_cls) {
     using L = SmemLayout<BM, BN, SPATIAL>;
@@ -156,67 +156,70 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     // spatial: per-row region, style applied to the A fragment; the K-step slice of the table lives in LDS.
     const float* sscale = (!SPATIAL && scaled) ? p.in_scale + (size_t)g * p.Cin : nullptr;
     const float* stable = (SPATIAL && scaled) ? p.in_scale + (size_t)tb * R * p.Cin : nullptr;
-    f32x4 ps = {1.f, 1.f, 1.f, 1.f};
-
-    f32x4 pa[PA], pb[BR];
+    // prefetch registers of one pipeline stage (global -> VGPR, later VGPR -> LDS)
+    struct Pref {
+        f32x4 a[PA];
+        f32x4 b[BR];
+        f32x4 s;
+    };
     const int ntaps = p.ntaps, nchunk = p.Cin / KC, nstage = nchunk * ntaps;
 
-    auto fetch_b = [&](int tap, int c0) {
+    auto fetch = [&](Pref& P, int tap, int c0) {
+        const bool new_chunk = (tap == 0);
         const float* wp = p.w + ((size_t)(cls * ntaps + tap) * p.Cout + n0) * p.Cin + c0 + c4;
 #pragma unroll
-        for (int j = 0; j < BR; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(r0 + 32 * j) * p.Cin);
+        for (int j = 0; j < BR; ++j) P.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(r0 + 32 * j) * p.Cin);
         if (sscale) {
             const f32x4 sv = *reinterpret_cast<const f32x4*>(sscale + c0 + c4);
 #pragma unroll
-            for (int j = 0; j < BR; ++j) pb[j] *= sv;
+            for (int j = 0; j < BR; ++j) P.b[j] *= sv;
         }
-    };
-    auto fetch_a_gather = [&](int tap, int c0) {
-        const int oy = (ntaps == 9) ? tap / 3 - 1 : 0, ox = (ntaps == 9) ? tap % 3 - 1 : 0;
-        const int doff = oy * p.Wi + ox;
-#pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            const int iy = (a_yx[j] >> 16) + oy, ix = (a_yx[j] & 0xffff) + ox;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-                v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_base[j] + doff) * p.Cin + c0 + c4);
-            pa[j] = v;
-        }
-    };
-    auto fetch_a_halo = [&](int c0) {
-#pragma unroll
-        for (int j = 0; j < HR; ++j) {
-            const int h = r0 + 32 * j;
-            const int hy = h / HALO_W, hx = h - hy * HALO_W;
-            const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (h < HALO && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-                v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(tb * p.Hi + iy) * p.Wi + ix) * p.Cin + c0 + c4);
-            pa[j] = v;
-        }
-    };
-    auto fetch_s = [&](int c0) {
-        if (stable && tid < R * 8) ps = *reinterpret_cast<const f32x4*>(stable + (size_t)(tid >> 3) * p.Cin + c0 + c4);
-    };
-    auto store_s = [&]() {
-        if (stable && tid < R * 8) *reinterpret_cast<f32x4*>(sS + (tid >> 3) * LDA + c4) = ps;
-    };
-    auto store_b = [&](int buf) {
-        float* d = sB + buf * (BN * LDA) + r0 * LDA + c4;
-#pragma unroll
-        for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(d + 32 * j * LDA) = pb[j];
-    };
-    auto store_a = [&](int buf) {
         if (SPATIAL) {
+            if (new_chunk) {
 #pragma unroll
-            for (int j = 0; j < HR; ++j) {
-                const int h = r0 + 32 * j;
-                if (h < HALO) *reinterpret_cast<f32x4*>(sA + h * LDA + c4) = pa[j];
+                for (int j = 0; j < HR; ++j) {
+                    const int h = r0 + 32 * j;
+                    const int hy = h / HALO_W, hx = h - hy * HALO_W;
+                    const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (h < HALO && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                        v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(tb * p.Hi + iy) * p.Wi + ix) * p.Cin + c0 + c4);
+                    P.a[j] = v;
+                }
+                if (stable && tid < R * 8)
+                    P.s = *reinterpret_cast<const f32x4*>(stable + (size_t)(tid >> 3) * p.Cin + c0 + c4);
             }
         } else {
-            float* d = sA + buf * (BM * LDA) + r0 * LDA + c4;
+            const int oy = (ntaps == 9) ? tap / 3 - 1 : 0, ox = (ntaps == 9) ? tap % 3 - 1 : 0;
+            const int doff = oy * p.Wi + ox;
 #pragma unroll
-            for (int j = 0; j < AR; ++j) *reinterpret_cast<f32x4*>(d + 32 * j * LDA) = pa[j];
+            for (int j = 0; j < AR; ++j) {
+                const int iy = (a_yx[j] >> 16) + oy, ix = (a_yx[j] & 0xffff) + ox;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                    v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_base[j] + doff) * p.Cin + c0 + c4);
+                P.a[j] = v;
+            }
+        }
+    };
+    // VGPR -> LDS for the stage whose first tap flag is `new_chunk`; B (and gather A) go to buffer `buf`
+    auto store = [&](const Pref& P, int buf, bool new_chunk) {
+        float* d = sB + buf * (BN * LDA) + r0 * LDA + c4;
+#pragma unroll
+        for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(d + 32 * j * LDA) = P.b[j];
+        if (SPATIAL) {
+            if (new_chunk) {
+#pragma unroll
+                for (int j = 0; j < HR; ++j) {
+                    const int h = r0 + 32 * j;
+                    if (h < HALO) *reinterpret_cast<f32x4*>(sA + h * LDA + c4) = P.a[j];
+                }
+                if (stable && tid < R * 8) *reinterpret_cast<f32x4*>(sS + (tid >> 3) * LDA + c4) = P.s;
+            }
+        } else {
+            float* da = sA + buf * (BM * LDA) + r0 * LDA + c4;
+#pragma unroll
+            for (int j = 0; j < AR; ++j) *reinterpret_cast<f32x4*>(da + 32 * j * LDA) = P.a[j];
         }
     };
 
@@ -239,59 +242,81 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    // ---- prologue: stage 0 -----------------------------------------------------------
-    fetch_b(0, 0);
-    if (SPATIAL) { fetch_a_halo(0); fetch_s(0); } else fetch_a_gather(0, 0);
-    store_b(0);
-    store_a(0);
-    if (SPATIAL) store_s();
+    auto compute = [&](int s, int tap) {
+        const int buf = s & 1;
+        const float* Ab = SPATIAL ? sA + ((tap / 3) * HALO_W + (tap % 3)) * LDA : sA + buf * (BM * LDA);
+        const float* Bb = sB + buf * (BN * LDA);
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(Ab + arow[tm] + kk * 8 + kh * 4);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(Bb + brow[tn] + kk * 8 + kh * 4);
+            if (SPATIAL && scaled) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) a[tm] *= *reinterpret_cast<const f32x4*>(sS + srow[tm] + kk * 8 + kh * 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+        }
+    };
+    auto advance = [&](int& tap, int& c0) {
+        if (++tap == ntaps) { tap = 0; c0 += KC; }
+    };
+
+    // ---- software pipeline: LDS holds stage s, registers hold stage s+1 (PF == 1) or s+1 and s+2 (PF == 2:
+    // the small column tiles have only ~1000 MFMA cycles per stage, not enough to cover an L2 round trip) ----
+    Pref P0, P1;
+    P0.s = P1.s = f32x4{1.f, 1.f, 1.f, 1.f};
+    int tap = 0, c0 = 0, t1 = 0, c1 = 0;
+    advance(t1, c1);
+    fetch(P0, 0, 0);
+    store(P0, 0, true);
+    if (PF == 2 && nstage > 1) fetch(P1, t1, c1);
     __syncthreads();
 
-    int tap = 0, c0 = 0;
-    for (int s = 0; s < nstage; ++s) {
-        int ntap = tap + 1, nc0 = c0;
-        if (ntap == ntaps) { ntap = 0; nc0 += KC; }
-        const bool more = (s + 1 < nstage);
-        const bool new_chunk = (ntap == 0);
-        if (more) {
-            fetch_b(ntap, nc0);
-            if (SPATIAL) { if (new_chunk) { fetch_a_halo(nc0); fetch_s(nc0); } } else fetch_a_gather(ntap, nc0);
-        }
-        // ---- MFMAs on stage s ----
-        {
-            const int buf = s & 1;
-            const float* Ab = SPATIAL ? sA + ((tap / 3) * HALO_W + (tap % 3)) * LDA : sA + buf * (BM * LDA);
-            const float* Bb = sB + buf * (BN * LDA);
-#pragma unroll
-            for (int kk = 0; kk < KC / 8; ++kk) {
-                f32x4 a[TM], b[TN];
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(Ab + arow[tm] + kk * 8 + kh * 4);
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(Bb + brow[tn] + kk * 8 + kh * 4);
-                if (SPATIAL && scaled) {
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) a[tm] *= *reinterpret_cast<const f32x4*>(sS + srow[tm] + kk * 8 + kh * 4);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < TN; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+    if (PF == 1) {
+        for (int s = 0; s < nstage; ++s) {
+            const bool more = (s + 1 < nstage);
+            const bool new_chunk = (t1 == 0);
+            if (more) fetch(P0, t1, c1);
+            compute(s, tap);
+            if (more) {
+                if (SPATIAL && new_chunk) __syncthreads();   // single A halo buffer: everyone done reading it
+                store(P0, (s + 1) & 1, new_chunk);
             }
+            __syncthreads();
+            tap = t1; c0 = c1;
+            advance(t1, c1);
         }
-        if (more) {
-            if (SPATIAL && new_chunk) __syncthreads();   // single A halo buffer: everyone done reading it
-            store_b((s + 1) & 1);
-            if (!SPATIAL || new_chunk) store_a((s + 1) & 1);
-            if (SPATIAL && new_chunk) store_s();
+    } else {
+        int t2 = t1, c2 = c1;
+        advance(t2, c2);
+        auto step = [&](Pref& Pf, const Pref& Ps, int s) {
+            if (s + 2 < nstage) fetch(Pf, t2, c2);
+            compute(s, tap);
+            if (s + 1 < nstage) {
+                const bool new_chunk = (t1 == 0);
+                if (SPATIAL && new_chunk) __syncthreads();
+                store(Ps, (s + 1) & 1, new_chunk);
+            }
+            __syncthreads();
+            tap = t1; c0 = c1;
+            t1 = t2; c1 = c2;
+            advance(t2, c2);
+        };
+        for (int s = 0; s < nstage; s += 2) {
+            step(P0, P1, s);
+            if (s + 1 < nstage) step(P1, P0, s + 1);
         }
-        __syncthreads();
-        tap = ntap;
-        c0 = nc0;
     }
+    (void)c0;
 
     // ---- epilogue: demod * acc + noise + bias, activation, scatter to NHWC ------------
     // spatial mode: the demodulation coefficient depends on the row's region -> table d[r][n] in LDS
@@ -339,10 +364,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool SPATIAL>
+template <int BM, int BN, int WM, int WN, bool SPATIAL, int PF = 1>
 int launch(const e4s_conv_params& p, hipStream_t st) {
     using L = SmemLayout<BM, BN, SPATIAL>;
-    auto kern = conv_mfma_kernel<BM, BN, WM, WN, SPATIAL>;
+    auto kern = conv_mfma_kernel<BM, BN, WM, WN, SPATIAL, PF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -394,13 +419,13 @@ extern "C" int e4s_conv_mfma_f32(const e4s_conv_params* pp, int spatial, void* s
         const int64_t mt = (int64_t)p.B * ((p.Ha + 7) / 8) * ((p.Wa + 15) / 16) * p.ncls;
         const int bn = pick_bn(p, mt);
         if (bn == 128) return launch<128, 128, 2, 2, true>(p, st);
-        if (bn == 64) return launch<128, 64, 2, 2, true>(p, st);
-        return launch<128, 32, 4, 1, true>(p, st);
+        if (bn == 64) return launch<128, 64, 2, 2, true, 2>(p, st);
+        return launch<128, 32, 4, 1, true, 2>(p, st);
     }
     if (p.labels) return (int)hipErrorInvalidValue;     // per-row regions exist only in spatial mode
     const int64_t mt = p.tiles ? p.tiles_cap : (int64_t)p.B * p.Ha * p.Wa / 128 * p.ncls;
     const int bn = pick_bn(p, mt);
     if (bn == 128) return launch<128, 128, 2, 2, false>(p, st);
-    if (bn == 64) return launch<128, 64, 2, 2, false>(p, st);
-    return launch<128, 32, 4, 1, false>(p, st);
+    if (bn == 64) return launch<128, 64, 2, 2, false, 2>(p, st);
+    return launch<128, 32, 4, 1, false, 2>(p, st);
 }
