@@ -161,6 +161,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
         f32x4 a[PA];
         f32x4 b[BR];
         f32x4 s;
+        unsigned ok;      // bit j: a[j] is a real (in-image) sample; applied when the registers are written to LDS, so
+                          // that nothing consumes a load result before the stage that needs it
     };
     const int ntaps = p.ntaps, nchunk = p.Cin / KC, nstage = nchunk * ntaps;
 
@@ -176,30 +178,38 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
         }
         if (SPATIAL) {
             if (new_chunk) {
+                unsigned okm = 0;
 #pragma unroll
                 for (int j = 0; j < HR; ++j) {
                     const int h = r0 + 32 * j;
                     const int hy = h / HALO_W, hx = h - hy * HALO_W;
                     const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (h < HALO && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-                        v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(tb * p.Hi + iy) * p.Wi + ix) * p.Cin + c0 + c4);
-                    P.a[j] = v;
+                    // branch-free: out-of-image halo pixels load a valid dummy address and are zeroed by a select, so
+                    // the loads stay in one basic block and the compiler can use counted s_waitcnt vmcnt(N)
+                    const bool ok = h < HALO && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                    const size_t off = ok ? ((size_t)(tb * p.Hi + iy) * p.Wi + ix) * p.Cin : 0;
+                    P.a[j] = *reinterpret_cast<const f32x4*>(p.x + off + c0 + c4);
+                    okm |= (ok ? 1u : 0u) << j;
                 }
-                if (stable && tid < R * 8)
-                    P.s = *reinterpret_cast<const f32x4*>(stable + (size_t)(tid >> 3) * p.Cin + c0 + c4);
+                P.ok = okm;
+                if (stable) {
+                    const int sr = min(tid >> 3, R - 1);
+                    P.s = *reinterpret_cast<const f32x4*>(stable + (size_t)sr * p.Cin + c0 + c4);
+                }
             }
         } else {
             const int oy = (ntaps == 9) ? tap / 3 - 1 : 0, ox = (ntaps == 9) ? tap % 3 - 1 : 0;
             const int doff = oy * p.Wi + ox;
+            unsigned okm = 0;
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
                 const int iy = (a_yx[j] >> 16) + oy, ix = (a_yx[j] & 0xffff) + ox;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-                    v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_base[j] + doff) * p.Cin + c0 + c4);
-                P.a[j] = v;
+                const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                const size_t off = ok ? (size_t)(a_base[j] + doff) * p.Cin : 0;
+                P.a[j] = *reinterpret_cast<const f32x4*>(p.x + off + c0 + c4);
+                okm |= (ok ? 1u : 0u) << j;
             }
+            P.ok = okm;
         }
     };
     // VGPR -> LDS for the stage whose first tap flag is `new_chunk`; B (and gather A) go to buffer `buf`
@@ -212,14 +222,16 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
 #pragma unroll
                 for (int j = 0; j < HR; ++j) {
                     const int h = r0 + 32 * j;
-                    if (h < HALO) *reinterpret_cast<f32x4*>(sA + h * LDA + c4) = P.a[j];
+                    if (h < HALO)
+                        *reinterpret_cast<f32x4*>(sA + h * LDA + c4) = ((P.ok >> j) & 1u) ? P.a[j] : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 if (stable && tid < R * 8) *reinterpret_cast<f32x4*>(sS + (tid >> 3) * LDA + c4) = P.s;
             }
         } else {
             float* da = sA + buf * (BM * LDA) + r0 * LDA + c4;
 #pragma unroll
-            for (int j = 0; j < AR; ++j) *reinterpret_cast<f32x4*>(da + 32 * j * LDA) = P.a[j];
+            for (int j = 0; j < AR; ++j)
+                *reinterpret_cast<f32x4*>(da + 32 * j * LDA) = ((P.ok >> j) & 1u) ? P.a[j] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -274,6 +286,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     // the small column tiles have only ~1000 MFMA cycles per stage, not enough to cover an L2 round trip) ----
     Pref P0, P1;
     P0.s = P1.s = f32x4{1.f, 1.f, 1.f, 1.f};
+    P0.ok = P1.ok = 0u;
     int tap = 0, c0 = 0, t1 = 0, c1 = 0;
     advance(t1, c1);
     fetch(P0, 0, 0);
@@ -298,10 +311,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     } else {
         int t2 = t1, c2 = c1;
         advance(t2, c2);
-        auto step = [&](Pref& Pf, const Pref& Ps, int s) {
-            if (s + 2 < nstage) fetch(Pf, t2, c2);
+        // steady state: the prefetch is unconditional (a conditional load would force s_waitcnt vmcnt(0) on the
+        // older register set); the last stages run the guarded form
+        auto step = [&](Pref& Pf, const Pref& Ps, int s, bool guarded) {
+            if (!guarded || s + 2 < nstage) fetch(Pf, t2, c2);
             compute(s, tap);
-            if (s + 1 < nstage) {
+            if (!guarded || s + 1 < nstage) {
                 const bool new_chunk = (t1 == 0);
                 if (SPATIAL && new_chunk) __syncthreads();
                 store(Ps, (s + 1) & 1, new_chunk);
@@ -311,9 +326,14 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
             t1 = t2; c1 = c2;
             advance(t2, c2);
         };
-        for (int s = 0; s < nstage; s += 2) {
-            step(P0, P1, s);
-            if (s + 1 < nstage) step(P1, P0, s + 1);
+        int s = 0;
+        for (; s + 3 < nstage; s += 2) {
+            step(P0, P1, s, false);
+            step(P1, P0, s + 1, false);
+        }
+        for (; s < nstage; s += 2) {
+            step(P0, P1, s, true);
+            if (s + 1 < nstage) step(P1, P0, s + 1, true);
         }
     }
     (void)c0;
