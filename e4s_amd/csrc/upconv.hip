@@ -1,0 +1,224 @@
+// Exact up-sampling StyledConv: conv_transpose2d(stride 2, 3x3) followed by the 4x4 FIR blur
+// (src/models/stylegan2/model.py:287-300, 206-213), tile-fused so that the (2H+1)^2 intermediate lives only in LDS.
+//
+// The polyphase form used by e4s_conv_mfma_f32 (ncls = 4) spends 36*Cin*Cout MACs per input pixel; the transposed
+// conv itself needs 9.  This kernel does the minimal products on the matrix cores and the blur on the VALU:
+//   P_k[u, co] = sum_ci x[u, ci] * s[ci] * W[co, ci, k]                 9 taps k, fp32 MFMA, rows u = halo pixels
+//   I[q]       = sum_{2u + k = q} P_k[u]                               scatter-add into an LDS tile
+//   out[p]     = act( d[co] * sum_j kflip[j] * I[p + j - 1] + noise + bias )
+// Block = 6 x 14 input pixels (+1 halo on each side = 8 x 16 = 128 GEMM rows, one 32-row MFMA block per wave) x 32
+// output channels -> a 12 x 28 output tile; 3.4*Cin MACs per output element instead of 9*Cin.  The nine tap
+// accumulators (9 x 16 VGPRs) stay in registers across the whole K loop; the A tile (halo x 32 channels) is staged
+// once per channel chunk and reused by the 9 taps, B (32 x 32 weights of one tap) is staged per step.
+// Region-select: the style of a tile is uniform per pass; tiles whose output pixels belong to several regions run one
+// pass per region present (style folded into the B tile while staging) and each pass writes only its own pixels.
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 32, LDA = 36, NTHR = 256;
+constexpr int TAH = 6, TAW = 14;                 // input pixels (anchors) per tile
+constexpr int HW_ = TAW + 2;                     // halo width 16; halo rows = (TAH + 2) * 16 = 128
+constexpr int ROWS = (TAH + 2) * HW_;
+constexpr int BN = 32;
+constexpr int OH = 2 * TAH, OW = 2 * TAW;        // 12 x 28 outputs
+constexpr int IQH = 2 * (TAH + 2) + 1, IQW = 2 * HW_ + 1;   // 17 x 33: every position a halo pixel scatters to
+                                                            // (the 15 x 31 interior feeds the tile's outputs)
+constexpr int STAGE_WORDS = 2 * ROWS * LDA + 2 * BN * LDA;
+constexpr int ITILE_WORDS = IQH * IQW * BN;
+constexpr int UNION_WORDS = STAGE_WORDS > ITILE_WORDS ? STAGE_WORDS : ITILE_WORDS;
+
+struct UpSmem {
+    float kf[16];
+    int regmask;
+    int pad_[3];
+    unsigned char lab[OH * OW];                  // region of each output pixel of the tile (336 B)
+    float buf[UNION_WORDS];                      // K loop: A[2][128][36], B[2][32][36];  epilogue: I[15][31][32]
+};
+
+__global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p, const float* __restrict__ k4,
+                                                         const int ntn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    UpSmem& sm = *reinterpret_cast<UpSmem*>(smem_raw);
+    float* sA = sm.buf;
+    float* sB = sm.buf + 2 * ROWS * LDA;
+    float* sI = sm.buf;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = logical / ntn, nt = logical - mt * ntn;
+    const int n0 = nt * BN;
+    const int tx_n = (p.Wi + TAW - 1) / TAW, per_img = ((p.Hi + TAH - 1) / TAH) * tx_n;
+    const int tb = mt / per_img;
+    const int rem0 = mt - tb * per_img;
+    const int ay0 = (rem0 / tx_n) * TAH, ax0 = (rem0 % tx_n) * TAW;
+    const int oy0 = 2 * ay0, ox0 = 2 * ax0;
+    const int R = p.labels ? p.groups_per_batch : 1;
+
+    // ---- tile metadata: flipped blur taps, labels of the output pixels, set of regions present -----------------
+    if (tid < 16) sm.kf[tid] = k4[15 - tid];
+    if (tid == 0) sm.regmask = 0;
+    __syncthreads();
+    for (int t = tid; t < OH * OW; t += NTHR) {
+        const int oy = oy0 + t / OW, ox = ox0 + t % OW;
+        int r = 255;
+        if (oy < p.Ho && ox < p.Wo) {
+            r = 0;
+            if (p.labels) {
+                const int sy = min((int)floorf((float)oy * ((float)p.Hm / (float)p.Ho)), p.Hm - 1);
+                const int sx = min((int)floorf((float)ox * ((float)p.Wm / (float)p.Wo)), p.Wm - 1);
+                r = p.labels[((size_t)tb * p.Hm + sy) * p.Wm + sx];
+            }
+            atomicOr(&sm.regmask, 1 << r);
+        }
+        sm.lab[t] = (unsigned char)r;
+    }
+    __syncthreads();
+    const int regmask = sm.regmask;
+
+    // ---- staging roles ---------------------------------------------------------------------------------------
+    const int c4 = (tid & 7) * 4, r0 = tid >> 3;              // A: rows r0 + 32 j (j < 4); B: row r0
+    size_t a_off[4];
+    unsigned a_ok = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = r0 + 32 * j;
+        const int uy = ay0 + row / HW_ - 1, ux = ax0 + row % HW_ - 1;
+        const bool ok = (unsigned)uy < (unsigned)p.Hi && (unsigned)ux < (unsigned)p.Wi;
+        a_off[j] = ok ? ((size_t)(tb * p.Hi + uy) * p.Wi + ux) * p.Cin : 0;
+        a_ok |= (ok ? 1u : 0u) << j;
+    }
+    const int nchunk = p.Cin / KC;
+    const int arow = (wave * 32 + li) * LDA, brow = li * LDA;
+
+    for (int reg = 0; reg < R; ++reg) {
+        if (!((regmask >> reg) & 1)) continue;
+        const int g = tb * R + reg;
+        const float* sscale = p.in_scale ? p.in_scale + (size_t)g * p.Cin : nullptr;
+
+        f32x16 acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+        f32x4 pa[4], pb;
+        auto fetch_a = [&](int c0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pa[j] = *reinterpret_cast<const f32x4*>(p.x + a_off[j] + c0 + c4);
+        };
+        auto store_a = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(sA + buf * (ROWS * LDA) + (r0 + 32 * j) * LDA + c4) =
+                    ((a_ok >> j) & 1u) ? pa[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        auto fetch_b = [&](int tap, int c0) {
+            pb = *reinterpret_cast<const f32x4*>(p.w + ((size_t)tap * p.Cout + n0 + r0) * p.Cin + c0 + c4);
+            if (sscale) pb *= *reinterpret_cast<const f32x4*>(sscale + c0 + c4);
+        };
+        auto store_b = [&](int buf) { *reinterpret_cast<f32x4*>(sB + buf * (BN * LDA) + r0 * LDA + c4) = pb; };
+
+        fetch_a(0);
+        fetch_b(0, 0);
+        store_a(0);
+        store_b(0);
+        __syncthreads();
+
+        int s = 0;
+        for (int c = 0; c < nchunk; ++c) {
+            const bool more_c = (c + 1 < nchunk);
+            if (more_c) fetch_a((c + 1) * KC);
+            const float* Ab = sA + (c & 1) * (ROWS * LDA) + arow;
+#pragma unroll
+            for (int k = 0; k < 9; ++k, ++s) {
+                const bool more = (k < 8) || more_c;
+                if (more) fetch_b(k < 8 ? k + 1 : 0, (k < 8 ? c : c + 1) * KC);
+                const float* Bb = sB + (s & 1) * (BN * LDA) + brow;
+#pragma unroll
+                for (int kk = 0; kk < KC / 8; ++kk) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(Ab + kk * 8 + kh * 4);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(Bb + kk * 8 + kh * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[k], 0, 0, 0);
+                }
+                if (k == 8 && more_c) store_a((c + 1) & 1);
+                if (more) store_b((s + 1) & 1);
+                __syncthreads();
+            }
+        }
+
+        // ---- transposed-conv scatter: I[2u + k] += P_k[u] (the staging buffers are free now) -----------------
+        for (int t = tid; t < ITILE_WORDS; t += NTHR) sI[t] = 0.f;
+        int ibase[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            ibase[r] = ((2 * (row / HW_)) * IQW + 2 * (row % HW_)) * BN + li;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int off = ((k / 3) * IQW + (k % 3)) * BN;       // q = 2u + k: no predicate, the tile holds all of them
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sI[ibase[r] + off] += acc[k][r];
+            __syncthreads();
+        }
+
+        // ---- blur + demodulation + noise + bias + activation; a pass writes only the pixels of its own region ------
+        {
+            const int co = tid & 31, grp = tid >> 5;
+            const int col = n0 + co;
+            const float dsc = p.out_scale ? p.out_scale[(size_t)g * p.Cout + col] : 1.f;
+            const float bsv = p.bias ? p.bias[col] : 0.f;
+            const float nw = p.noise ? p.noise_w[0] : 0.f;
+            const float slp = (p.act == 2) ? p.slope[col] : p.alpha;
+            const float gain = (p.act == 1) ? p.gain : 1.f;
+            for (int t = grp; t < OH * OW; t += NTHR / 32) {
+                const int lab = sm.lab[t];
+                if (lab == 255 || (p.labels && lab != reg)) continue;
+                const int py = t / OW, px = t - py * OW;
+                float v = 0.f;
+#pragma unroll
+                for (int jy = 0; jy < 4; ++jy)
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx)
+                        v += sm.kf[jy * 4 + jx] * sI[((py + jy + 1) * IQW + px + jx + 1) * BN + co];
+                const int oy = oy0 + py, ox = ox0 + px;
+                const int64_t opix = ((int64_t)tb * p.Ho + oy) * p.Wo + ox;
+                v = v * dsc + bsv;
+                if (p.noise) {
+                    const int64_t npix = (int64_t)tb * p.noise_bstride + (int64_t)oy * p.Wo + ox;
+                    v += p.noise_per_channel ? nw * p.noise[npix * p.Cout + col] : nw * p.noise[npix];
+                }
+                if (p.act) v = (v > 0.f ? v : v * slp) * gain;
+                p.y[opix * p.Cout + col] = v;
+            }
+        }
+        __syncthreads();          // the I tile is overwritten by the next pass's staging
+    }
+}
+
+}  // namespace
+
+extern "C" int e4s_upconv_mfma_f32(const e4s_conv_params* pp, const float* k4, void* stream) {
+    const e4s_conv_params& p = *pp;
+    if (p.Cin % KC || p.Cout % BN || !k4) return (int)hipErrorInvalidValue;
+    if (p.Ho != 2 * p.Hi || p.Wo != 2 * p.Wi) return (int)hipErrorInvalidValue;
+    if (p.labels && (p.groups_per_batch < 1 || p.groups_per_batch > 16)) return (int)hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UpSmem));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int ntn = p.Cout / BN;
+    const int64_t mtiles = (int64_t)p.B * ((p.Hi + TAH - 1) / TAH) * ((p.Wi + TAW - 1) / TAW);
+    if (mtiles <= 0) return 0;
+    hipLaunchKernelGGL(upconv_kernel, dim3((unsigned)(mtiles * ntn)), dim3(NTHR), sizeof(UpSmem), as_stream(stream), p, k4, ntn);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}

@@ -245,6 +245,40 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     return y
 
 
+def upconv_mfma(x, w3, cout, k4, *, in_scale=None, out_scale=None, labels=None, num_regions=1, noise=None,
+                noise_w=None, noise_per_channel=False, bias=None, act=0, alpha=0.2, gain=LRELU_GAIN):
+    """Exact transposed-conv + blur up-sampling conv.  x NHWC [B,H,W,Cin]; w3 [1,9,Cout,Cin] (plain taps);
+    k4 the 4x4 blur kernel -> y NHWC [B,2H,2W,Cout]."""
+    b, hi, wi, cin = x.shape
+    ho, wo = 2 * hi, 2 * wi
+    y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32)
+    p = ConvParams()
+    p.x, p.w, p.y = fptr(x), fptr(w3), fptr(y)
+    p.rows = p.tiles = p.meta = None
+    p.tiles_cap = 0
+    p.B, p.Ha, p.Wa = b, hi, wi
+    p.Hi, p.Wi, p.Ho, p.Wo, p.Cin, p.Cout = hi, wi, ho, wo, cin, cout
+    p.istride, p.ostride, p.ntaps, p.ncls = 1, 2, 9, 1
+    p.in_scale, p.out_scale = fptr(in_scale), fptr(out_scale)
+    p.groups_per_batch = num_regions if labels is not None else 1
+    if labels is not None:
+        p.labels, p.Hm, p.Wm = ptr(labels), labels.shape[1], labels.shape[2]
+    else:
+        p.labels, p.Hm, p.Wm = None, 0, 0
+    if noise is not None:
+        p.noise, p.noise_w = fptr(noise), fptr(noise_w)
+        p.noise_bstride = ho * wo if noise.shape[0] > 1 else 0
+        p.noise_per_channel = 1 if noise_per_channel else 0
+    else:
+        p.noise = p.noise_w = None
+        p.noise_bstride = 0
+        p.noise_per_channel = 0
+    p.bias, p.slope = fptr(bias), None
+    p.act, p.alpha, p.gain = act, alpha, gain
+    call("e4s_upconv_mfma_f32", ctypes.byref(p), fptr(_f32(k4)), stream())
+    return y
+
+
 def torgb(x, ws, bias, skip, k4, labels, num_regions):
     """x NHWC [B,H,W,Cin]; ws [G,3,Cin]; skip NCHW [B,3,H/2,W/2] or None -> NCHW [B,3,H,W]."""
     b, h, w, cin = x.shape

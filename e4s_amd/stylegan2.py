@@ -19,6 +19,7 @@ chain of per-region ATen ops; it drives the fused HIP kernels of libe4s_hip.so
 There is no CPU path: tensors must live on a ROCm device and the library must be built.
 """
 import math
+import os
 import random
 
 import torch
@@ -27,6 +28,11 @@ from torch.nn import functional as F
 
 from . import kernels as K
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix
+
+
+# Up-sampling StyledConvs: exact tile-fused transposed conv + blur (e4s_upconv_mfma_f32, 9*Cin*Cout MACs per input
+# pixel) or the polyphase form on the generic conv kernel (36).  Same function, different rounding order.
+UPCONV_EXACT = os.environ.get("E4S_UPCONV", "exact") != "polyphase"
 
 
 def make_kernel(k):
@@ -193,6 +199,7 @@ class ModulatedConv2d(nn.Module):
             else:
                 # same math as polyphase_upconv_weights() below (the CPU-tested statement of it)
                 pack["w"] = K.polyphase_weights(w.contiguous(), self.blur.kernel.detach().float())
+                pack["w3"] = K.pack_taps(w.contiguous())        # plain taps for the exact tile-fused up-conv
             pack["wsq"] = K.weight_sqsum(w.contiguous()) if self.demodulate else None
         self._pack = pack
         return pack
@@ -278,6 +285,11 @@ class StyledConv(nn.Module):
             if per_ch:
                 raise NotImplementedError("backward with per-channel noise maps")
             rec.update(d=d, noise=nz)
+        if conv.upsample and plan is None and UPCONV_EXACT:
+            return K.upconv_mfma(x, pk["w3"], conv.out_channel, conv.blur.kernel, in_scale=s, out_scale=d,
+                                 labels=labels, num_regions=num_regions, noise=nz, noise_w=self.noise.weight,
+                                 noise_per_channel=per_ch, bias=self.activate.bias, act=1,
+                                 alpha=self.activate.negative_slope, gain=self.activate.scale)
         return K.conv_mfma(x, pk["w"], conv.out_channel, plan=plan, labels=None if plan is not None else labels,
                            num_regions=num_regions, ncls=4 if conv.upsample else 1,
                            ostride=2 if conv.upsample else 1, in_scale=s, out_scale=d, noise=nz,

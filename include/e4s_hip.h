@@ -133,6 +133,13 @@ typedef struct {
  * (natural order, istride == 1, Ha % 8 == 0, Wa % 16 == 0). */
 int e4s_conv_mfma_f32(const e4s_conv_params* p, int spatial, void* stream);
 
+/* Exact up-sampling StyledConv: conv_transpose2d(stride 2) + 4x4 blur (model.py:287-300) with the transposed conv's
+ * minimal 9*Cin*Cout MACs per input pixel on the matrix cores and the blur applied from an LDS-resident intermediate
+ * (the polyphase ncls = 4 form of e4s_conv_mfma_f32 spends 36).  Same params struct: x NHWC [B,Hi,Wi,Cin], w = plain
+ * tap-packed 3x3 weights [9][Cout][Cin] (e4s_pack_taps_f32), y NHWC [B,2Hi,2Wi,Cout], in_scale/out_scale/labels/noise/
+ * bias/act as for the spatial mode; k4 = the module's 4x4 blur kernel.  Cin % 32 == 0, Cout % 32 == 0. */
+int e4s_upconv_mfma_f32(const e4s_conv_params* p, const float* k4, void* stream);
+
 /* ---- backward of the fused generator (configs 3 and 5) -------------------- */
 typedef struct {
     const float* gz;         /* dL/d(out_pre), NHWC [B, Hy, Wy, Cy]  (Cy = forward Cout) */
