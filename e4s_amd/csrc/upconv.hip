@@ -24,7 +24,8 @@ constexpr int BN = 32;
 constexpr int OH = 2 * TAH, OW = 2 * TAW;        // 12 x 28 outputs
 constexpr int IQH = 2 * (TAH + 2) + 1, IQW = 2 * HW_ + 1;   // 17 x 33: every position a halo pixel scatters to
                                                             // (the 15 x 31 interior feeds the tile's outputs)
-constexpr int STAGE_WORDS = 2 * ROWS * LDA + 2 * BN * LDA;
+constexpr int TG = 3;                            // taps staged (and MFMA'd) per barrier: 3 x 16 MFMAs per wave
+constexpr int STAGE_WORDS = 2 * ROWS * LDA + 2 * TG * BN * LDA;
 constexpr int ITILE_WORDS = IQH * IQW * BN;
 constexpr int UNION_WORDS = STAGE_WORDS > ITILE_WORDS ? STAGE_WORDS : ITILE_WORDS;
 
@@ -33,7 +34,7 @@ struct UpSmem {
     int regmask;
     int pad_[3];
     unsigned char lab[OH * OW];                  // region of each output pixel of the tile (336 B)
-    float buf[UNION_WORDS];                      // K loop: A[2][128][36], B[2][32][36];  epilogue: I[15][31][32]
+    float buf[UNION_WORDS];                      // K loop: A[2][128][36], B[2][3][32][36];  epilogue: I[17][33][32]
 };
 
 __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p, const float* __restrict__ k4,
@@ -80,14 +81,14 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
 
     // ---- staging roles ---------------------------------------------------------------------------------------
     const int c4 = (tid & 7) * 4, r0 = tid >> 3;              // A: rows r0 + 32 j (j < 4); B: row r0
-    size_t a_off[4];
+    unsigned a_off[4];                                   // element offsets (launcher checks they fit 32 bits)
     unsigned a_ok = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = r0 + 32 * j;
         const int uy = ay0 + row / HW_ - 1, ux = ax0 + row % HW_ - 1;
         const bool ok = (unsigned)uy < (unsigned)p.Hi && (unsigned)ux < (unsigned)p.Wi;
-        a_off[j] = ok ? ((size_t)(tb * p.Hi + uy) * p.Wi + ux) * p.Cin : 0;
+        a_off[j] = ok ? (unsigned)(((tb * p.Hi + uy) * p.Wi + ux) * p.Cin) : 0u;
         a_ok |= (ok ? 1u : 0u) << j;
     }
     const int nchunk = p.Cin / KC;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-        f32x4 pa[4], pb;
+        f32x4 pa[4], pb[TG], psc = {1.f, 1.f, 1.f, 1.f};
         auto fetch_a = [&](int c0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) pa[j] = *reinterpret_cast<const f32x4*>(p.x + a_off[j] + c0 + c4);
@@ -115,11 +116,19 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
                 *reinterpret_cast<f32x4*>(sA + buf * (ROWS * LDA) + (r0 + 32 * j) * LDA + c4) =
                     ((a_ok >> j) & 1u) ? pa[j] : f32x4{0.f, 0.f, 0.f, 0.f};
         };
-        auto fetch_b = [&](int tap, int c0) {
-            pb = *reinterpret_cast<const f32x4*>(p.w + ((size_t)tap * p.Cout + n0 + r0) * p.Cin + c0 + c4);
-            if (sscale) pb *= *reinterpret_cast<const f32x4*>(sscale + c0 + c4);
+        // B of one tap group (3 taps x 32 couts x 32 channels); the style scale is applied when the registers are
+        // written to LDS, so that nothing waits on a load right after issuing it
+        auto fetch_b = [&](int tg, int c0) {
+#pragma unroll
+            for (int j = 0; j < TG; ++j)
+                pb[j] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)(tg * TG + j) * p.Cout + n0 + r0) * p.Cin + c0 + c4);
+            if (sscale) psc = *reinterpret_cast<const f32x4*>(sscale + c0 + c4);
         };
-        auto store_b = [&](int buf) { *reinterpret_cast<f32x4*>(sB + buf * (BN * LDA) + r0 * LDA + c4) = pb; };
+        auto store_b = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < TG; ++j)
+                *reinterpret_cast<f32x4*>(sB + (buf * TG + j) * (BN * LDA) + r0 * LDA + c4) = pb[j] * psc;
+        };
 
         fetch_a(0);
         fetch_b(0, 0);
@@ -133,18 +142,23 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
             if (more_c) fetch_a((c + 1) * KC);
             const float* Ab = sA + (c & 1) * (ROWS * LDA) + arow;
 #pragma unroll
-            for (int k = 0; k < 9; ++k, ++s) {
-                const bool more = (k < 8) || more_c;
-                if (more) fetch_b(k < 8 ? k + 1 : 0, (k < 8 ? c : c + 1) * KC);
-                const float* Bb = sB + (s & 1) * (BN * LDA) + brow;
+            for (int tg = 0; tg < 9 / TG; ++tg, ++s) {
+                const bool last = (tg == 9 / TG - 1);
+                const bool more = !last || more_c;
+                if (more) fetch_b(last ? 0 : tg + 1, (last ? c + 1 : c) * KC);
 #pragma unroll
-                for (int kk = 0; kk < KC / 8; ++kk) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(Ab + kk * 8 + kh * 4);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(Bb + kk * 8 + kh * 4);
+                for (int j = 0; j < TG; ++j) {
+                    const float* Bb = sB + ((s & 1) * TG + j) * (BN * LDA) + brow;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[k], 0, 0, 0);
+                    for (int kk = 0; kk < KC / 8; ++kk) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(Ab + kk * 8 + kh * 4);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(Bb + kk * 8 + kh * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[tg * TG + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[tg * TG + j], 0, 0, 0);
+                    }
                 }
-                if (k == 8 && more_c) store_a((c + 1) & 1);
+                if (last && more_c) store_a((c + 1) & 1);
                 if (more) store_b((s + 1) & 1);
                 __syncthreads();
             }
@@ -207,6 +221,7 @@ extern "C" int e4s_upconv_mfma_f32(const e4s_conv_params* pp, const float* k4, v
     const e4s_conv_params& p = *pp;
     if (p.Cin % KC || p.Cout % BN || !k4) return (int)hipErrorInvalidValue;
     if (p.Ho != 2 * p.Hi || p.Wo != 2 * p.Wi) return (int)hipErrorInvalidValue;
+    if ((int64_t)p.B * p.Hi * p.Wi * p.Cin >= (1ll << 31)) return (int)hipErrorInvalidValue;
     if (p.labels && (p.groups_per_batch < 1 || p.groups_per_batch > 16)) return (int)hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {

@@ -33,6 +33,7 @@ from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix
 # Up-sampling StyledConvs: exact tile-fused transposed conv + blur (e4s_upconv_mfma_f32, 9*Cin*Cout MACs per input
 # pixel) or the polyphase form on the generic conv kernel (36).  Same function, different rounding order.
 UPCONV_EXACT = os.environ.get("E4S_UPCONV", "exact") != "polyphase"
+UPCONV_EXACT_MIN_RES = int(os.environ.get("E4S_UPCONV_MIN_RES", "128"))     # masked layers below this stay polyphase
 
 
 def make_kernel(k):
@@ -285,7 +286,8 @@ class StyledConv(nn.Module):
             if per_ch:
                 raise NotImplementedError("backward with per-channel noise maps")
             rec.update(d=d, noise=nz)
-        if conv.upsample and plan is None and UPCONV_EXACT:
+        # a masked tile runs one pass per region present: exact only where 12x28 output tiles are mostly uniform
+        if conv.upsample and plan is None and UPCONV_EXACT and (labels is None or ho >= UPCONV_EXACT_MIN_RES):
             return K.upconv_mfma(x, pk["w3"], conv.out_channel, conv.blur.kernel, in_scale=s, out_scale=d,
                                  labels=labels, num_regions=num_regions, noise=nz, noise_w=self.noise.weight,
                                  noise_per_channel=per_ch, bias=self.activate.bias, act=1,
