@@ -34,6 +34,7 @@ struct UpSmem {
     int regmask;
     int pad_[3];
     unsigned char lab[OH * OW];                  // region of each output pixel of the tile (336 B)
+    float nz[OH * OW];                           // noise_w * noise of each output pixel (per-pixel noise maps)
     float buf[UNION_WORDS];                      // K loop: A[2][128][36], B[2][3][32][36];  epilogue: I[17][33][32]
 };
 
@@ -75,6 +76,10 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
             atomicOr(&sm.regmask, 1 << r);
         }
         sm.lab[t] = (unsigned char)r;
+        float nzv = 0.f;
+        if (r != 255 && p.noise && !p.noise_per_channel)
+            nzv = p.noise_w[0] * p.noise[(int64_t)tb * p.noise_bstride + (int64_t)oy * p.Wo + ox];
+        sm.nz[t] = nzv;
     }
     __syncthreads();
     const int regmask = sm.regmask;
@@ -190,23 +195,25 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
             const float nw = p.noise ? p.noise_w[0] : 0.f;
             const float slp = (p.act == 2) ? p.slope[col] : p.alpha;
             const float gain = (p.act == 1) ? p.gain : 1.f;
+            const bool nz_pc = p.noise && p.noise_per_channel;
+            float kf[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) kf[j] = sm.kf[j];
+#pragma unroll 2
             for (int t = grp; t < OH * OW; t += NTHR / 32) {
                 const int lab = sm.lab[t];
                 if (lab == 255 || (p.labels && lab != reg)) continue;
                 const int py = t / OW, px = t - py * OW;
+                const float* ip = sI + ((py + 1) * IQW + px + 1) * BN + co;
                 float v = 0.f;
 #pragma unroll
                 for (int jy = 0; jy < 4; ++jy)
 #pragma unroll
-                    for (int jx = 0; jx < 4; ++jx)
-                        v += sm.kf[jy * 4 + jx] * sI[((py + jy + 1) * IQW + px + jx + 1) * BN + co];
+                    for (int jx = 0; jx < 4; ++jx) v += kf[jy * 4 + jx] * ip[(jy * IQW + jx) * BN];
                 const int oy = oy0 + py, ox = ox0 + px;
                 const int64_t opix = ((int64_t)tb * p.Ho + oy) * p.Wo + ox;
-                v = v * dsc + bsv;
-                if (p.noise) {
-                    const int64_t npix = (int64_t)tb * p.noise_bstride + (int64_t)oy * p.Wo + ox;
-                    v += p.noise_per_channel ? nw * p.noise[npix * p.Cout + col] : nw * p.noise[npix];
-                }
+                v = v * dsc + bsv + sm.nz[t];
+                if (nz_pc) v += nw * p.noise[((int64_t)tb * p.noise_bstride + (int64_t)oy * p.Wo + ox) * p.Cout + col];
                 if (p.act) v = (v > 0.f ? v : v * slp) * gain;
                 p.y[opix * p.Cout + col] = v;
             }
