@@ -13,6 +13,7 @@
 // Region-select: the style of a tile is uniform per pass; tiles whose output pixels belong to several regions run one
 // pass per region present (style folded into the B tile while staging) and each pass writes only its own pixels.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -38,6 +39,8 @@ struct UpSmem {
     float buf[UNION_WORDS];                      // K loop: A[2][128][36], B[2][3][32][36];  epilogue: I[17][33][32]
 };
 
+// ABL (ablation, profiling only): 0 full; 1 skip the K loop; 2 skip zero-fill + scatter; 3 skip the blur/store phase
+template <int ABL>
 __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p, const float* __restrict__ k4,
                                                          const int ntn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
         __syncthreads();
 
         int s = 0;
-        for (int c = 0; c < nchunk; ++c) {
+        for (int c = 0; c < (ABL == 1 ? 0 : nchunk); ++c) {
             const bool more_c = (c + 1 < nchunk);
             if (more_c) fetch_a((c + 1) * KC);
             const float* Ab = sA + (c & 1) * (ROWS * LDA) + arow;
@@ -170,7 +173,8 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
         }
 
         // ---- transposed-conv scatter: I[2u + k] += P_k[u] (the staging buffers are free now) -----------------
-        for (int t = tid; t < ITILE_WORDS; t += NTHR) sI[t] = 0.f;
+        if (ABL != 2)
+            for (int t = tid; t < ITILE_WORDS / 4; t += NTHR) reinterpret_cast<f32x4*>(sI)[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         int ibase[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -178,13 +182,20 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
             ibase[r] = ((2 * (row / HW_)) * IQW + 2 * (row % HW_)) * BN + li;
         }
         __syncthreads();
+        // LDS float atomics (ds_add_f32, no return value): taps that hit the same q are ordered by the hardware, so no
+        // barrier is needed between taps and the 144 adds of a thread pipeline instead of 144 read-modify-write trips
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int off = ((k / 3) * IQW + (k % 3)) * BN;       // q = 2u + k: no predicate, the tile holds all of them
+            if (ABL != 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sI[ibase[r] + off] += acc[k][r];
-            __syncthreads();
+                for (int r = 0; r < 16; ++r) atomicAdd(&sI[ibase[r] + off], acc[k][r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[k][r]), "v"(ibase[r] + off));
+            }
         }
+        __syncthreads();
 
         // ---- blur + demodulation + noise + bias + activation; a pass writes only the pixels of its own region ------
         {
@@ -199,23 +210,36 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
             float kf[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) kf[j] = sm.kf[j];
-#pragma unroll 2
-            for (int t = grp; t < OH * OW; t += NTHR / 32) {
-                const int lab = sm.lab[t];
-                if (lab == 255 || (p.labels && lab != reg)) continue;
-                const int py = t / OW, px = t - py * OW;
-                const float* ip = sI + ((py + 1) * IQW + px + 1) * BN + co;
-                float v = 0.f;
+            // sliding 4x4 window down each output column: 4 new LDS reads per output instead of 16
+            for (int px = grp; px < (ABL == 3 ? 0 : OW); px += NTHR / 32) {
+                const float* ip = sI + (IQW + px + 1) * BN + co;          // I row 1, column px + 1
+                float w0[4], w1[4], w2[4], w3[4];
 #pragma unroll
-                for (int jy = 0; jy < 4; ++jy)
+                for (int jx = 0; jx < 4; ++jx) {
+                    w0[jx] = ip[jx * BN];
+                    w1[jx] = ip[(IQW + jx) * BN];
+                    w2[jx] = ip[(2 * IQW + jx) * BN];
+                }
 #pragma unroll
-                    for (int jx = 0; jx < 4; ++jx) v += kf[jy * 4 + jx] * ip[(jy * IQW + jx) * BN];
-                const int oy = oy0 + py, ox = ox0 + px;
-                const int64_t opix = ((int64_t)tb * p.Ho + oy) * p.Wo + ox;
-                v = v * dsc + bsv + sm.nz[t];
-                if (nz_pc) v += nw * p.noise[((int64_t)tb * p.noise_bstride + (int64_t)oy * p.Wo + ox) * p.Cout + col];
-                if (p.act) v = (v > 0.f ? v : v * slp) * gain;
-                p.y[opix * p.Cout + col] = v;
+                for (int py = 0; py < OH; ++py) {
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) w3[jx] = ip[((py + 3) * IQW + jx) * BN];
+                    float v = 0.f;
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx)
+                        v += kf[jx] * w0[jx] + kf[4 + jx] * w1[jx] + kf[8 + jx] * w2[jx] + kf[12 + jx] * w3[jx];
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) { w0[jx] = w1[jx]; w1[jx] = w2[jx]; w2[jx] = w3[jx]; }
+                    const int t = py * OW + px;
+                    const int lab = sm.lab[t];
+                    if (lab == 255 || (p.labels && lab != reg)) continue;
+                    const int oy = oy0 + py, ox = ox0 + px;
+                    const int64_t opix = ((int64_t)tb * p.Ho + oy) * p.Wo + ox;
+                    v = v * dsc + bsv + sm.nz[t];
+                    if (nz_pc) v += nw * p.noise[((int64_t)tb * p.noise_bstride + (int64_t)oy * p.Wo + ox) * p.Cout + col];
+                    if (p.act) v = (v > 0.f ? v : v * slp) * gain;
+                    p.y[opix * p.Cout + col] = v;
+                }
             }
         }
         __syncthreads();          // the I tile is overwritten by the next pass's staging
@@ -232,7 +256,7 @@ extern "C" int e4s_upconv_mfma_f32(const e4s_conv_params* pp, const float* k4, v
     if (p.labels && (p.groups_per_batch < 1 || p.groups_per_batch > 16)) return (int)hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_kernel<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UpSmem));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -240,7 +264,26 @@ extern "C" int e4s_upconv_mfma_f32(const e4s_conv_params* pp, const float* k4, v
     const int ntn = p.Cout / BN;
     const int64_t mtiles = (int64_t)p.B * ((p.Hi + TAH - 1) / TAH) * ((p.Wi + TAW - 1) / TAW);
     if (mtiles <= 0) return 0;
-    hipLaunchKernelGGL(upconv_kernel, dim3((unsigned)(mtiles * ntn)), dim3(NTHR), sizeof(UpSmem), as_stream(stream), p, k4, ntn);
+    static const int abl = getenv("E4S_UPCONV_ABL") ? atoi(getenv("E4S_UPCONV_ABL")) : 0;
+    if (abl) {          // profiling only: wrong results by construction
+        auto set = [](const void* f) { hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UpSmem)); };
+        dim3 gr((unsigned)(mtiles * ntn)), bl(NTHR);
+        if (abl == 1) { set((const void*)upconv_kernel<1>); hipLaunchKernelGGL(upconv_kernel<1>, gr, bl, sizeof(UpSmem), as_stream(stream), p, k4, ntn); }
+        if (abl == 2) { set((const void*)upconv_kernel<2>); hipLaunchKernelGGL(upconv_kernel<2>, gr, bl, sizeof(UpSmem), as_stream(stream), p, k4, ntn); }
+        if (abl == 3) { set((const void*)upconv_kernel<3>); hipLaunchKernelGGL(upconv_kernel<3>, gr, bl, sizeof(UpSmem), as_stream(stream), p, k4, ntn); }
+        E4S_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(upconv_kernel<0>, dim3((unsigned)(mtiles * ntn)), dim3(NTHR), sizeof(UpSmem), as_stream(stream), p, k4, ntn);
     E4S_CHECK_LAUNCH();
     return 0;
+}
+
+// diagnostic: resident blocks per CU of the up-conv kernel according to the runtime
+extern "C" int e4s_upconv_blocks_per_cu(void) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)sizeof(UpSmem));
+    int n = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(upconv_kernel<0>), NTHR, sizeof(UpSmem));
+    return n;
 }

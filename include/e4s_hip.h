@@ -139,6 +139,7 @@ int e4s_conv_mfma_f32(const e4s_conv_params* p, int spatial, void* stream);
  * tap-packed 3x3 weights [9][Cout][Cin] (e4s_pack_taps_f32), y NHWC [B,2Hi,2Wi,Cout], in_scale/out_scale/labels/noise/
  * bias/act as for the spatial mode; k4 = the module's 4x4 blur kernel.  Cin % 32 == 0, Cout % 32 == 0. */
 int e4s_upconv_mfma_f32(const e4s_conv_params* p, const float* k4, void* stream);
+int e4s_upconv_blocks_per_cu(void);    /* diagnostic: occupancy of that kernel as the runtime computes it */
 
 /* ---- backward of the fused generator (configs 3 and 5) -------------------- */
 typedef struct {
