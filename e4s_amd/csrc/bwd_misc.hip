@@ -50,7 +50,7 @@ __global__ void demod_grad_kernel(const float* __restrict__ gz, const float* __r
         if (cc >= cw) continue;
         float s = 0.f;
         for (int j = 0; j < NPG; ++j) s += sums[(j * R + r) * 64 + cc];
-        if (s != 0.f) atomicAdd(&dd[((int64_t)b * R + r) * C + slab * cw + cc], s);
+        if (s != 0.f) unsafeAtomicAdd(&dd[((int64_t)b * R + r) * C + slab * cw + cc], s);
     }
 }
 
@@ -87,7 +87,7 @@ __global__ void torgb_bwd_w_kernel(const float* __restrict__ drgb, const float* 
         if (cc >= cw) continue;
         float s = 0.f;
         for (int j = 0; j < NPG; ++j) s += sums[((j * R + r) * 3 + ch) * 64 + cc];
-        if (s != 0.f) atomicAdd(&dws[(((int64_t)b * R + r) * 3 + ch) * C + slab * cw + cc], s);
+        if (s != 0.f) unsafeAtomicAdd(&dws[(((int64_t)b * R + r) * 3 + ch) * C + slab * cw + cc], s);
     }
 }
 

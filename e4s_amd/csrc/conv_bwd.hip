@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
                 acc[tm][r] += sm.sS[g * BN + ncol] * t;
                 if (p.ds) {
                     const int off = sm.out_off[row];
-                    if (off >= 0) atomicAdd(&sm.dS[g * BN + ncol], p.x[(size_t)off * p.Cx + n0 + ncol] * t);
+                    if (off >= 0) unsafeAtomicAdd(&sm.dS[g * BN + ncol], p.x[(size_t)off * p.Cx + n0 + ncol] * t);
                 }
             }
         }
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
         __syncthreads();
         for (int t = tid; t < R * BN; t += NTHR) {
             const float v = sm.dS[t];
-            if (v != 0.f) atomicAdd(&p.ds[((size_t)tb * R + t / BN) * p.Cx + n0 + (t % BN)], v);
+            if (v != 0.f) unsafeAtomicAdd(&p.ds[((size_t)tb * R + t / BN) * p.Cx + n0 + (t % BN)], v);
         }
     }
 }

@@ -90,8 +90,8 @@ __global__ void instnorm_partial_kernel(const float* __restrict__ x, double* __r
     if (pg == 0) {
         s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
         q = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-        atomicAdd(&ws[((int64_t)b * C + c) * 2 + 0], s);
-        atomicAdd(&ws[((int64_t)b * C + c) * 2 + 1], q);
+        unsafeAtomicAdd(&ws[((int64_t)b * C + c) * 2 + 0], s);
+        unsafeAtomicAdd(&ws[((int64_t)b * C + c) * 2 + 1], q);
     }
 }
 

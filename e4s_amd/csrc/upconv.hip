@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
             const int off = ((k / 3) * IQW + (k % 3)) * BN;       // q = 2u + k: no predicate, the tile holds all of them
             if (ABL != 2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(&sI[ibase[r] + off], acc[k][r]);
+                for (int r = 0; r < 16; ++r) unsafeAtomicAdd(&sI[ibase[r] + off], acc[k][r]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[k][r]), "v"(ibase[r] + off));
