@@ -27,7 +27,9 @@ struct BwdSmem {
     int yx[BM];                      // (qy << 16) | qx
     unsigned char grp[36][BM];       // region of the tap-shifted pixel per (phase*9+tap', row); 255 = outside
     float sS[MAXR * BN];             // s[r][n0 + n]
-    float dS[MAXR * BN];             // ds partial sums of this tile
+    float dS[128 / BN][MAXR * BN];   // ds partial sums of this tile, one slab per wave row (wm = 0 .. 4/(BN/32)-1): no atomics
+    int regmask;                     // regions touched by any (row, tap) of the tile
+    int pad_[3];
     float sD[2][MAXR * LDA];         // d[r][k0 .. k0+32) of the current stage
     float A[2][BM * LDA];
     float B[2][BN * LDA];
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
         sm.out_off[tid] = valid ? (tb * p.Hx + qy) * p.Wx + qx : -1;
         sm.yx[tid] = (qy << 16) | qx;
     }
+    if (tid == 0) sm.regmask = 0;
+    __syncthreads();
     for (int t = tid; t < ngroups * BM; t += NTHR) {
         const int grp = t / BM, row = t - grp * BM;
         const int ph = grp / 9, tp = grp - ph * 9;
@@ -75,11 +79,13 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
             }
         }
         sm.grp[grp][row] = r;
+        if (r != 255) atomicOr(&sm.regmask, 1 << r);
     }
     for (int t = tid; t < R * BN; t += NTHR) {
         const int r = t / BN, n = t - r * BN;
         sm.sS[t] = p.s ? p.s[((size_t)tb * R + r) * p.Cx + n0 + n] : 1.f;
-        sm.dS[t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 128 / BN; ++j) sm.dS[j][t] = 0.f;
     }
     __syncthreads();
 
@@ -125,6 +131,18 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
     for (int tm = 0; tm < TM; ++tm) arow[tm] = (wm * TM + tm) * 32 + li;
     const int brow = (wn * 32 + li) * LDA;
 
+    // forward input of this tile in accumulator layout (rows x column li), for ds = sum x * T
+    f32x16 xv[TM];
+    const int regmask = sm.regmask;
+    if (p.ds) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = sm.out_off[(wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+                xv[tm][r] = off >= 0 ? p.x[(size_t)off * p.Cx + n0 + wn * 32 + li] : 0.f;
+            }
+    }
     f32x16 acc[TM], tmp[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -177,20 +195,30 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
             __syncthreads();
         }
         // ---- tap-group epilogue: final += s[r(p)][ci] * T ;  ds[r(p)][ci] += x[q,ci] * T ----------------------
+        // ds: per region present, an in-register masked sum over this lane's 16*TM rows, one shuffle across the two
+        // row halves of the wave, then a plain add into the wave-row's own LDS slab (LDS float atomics are ~100x slower)
         const int ncol = wn * 32 + li;
+        int gq[TM][16];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 const int g = sm.grp[grp][row];
-                if (g == 255) continue;                      // tap outside the image: T is exactly 0
-                const float t = tmp[tm][r];
-                acc[tm][r] += sm.sS[g * BN + ncol] * t;
-                if (p.ds) {
-                    const int off = sm.out_off[row];
-                    if (off >= 0) unsafeAtomicAdd(&sm.dS[g * BN + ncol], p.x[(size_t)off * p.Cx + n0 + ncol] * t);
-                }
+                gq[tm][r] = g;
+                if (g != 255) acc[tm][r] += sm.sS[g * BN + ncol] * tmp[tm][r];    // outside the image T is exactly 0
+            }
+        }
+        if (p.ds) {
+            for (int rr = 0; rr < R; ++rr) {
+                if (!((regmask >> rr) & 1)) continue;
+                float part = 0.f;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part += (gq[tm][r] == rr) ? xv[tm][r] * tmp[tm][r] : 0.f;
+                part += __shfl_xor(part, 32, 64);
+                if (kh == 0) sm.dS[wm][rr * BN + ncol] += part;
             }
         }
     }
@@ -208,7 +236,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
     if (p.ds) {
         __syncthreads();
         for (int t = tid; t < R * BN; t += NTHR) {
-            const float v = sm.dS[t];
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 128 / BN; ++j) v += sm.dS[j][t];
             if (v != 0.f) unsafeAtomicAdd(&p.ds[((size_t)tb * R + t / BN) * p.Cx + n0 + (t % BN)], v);
         }
     }

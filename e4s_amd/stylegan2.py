@@ -33,7 +33,7 @@ from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix
 # Up-sampling StyledConvs: exact tile-fused transposed conv + blur (e4s_upconv_mfma_f32, 9*Cin*Cout MACs per input
 # pixel) or the polyphase form on the generic conv kernel (36).  Same function, different rounding order.
 UPCONV_EXACT = os.environ.get("E4S_UPCONV", "exact") != "polyphase"
-UPCONV_EXACT_MIN_RES = int(os.environ.get("E4S_UPCONV_MIN_RES", "128"))     # masked layers below this stay polyphase
+UPCONV_EXACT_MIN_RES = int(os.environ.get("E4S_UPCONV_MIN_RES", "256"))     # masked layers below this stay polyphase
 
 
 def make_kernel(k):
