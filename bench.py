@@ -158,13 +158,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()      # == local_rank on a real N-GPU node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        backend = os.environ.get("E4S_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only to exercise the
+        if backend == "nccl":                                  # N>1 code path on a 1-GPU box
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
 

@@ -369,8 +369,10 @@ def grouped_linear(x, w, bias, add, scale, act=0, alpha=0.01):
     b, r, k = x.shape
     o = w.shape[1]
     y = torch.empty(b, r, o, device=x.device, dtype=torch.float32)
-    call("e4s_grouped_linear_f32", fptr(x), fptr(w), fptr(bias), fptr(add), fptr(y), b, r, k, o, float(scale),
-         act, float(alpha), stream())
+    for lo in range(0, b, 16):                      # the kernel keeps <= 16 samples' partial sums in registers
+        n = min(16, b - lo)
+        call("e4s_grouped_linear_f32", fptr(x[lo:lo + n]), fptr(w), fptr(bias), fptr(add), fptr(y[lo:lo + n]), n, r, k, o,
+             float(scale), act, float(alpha), stream())
     return y
 
 

@@ -86,3 +86,26 @@ def test_no_cpu_fallback():
         fused_leaky_relu(torch.zeros(1, 4, 2, 2), torch.zeros(4))
     with pytest.raises(RuntimeError):
         upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback when libe4s_hip.so is absent: load() must raise, naming the build command."""
+    from e4s_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "libe4s_hip.so"))
+    with pytest.raises(RuntimeError, match="e4s_amd.build"):
+        lib.load()
+
+
+def test_src_shim_reexports_native_modules():
+    import src.models.networks as n
+    import src.models.stylegan2.model as m
+    import src.models.stylegan2.op as op
+    import e4s_amd.networks, e4s_amd.stylegan2, e4s_amd.op
+    assert n.Net3 is e4s_amd.networks.Net3
+    assert m.Generator is e4s_amd.stylegan2.Generator and m.Discriminator is e4s_amd.stylegan2.Discriminator
+    assert op.upfirdn2d is e4s_amd.op.upfirdn2d and op.fused_leaky_relu is e4s_amd.op.fused_leaky_relu
+    from src.utils.torch_utils import labelMap2OneHot
+    lab = torch.randint(0, 12, (2, 1, 8, 8))
+    oh = labelMap2OneHot(lab, 12)
+    assert oh.shape == (2, 12, 8, 8) and torch.equal(oh.argmax(1, keepdim=True), lab) and float(oh.sum()) == 128.0
