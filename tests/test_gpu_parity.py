@@ -564,3 +564,28 @@ def test_soft_mask_fallback_and_net3_forward():
     assert torch.equal(imgs, img2) and torch.equal(latent, codes) and torch.equal(feats16, feats2)
     with pytest.raises(NotImplementedError):
         net.get_style_vectors(x, torch.softmax(torch.randn(1, 12, 512, 512, device=DEV), 1))
+
+
+def test_ops_double_backward_matches_oracle():
+    """Second-order path used by the R1 / path-length regularisers (op/fused_act.py:41-47, op/upfirdn2d.py:59-82)."""
+    from e4s_amd.op import fused_leaky_relu, upfirdn2d
+    g = torch.Generator().manual_seed(70)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    b = torch.randn(4, generator=g)
+    k = orc.make_blur_kernel() * 4
+    w = torch.randn(2, 4, 16, 16, generator=g)
+
+    def second_order(xt, bt, kt, wt, lrelu, up):
+        y = up(lrelu(xt, bt), kt)
+        (gx,) = torch.autograd.grad((y * wt).sum(), xt, create_graph=True)
+        return (gx ** 2).sum() + (y ** 2).sum()
+
+    xd, bd = x.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    ld = second_order(xd, bd, k.to(DEV), w.to(DEV), fused_leaky_relu, lambda t, kk: upfirdn2d(t, kk, up=2, pad=(2, 1)))
+    ld.backward()
+    xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lr_ = second_order(xr, br, k, w, orc.fused_leaky_relu, lambda t, kk: orc.upfirdn2d(t, kk, up=2, pad=(2, 1)))
+    lr_.backward()
+    assert abs(float(ld) - float(lr_)) < 1e-3 * abs(float(lr_))
+    assert maxabs(xd.grad, xr.grad) < 1e-4 * float(xr.grad.abs().max())
+    assert maxabs(bd.grad, br.grad) < 1e-4 * float(br.grad.abs().max())
