@@ -14,7 +14,7 @@ import torch
 from . import kernels as K
 
 
-def styled_conv_backward(rec, dy, num_regions):
+def styled_conv_backward(rec, dy, num_regions, extras=None):
     """Backward of one fused StyledConv launch.  rec: the forward tape record (layer, x, y, s, d, noise, labels);
     dy: dL/dy NHWC.  Returns (dL/dx NHWC, dL/ds [G,Cin] including the path through the demodulation d(s))."""
     layer = rec["layer"]
@@ -28,30 +28,103 @@ def styled_conv_backward(rec, dy, num_regions):
         pk["wt"] = K.pack_taps_bwd(pk["w"])
     dx, ds = K.conv_bwd(gz, pk["wt"], rec["x"], s, d, labels, num_regions, 4 if conv.upsample else 1)
     # d = scale * rsqrt(scale^2 sum_ci s^2 Wsq + eps)  =>  dd/ds_ci = -d^3 s_ci Wsq[co,ci]
-    ds = ds - s * ((dd * d * d * d) @ pk["wsq"])
+    dd3 = dd * d * d * d
+    ds = ds - s * (dd3 @ pk["wsq"])
+    if extras is not None:
+        extras.update(gz=gz, dd3=dd3)
     return dx, ds
 
 
+def _polyphase_map(blur_kernel):
+    """C[ph, e, k] with Weff[ph][e] = sum_k C[ph,e,k] W[k]  (same linear map as e4s_polyphase_weights_f32 /
+    stylegan2.polyphase_upconv_weights): C = kflip[ky - ty + 1, kx - tx + 1], ty = py - 2(ey - 1)."""
+    kf = torch.flip(blur_kernel.detach().float().cpu(), [0, 1])
+    cmap = torch.zeros(4, 9, 9)
+    for py in range(2):
+        for px in range(2):
+            for ey in range(3):
+                for ex in range(3):
+                    ty, tx = py - 2 * (ey - 1), px - 2 * (ex - 1)
+                    for ky in range(3):
+                        for kx in range(3):
+                            jy, jx = ky - ty + 1, kx - tx + 1
+                            if 0 <= jy < 4 and 0 <= jx < 4:
+                                cmap[py * 2 + px, ey * 3 + ex, ky * 3 + kx] = kf[jy, jx]
+    return cmap
+
+
+def styled_conv_weight_grad(rec, extras, num_regions):
+    """dL/d(conv.weight) [1,Cout,Cin,3,3] of one fused StyledConv (config 5, train_G=True).
+    out_pre = d * sum W s x:  dW = (gz*d)^T (s*x shifted)  [a plain GEMM over all pixels, operands built by
+    e4s_shift_scale_f32]  -  W * ((dd*d^3)^T s^2)  [through the demodulation]."""
+    layer = rec["layer"]
+    conv = layer.conv
+    x, s, d, labels = rec["x"], rec["s"], rec["d"], rec["labels"]
+    gz, dd3 = extras["gz"], extras["dd3"]
+    b, ho, wo, cout = gz.shape
+    _, h, w, cin = x.shape
+    gds = K.shift_scale(gz, d, labels, num_regions, (ho, wo))
+    wraw = conv.weight.detach()[0]                                   # [Cout,Cin,3,3]
+    if not conv.upsample:
+        g2 = gds.view(-1, cout)
+        taps = []
+        for ty in range(3):
+            for tx in range(3):
+                xs = K.shift_scale(x, s, labels, num_regions, (h, w), dy=ty - 1, dx=tx - 1)
+                taps.append(g2.t() @ xs.view(-1, cin))
+        dw = torch.stack(taps, -1).view(cout, cin, 3, 3)
+    else:
+        deff = []
+        for ph in range(4):
+            py, px = ph >> 1, ph & 1
+            g2 = gds[:, py::2, px::2].reshape(-1, cout)
+            for e in range(9):
+                xs = K.shift_scale(x, s, labels, num_regions, (h, w), dy=e // 3 - 1, dx=e % 3 - 1, os=2, py=py, px=px)
+                deff.append(g2.t() @ xs.view(-1, cin))
+        deff = torch.stack(deff, 0).view(36, cout * cin)
+        cmap = _polyphase_map(conv.blur.kernel).to(deff.device).view(36, 9)
+        dw = (cmap.t() @ deff).view(9, cout, cin).permute(1, 2, 0).reshape(cout, cin, 3, 3)
+    dw = dw - wraw * (dd3.t() @ (s * s)).view(cout, cin, 1, 1)
+    return dw.unsqueeze(0)
+
+
 class GeneratorFn(torch.autograd.Function):
+    """Fused generator with gradients w.r.t. the latent and (config 5, train_G=True) w.r.t. the generator's
+    trainable parameters, which are passed as extra inputs so that autograd routes their gradients."""
+
     @staticmethod
-    def forward(ctx, gen, latent, mask, noise):
+    def forward(ctx, gen, latent, mask, noise, *params):
         tape = []
         lat = latent.detach().to(torch.float32).contiguous()
         image, feats = gen._fused_forward(lat, mask, noise, tape=tape)
-        ctx.gen, ctx.tape, ctx.lat_shape = gen, tape, tuple(lat.shape)
+        ctx.gen, ctx.tape, ctx.lat = gen, tape, lat
+        ctx.need_lat = latent.requires_grad
+        ctx.pidx = {id(p_): i for i, p_ in enumerate(params)}
         ctx.set_materialize_grads(False)
         return image, feats
 
     @staticmethod
     def backward(ctx, dimage, dfeats):
-        gen, tape = ctx.gen, ctx.tape
-        b, r, nl, _ = ctx.lat_shape
+        gen, tape, lat = ctx.gen, ctx.tape, ctx.lat
+        b, r, nl, _ = lat.shape
         if dimage is None:
             dimage = torch.zeros_like(tape[-1]["out"])
         dev = dimage.device
-        dlat = torch.zeros(ctx.lat_shape, device=dev, dtype=torch.float32)
+        dlat = torch.zeros_like(lat)
+        pgrads = [None] * len(ctx.pidx)
+
+        def want(p_):
+            return id(p_) in ctx.pidx
+
+        def give(p_, g):
+            i = ctx.pidx[id(p_)]
+            pgrads[i] = g if pgrads[i] is None else pgrads[i] + g
+
         dskip = dimage.contiguous().to(torch.float32)
         dact = None                                     # grad w.r.t. the activation feeding the current rgb / next conv
+
+        def style_rows(rec):
+            return lat[:, :, rec["idx"]].reshape(b * r, -1) if rec["masked"] else lat[:, 0, rec["idx"]]
 
         def add_style_grad(rec, ds_total):
             mod = rec["layer"].conv.modulation
@@ -60,6 +133,10 @@ class GeneratorFn(torch.autograd.Function):
                 dlat[:, :, rec["idx"]] += dstyle.view(b, r, -1)
             else:
                 dlat[:, 0, rec["idx"]] += dstyle
+            if want(mod.weight):                                             # s = style @ Wm^T * scale + bias
+                give(mod.weight, (ds_total.t() @ style_rows(rec)) * mod.scale)
+            if want(mod.bias):
+                give(mod.bias, ds_total.sum(0))
 
         for rec in reversed(tape):
             layer = rec["layer"]
@@ -68,6 +145,10 @@ class GeneratorFn(torch.autograd.Function):
                 dact, dws = K.torgb_bwd(dskip, rec["x"], rec["ws"], labels, r, dx_acc=dact)
                 w3 = layer.conv.weight.detach()[0, :, :, 0, 0]                  # [3,Cin]
                 ds = layer.conv.scale * (dws * w3.unsqueeze(0)).sum(1)         # [G,Cin]
+                if want(layer.conv.weight):                                     # ws = scale * w * s
+                    give(layer.conv.weight, (layer.conv.scale * (dws * rec["s"].unsqueeze(1)).sum(0)).view(1, 3, -1, 1, 1))
+                if want(layer.bias):
+                    give(layer.bias, dskip.sum((0, 2, 3)).view(1, 3, 1, 1))
                 add_style_grad(rec, ds)
                 if rec["has_skip"]:                     # Upsample backward = FIR-downsample of the incoming grad
                     k4 = layer.upsample.kernel
@@ -81,9 +162,23 @@ class GeneratorFn(torch.autograd.Function):
             if rec.get("is_feats") and dfeats is not None:
                 df = K.nchw_to_nhwc(dfeats.contiguous())
                 dact = df if dact is None else dact + df
-            dact, ds = styled_conv_backward(rec, dact, r)
+            conv = layer.conv
+            train_w = want(conv.weight)
+            extras = {} if (train_w or want(layer.noise.weight) or want(layer.activate.bias)) else None
+            dact, ds = styled_conv_backward(rec, dact, r, extras)
+            if extras is not None:
+                gz = extras["gz"]
+                if want(layer.activate.bias):
+                    give(layer.activate.bias, gz.sum((0, 1, 2)))
+                if want(layer.noise.weight):
+                    nz = rec["noise"]                                           # [Bn,1,H,W]
+                    give(layer.noise.weight, (gz.sum(-1) * nz[:, 0]).sum().view(1))
+                if train_w:
+                    give(conv.weight, styled_conv_weight_grad(rec, extras, r))
             add_style_grad(rec, ds)
-        return None, dlat, None, None
+        if want(gen.input.input) and dact is not None:
+            give(gen.input.input, dact.sum(0, keepdim=True).permute(0, 3, 1, 2).contiguous())
+        return (None, dlat if ctx.need_lat else None, None, None) + tuple(pgrads)
 
 
 class StyleCodesFn(torch.autograd.Function):

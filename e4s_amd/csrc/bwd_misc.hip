@@ -118,7 +118,52 @@ __global__ void torgb_bwd_x_kernel(const float* __restrict__ drgb, const float* 
     *reinterpret_cast<f32x4*>(dx + i * 4) = o;
 }
 
+// Weight-gradient operands (config 5, train_G=True): the contraction itself is a plain [C1 x P] x [P x C2] GEMM over
+// all pixels and goes to the BLAS; these kernels build its two operands with the region-dependent scales folded in.
+//   out[b, a, c] = tab[(b*R + lab(out pixel of anchor a)) * C + c] * in[b, a*is + (dy, dx), c]     (0 outside the image)
+// anchors a on a [Ha, Wa] grid; out pixel = a*os + (py, px) on the [Ha*os, Wa*os] grid decides the region.
+__global__ void shift_scale_kernel(const float* __restrict__ in, const float* __restrict__ tab,
+                                   const uint8_t* __restrict__ labels, int Hm, int Wm, int R, float* __restrict__ out,
+                                   int B, int Ha, int Wa, int Hi, int Wi, int C, int istride, int dy, int dx, int os,
+                                   int py, int px) {
+    const int C4 = C / 4;
+    const int64_t n = (int64_t)B * Ha * Wa * C4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C4) * 4;
+    int64_t r = i / C4;
+    const int ax = (int)(r % Wa); r /= Wa;
+    const int ay = (int)(r % Ha);
+    const int b = (int)(r / Ha);
+    const int iy = ay * istride + dy, ix = ax * istride + dx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) {
+        v = *reinterpret_cast<const f32x4*>(in + (((int64_t)b * Hi + iy) * Wi + ix) * C + c);
+        if (tab) {
+            int g = b;
+            if (labels) {
+                const int oy = ay * os + py, ox = ax * os + px;
+                g = b * R + labels[((int64_t)b * Hm + nearest_src(oy, Hm, Ha * os)) * Wm + nearest_src(ox, Wm, Wa * os)];
+            }
+            v *= *reinterpret_cast<const f32x4*>(tab + (size_t)g * C + c);
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+}
+
 }  // namespace
+
+extern "C" int e4s_shift_scale_f32(const float* in, const float* tab, const uint8_t* labels, int Hm, int Wm, int R,
+                                   float* out, int B, int Ha, int Wa, int Hi, int Wi, int C, int istride, int dy, int dx,
+                                   int os, int py, int px, void* stream) {
+    if (C % 4) return (int)hipErrorInvalidValue;
+    const int64_t n = (int64_t)B * Ha * Wa * (C / 4);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(shift_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), in, tab,
+                       labels, Hm, Wm, R, out, B, Ha, Wa, Hi, Wi, C, istride, dy, dx, os, py, px);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int e4s_demod_grad_f32(const float* gz, const float* y, const float* noise, const float* noise_w,
                                   int64_t noise_bstride, const float* bias, float alpha, float gain,

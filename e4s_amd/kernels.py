@@ -434,3 +434,16 @@ def torgb_bwd(drgb, x, ws, labels, num_regions, dx_acc=None):
     dx = dx_acc if dx_acc is not None else torch.empty_like(x)
     call("e4s_torgb_bwd_x_f32", fptr(drgb), fptr(ws), ptr(labels), hm, wm, r, fptr(dx), b, h, w, c, acc, stream())
     return dx, dws
+
+
+def shift_scale(x, tab, labels, num_regions, anchors, istride=1, dy=0, dx=0, os=1, py=0, px=0):
+    """out[b,a,c] = tab[group(out pixel of a)][c] * x[b, a*istride + (dy,dx), c] (0 outside); x NHWC."""
+    b, hi, wi, c = x.shape
+    ha, wa = anchors
+    out = torch.empty(b, ha, wa, c, device=x.device, dtype=torch.float32)
+    hm = wm = 0
+    if labels is not None:
+        hm, wm = labels.shape[1:]
+    call("e4s_shift_scale_f32", fptr(x), fptr(tab), ptr(labels), hm, wm, num_regions if labels is not None else 1,
+         fptr(out), b, ha, wa, hi, wi, c, istride, dy, dx, os, py, px, stream())
+    return out

@@ -65,6 +65,7 @@ SIGNATURES = {
     "e4s_demod_grad_f32": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_torgb_bwd_w_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_torgb_bwd_x_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "e4s_shift_scale_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p],
     "e4s_torgb_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_mask_mul_add_f32": [c_p, c_p, c_p] + [c_i] * 10 + [c_p],
     "e4s_noise_bias_act_nhwc_f32": [c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p],

@@ -477,12 +477,12 @@ class Generator(nn.Module):
                 [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
         if torch.is_grad_enabled() and any(n is not None and n.requires_grad for n in noise):
             raise NotImplementedError("gradients w.r.t. the injected noise maps are not implemented")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("weight gradients of the fused generator (config 5, train_G=True) are not "
-                                      "built yet; freeze G (Net3 opts.train_G=False) or use torch.no_grad()")
-        if torch.is_grad_enabled() and latent.requires_grad:
+        params = [p for p in self.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+        if any(p is q for q in self.style.parameters() for p in params) and not input_is_latent:
+            raise NotImplementedError("gradients of the mapping network G.style (always frozen by Net3, networks.py:68-70)")
+        if torch.is_grad_enabled() and (latent.requires_grad or params):
             from .autograd import GeneratorFn
-            image, feats = GeneratorFn.apply(self, latent, mask, noise)
+            image, feats = GeneratorFn.apply(self, latent, mask, noise, *params)
         else:
             image, feats = self._fused_forward(latent, mask, noise)
         return (image, latent, feats) if return_latents else (image, None, feats)
@@ -520,7 +520,7 @@ class Generator(nn.Module):
             rec = {} if tape is not None else None
             out = layer.run_nhwc(x, s, labels if layer.mask_op else None, r, skip, rec=rec)
             if tape is not None:
-                rec.update(kind="rgb", layer=layer, idx=idx, masked=layer.mask_op, x=x, has_skip=skip is not None, out=out,
+                rec.update(kind="rgb", layer=layer, idx=idx, masked=layer.mask_op, x=x, s=s, has_skip=skip is not None, out=out,
                            labels=labels if layer.mask_op else None)
                 tape.append(rec)
             return out

@@ -173,6 +173,13 @@ int e4s_torgb_bwd_w_f32(const float* drgb, const float* x, const uint8_t* labels
 int e4s_torgb_bwd_x_f32(const float* drgb, const float* ws, const uint8_t* labels, int Hm, int Wm, int R,
                         float* dx, int B, int H, int W, int C, int accumulate, void* stream);
 
+/* Weight-gradient operand builder (config 5): out[b,a,c] = tab[(b*R + label(out pixel a*os+(py,px)))*C + c] *
+ * in[b, a*istride + (dy,dx), c], zero outside the image; anchors a on [Ha,Wa].  The [C1 x P] x [P x C2] contraction over
+ * the pixels is a plain GEMM (BLAS).  tab/labels may be NULL (no scaling / group = b). */
+int e4s_shift_scale_f32(const float* in, const float* tab, const uint8_t* labels, int Hm, int Wm, int R,
+                        float* out, int B, int Ha, int Wa, int Hi, int Wi, int C, int istride, int dy, int dx,
+                        int os, int py, int px, void* stream);
+
 /* ---- ToRGB (model.py:422-448) -------------------------------------------------------------- */
 /* out[b,c,y,x] = sum_ci x[b,y,x,ci]*ws[g,c,ci] + bias[c] + upfirdn2d(skip, k4, up=2, pad=(2,1))
  * x NHWC, out/skip NCHW; labels ([B,Hm,Wm] label map) NULL => group = b (unmasked). */

@@ -589,3 +589,45 @@ def test_ops_double_backward_matches_oracle():
     assert abs(float(ld) - float(lr_)) < 1e-3 * abs(float(lr_))
     assert maxabs(xd.grad, xr.grad) < 1e-4 * float(xr.grad.abs().max())
     assert maxabs(bd.grad, br.grad) < 1e-4 * float(br.grad.abs().max())
+
+
+@pytest.mark.parametrize("size,K,cells", [(16, 13, 4), (32, 5, 8)])
+def test_generator_weight_grads_vs_oracle_f64(size, K, cells):
+    """Config 5 (train_G=True): gradients w.r.t. every generator parameter the fused path uses -- conv weights
+    (3x3, polyphase up-convs, ToRGB), modulation weights/biases, noise strengths, activation/RGB biases and the
+    constant input -- against the oracle's fp64 autograd."""
+    from e4s_amd.stylegan2 import Generator
+    sd = _gen_sd(size)
+    gen = Generator(size, 512, 8, split_layer_idx=5, remaining_layer_idx=K)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    for n_, p in gen.named_parameters():
+        p.requires_grad = not n_.startswith("style.")
+    g = torch.Generator().manual_seed(80)
+    b = 2
+    lat = torch.randn(b, 12, gen.n_latent, 512, generator=g) * 0.5
+    mask = synth.onehot(synth.synth_labels_blocks(b, 512, cells, seed=4))
+    noise = synth.synth_noise(size, seed=5, batch=b)
+    w_img = torch.randn(b, 3, size, size, generator=g)
+    img, _, _ = gen([lat.to(DEV)], None, mask.to(DEV), input_is_latent=True, noise=[n.to(DEV) for n in noise])
+    (img * w_img.to(DEV)).sum().backward()
+
+    f64 = torch.float64
+    sd64 = {"G." + k: v.to(f64).requires_grad_(not k.startswith("style.") and v.is_floating_point()
+                                               and not k.endswith("kernel") and not k.startswith("noises."))
+            for k, v in sd.items()}
+    img_r, _ = orc.generator_forward(sd64, lat.to(f64), mask.to(f64), [n.to(f64) for n in noise], size, K)
+    (img_r * w_img.to(f64)).sum().backward()
+    checked = 0
+    for name, p in gen.named_parameters():
+        ref = sd64["G." + name].grad
+        if name.startswith("style."):
+            continue
+        if ref is None or float(ref.abs().max()) == 0.0:          # parameter not on the path of this configuration
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        scale = float(ref.abs().max())
+        assert maxabs(p.grad, ref) < 5e-4 * scale, (name, maxabs(p.grad, ref), scale)
+        checked += 1
+    assert checked >= 20
