@@ -103,9 +103,7 @@ def optimisation_leg(net, one, steps):
 
     def one_step():
         opt.zero_grad()
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            codes = net.cal_style_codes(latent)
+        codes = net.cal_style_codes(latent)
         img, _, _ = net.gen_img(None, codes, tm, randomize_noise=True)
         loss = torch.nn.functional.mse_loss(img, target)
         loss.backward()

@@ -182,21 +182,31 @@ class GeneratorFn(torch.autograd.Function):
 
 
 class StyleCodesFn(torch.autograd.Function):
-    """cal_style_codes (networks.py:135-158) with d/d(style_vectors)."""
+    """cal_style_codes (networks.py:135-158): the two stacked LocalMLP layers on e4s_grouped_linear_f32.
+    Backward w.r.t. the style vectors (config 3) and the stacked weights/biases (config 5); the transposed
+    contractions are plain batched GEMMs (torch.bmm)."""
 
     @staticmethod
     def forward(ctx, style_vectors, w0, b0, w2, b2, add):
         sv = style_vectors.detach().to(torch.float32).contiguous()
-        h = K.grouped_linear(sv, w0, b0, None, 1.0 / math.sqrt(w0.shape[2]), act=1, alpha=0.01)
-        codes = K.grouped_linear(h, w2, b2, add, 1.0 / math.sqrt(w2.shape[2]))
-        ctx.save_for_backward(h, w0, w2)
+        w0d, b0d, w2d, b2d = (t_.detach().contiguous() for t_ in (w0, b0, w2, b2))
+        h = K.grouped_linear(sv, w0d, b0d, None, 1.0 / math.sqrt(w0.shape[2]), act=1, alpha=0.01)
+        codes = K.grouped_linear(h, w2d, b2d, add, 1.0 / math.sqrt(w2.shape[2]))
+        ctx.save_for_backward(sv, h, w0d, w2d)
         return codes
 
     @staticmethod
     def backward(ctx, dcodes):
-        h, w0, w2 = ctx.saved_tensors
+        sv, h, w0, w2 = ctx.saved_tensors
+        s0, s2 = 1.0 / math.sqrt(w0.shape[2]), 1.0 / math.sqrt(w2.shape[2])
         g = dcodes.to(torch.float32).transpose(0, 1).contiguous()                 # [R,B,O]
-        dh = torch.bmm(g, w2) * (1.0 / math.sqrt(w2.shape[2]))                   # [R,B,512]
-        dh = dh * torch.where(h.transpose(0, 1) > 0, 1.0, 0.01)
-        dsv = torch.bmm(dh, w0) * (1.0 / math.sqrt(w0.shape[2]))                 # [R,B,1280]
-        return dsv.transpose(0, 1).contiguous(), None, None, None, None, None
+        hT = h.transpose(0, 1).contiguous()                                      # [R,B,512]
+        dh = torch.bmm(g, w2) * s2                                               # [R,B,512]
+        dh = dh * torch.where(hT > 0, 1.0, 0.01)
+        need = ctx.needs_input_grad
+        dsv = (torch.bmm(dh, w0) * s0).transpose(0, 1).contiguous() if need[0] else None
+        dw0 = torch.bmm(dh.transpose(1, 2), sv.transpose(0, 1)) * s0 if need[1] else None      # [R,512,1280]
+        db0 = dh.sum(1) if need[2] else None
+        dw2 = torch.bmm(g.transpose(1, 2), hT) * s2 if need[3] else None                        # [R,O,512]
+        db2 = g.sum(1) if need[4] else None
+        return dsv, dw0, db0, dw2, db2, None

@@ -100,15 +100,16 @@ class Net3(nn.Module):
         """networks.py:135-158 -> [B,R,n_latent,512]."""
         if not self.opts.start_from_latent_avg or self.opts.learn_in_w:
             raise NotImplementedError("only start_from_latent_avg=True, learn_in_w=False (the shipped configs)")
-        if torch.is_grad_enabled() and style_vectors.requires_grad and not getattr(self, "_warned_mlp_grad", False) \
-                and any(p.requires_grad for m in self.MLPs for p in m.parameters()):
-            import warnings
-            warnings.warn("e4s_amd: gradients flow to the style vectors only (what scripts/optimization.py steps); "
-                          "LocalMLP weight gradients (config 5) are not computed yet")
-            self._warned_mlp_grad = True
         K_ = self.remaining_layer_idx
         nw = K_ if K_ != 17 else 18
-        w0, b0, w2, b2 = self._mlp_weights()
+        if torch.is_grad_enabled() and any(p.requires_grad for m in self.MLPs for p in m.parameters()):
+            # training: stack the live parameters so that autograd routes the stacked gradients back to the 12 MLPs
+            w0 = torch.stack([m.mlp[0].weight for m in self.MLPs])
+            b0 = torch.stack([m.mlp[0].bias for m in self.MLPs])
+            w2 = torch.stack([m.mlp[2].weight for m in self.MLPs])
+            b2 = torch.stack([m.mlp[2].bias for m in self.MLPs])
+        else:
+            w0, b0, w2, b2 = self._mlp_weights()
         b, r, _ = style_vectors.shape
         lat = self.latent_avg.to(device=style_vectors.device, dtype=torch.float32)
         add = lat[:nw].reshape(-1).contiguous()

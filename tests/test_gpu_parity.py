@@ -398,22 +398,26 @@ def test_generator_backward_vs_oracle_autograd(size, K, cells):
 
 
 def test_style_codes_backward_vs_oracle_autograd():
+    """cal_style_codes: gradients w.r.t. the style vectors (config 3) and the LocalMLP weights/biases (config 5)."""
     net = _net(256)
     sd = synth.synth_state_dict(256, 13)
     g = torch.Generator().manual_seed(41)
     sv = torch.randn(2, 12, 1280, generator=g)
     w = torch.randn(2, 12, 14, 512, generator=g)
     sv_d = sv.to(DEV).requires_grad_(True)
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        codes = net.cal_style_codes(sv_d)
+    codes = net.cal_style_codes(sv_d)
     (codes * w.to(DEV)).sum().backward()
+    sd_r = {k: (v.clone().requires_grad_(True) if k.startswith("MLPs.") else v) for k, v in sd.items()}
     sv_r = sv.clone().requires_grad_(True)
-    codes_r = orc.cal_style_codes(sd, sv_r, synth.synth_latent_avg(256), 13)
+    codes_r = orc.cal_style_codes(sd_r, sv_r, synth.synth_latent_avg(256), 13)
     (codes_r * w).sum().backward()
     assert maxabs(codes, codes_r) < 1e-4
     assert maxabs(sv_d.grad, sv_r.grad) < 1e-4 * float(sv_r.grad.abs().max())
+    for i in (0, 5, 11):
+        for j, nm in ((0, "weight"), (0, "bias"), (2, "weight"), (2, "bias")):
+            ref = sd_r[f"MLPs.{i}.mlp.{j}.{nm}"].grad
+            got = getattr(net.MLPs[i].mlp[j], nm).grad
+            assert maxabs(got, ref) < 2e-4 * float(ref.abs().max()), (i, j, nm)
 
 
 def test_optimization_step_runs_and_descends():
@@ -432,9 +436,7 @@ def test_optimization_step_runs_and_descends():
     losses = []
     for _ in range(6):
         opt.zero_grad()
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            codes = net.cal_style_codes(latent)
+        codes = net.cal_style_codes(latent)
         img, _, _ = net.gen_img(None, codes, mask, noise=noise)
         loss = torch.nn.functional.mse_loss(img, target)
         loss.backward()
