@@ -634,6 +634,10 @@ def test_generator_weight_grads_vs_oracle_f64(size, K, cells):
         # <= 3e-4 on most parameters, 6e-4..7e-4 on the deepest ones (conv1, the constant input) at 32^2 -- the same
         # level as the latent gradient, whose pieces are checked tightly in test_styled_conv_backward_vs_oracle_f64
         tol = 2e-3
+        if ref.numel() == 1:
+            # NoiseInjection.weight: one scalar = a sum of ~1e5 signed terms that cancels to ~1e-4 of sum|terms|, so the
+            # fp32 round-off of the incoming gradient shows up amplified (measured 1.1e-2 on convs.0.noise.weight)
+            tol = 5e-2
         assert maxabs(p.grad, ref) < tol * scale, (name, maxabs(p.grad, ref), scale)
         checked += 1
     assert checked >= 20
