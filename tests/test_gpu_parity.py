@@ -475,11 +475,15 @@ def test_styled_conv_backward_vs_oracle_f64(cin, cout, res, up, masked):
     rec = {}
     y = m.run_nhwc(xd, s, noise.to(DEV), labels, r, rec=rec)
     rec.update(layer=m, x=xd, y=y, s=s, labels=labels)
-    dx, ds = styled_conv_backward(rec, K.nchw_to_nhwc(wgt.to(DEV)), r)
+    extras = {}
+    dx, ds = styled_conv_backward(rec, K.nchw_to_nhwc(wgt.to(DEV)), r, extras)
     dstyle = (ds @ mod.weight.detach()) * mod.scale
+    from e4s_amd.autograd import styled_conv_weight_grad
+    dweight = styled_conv_weight_grad(rec, extras, r)
 
     f64 = torch.float64
     sd64 = {k: v.to(f64) for k, v in sd.items()}
+    sd64["conv.weight"].requires_grad_(True)
     xr = x.to(f64).requires_grad_(True)
     sr = style.to(f64).requires_grad_(True)
     yr = orc.styled_conv(sd64, "", xr, sr, mask.to(f64), noise.to(f64), up, masked)
@@ -487,6 +491,8 @@ def test_styled_conv_backward_vs_oracle_f64(cin, cout, res, up, masked):
     assert maxabs(K.nhwc_to_nchw(y), yr) < 5e-5
     assert maxabs(K.nhwc_to_nchw(dx), xr.grad) < 1e-4 * float(xr.grad.abs().max())
     assert maxabs(dstyle.view_as(sr), sr.grad) < 2e-4 * float(sr.grad.abs().max())
+    wref = sd64["conv.weight"].grad
+    assert maxabs(dweight, wref) < 2e-4 * float(wref.abs().max()), (maxabs(dweight, wref), float(wref.abs().max()))
 
 
 @pytest.mark.parametrize("cin,res,masked,with_skip", [(512, 8, True, True), (128, 32, False, True), (512, 4, True, False),
