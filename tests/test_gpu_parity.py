@@ -449,7 +449,7 @@ def test_optimization_step_runs_and_descends():
 @pytest.mark.parametrize("cin,cout,res,up,masked", [(64, 64, 16, False, True), (64, 64, 16, True, True),
                                                      (128, 64, 32, False, False), (64, 64, 24, True, False),
                                                      (512, 512, 8, False, True), (32, 32, 32, False, False),
-                                                     (64, 32, 16, True, False)])
+                                                     (64, 32, 16, True, False), (512, 512, 32, False, False)])
 def test_styled_conv_backward_vs_oracle_f64(cin, cout, res, up, masked):
     """One fused StyledConv: dL/dx (per-pixel, tight) and dL/dstyle against the oracle's fp64 autograd."""
     from e4s_amd import kernels as K
