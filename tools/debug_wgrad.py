@@ -48,3 +48,25 @@ img_r, _ = orc.generator_forward(sd64, lat.to(f64), mask.to(f64), [n.to(f64) for
 ref_full = sd64["G.convs.5.conv.weight"].grad
 print("layer-level ref vs full ref:", float((ref_layer - ref_full).abs().max()))
 print("mine vs full ref:", float((mine - ref_full).abs().max()), "img parity", float((img.cpu().double() - img_r).abs().max()))
+# ---- step-by-step oracle to expose x5 / y5 / dy5
+sdd = {"G." + k: v.to(f64) for k, v in sd.items()}
+L = lat.to(f64); M = mask.to(f64); N = [n.to(f64) for n in noise]
+p = "G."
+x = sdd[p + "input.input"].repeat(b, 1, 1, 1)
+x = orc.styled_conv(sdd, p + "conv1.", x, L[:, :, 0], M, N[0], False, True)
+skip = orc.to_rgb(sdd, p + "to_rgb1.", x, L[:, :, 1], M, None, True)
+x = orc.styled_conv(sdd, p + "convs.0.", x, L[:, :, 1], M, N[1], True, True)
+x = orc.styled_conv(sdd, p + "convs.1.", x, L[:, :, 2], M, N[2], False, True)
+skip = orc.to_rgb(sdd, p + "to_rgbs.0.", x, L[:, :, 3], M, skip, True)
+x = orc.styled_conv(sdd, p + "convs.2.", x, L[:, :, 3], M, N[3], True, True)
+x = orc.styled_conv(sdd, p + "convs.3.", x, L[:, :, 4], M, N[4], False, True)
+skip = orc.to_rgb(sdd, p + "to_rgbs.1.", x, L[:, 0, 5], M, skip, False)
+x4 = orc.styled_conv(sdd, p + "convs.4.", x, L[:, 0, 5], M, N[5], True, False)
+x4 = x4.detach().requires_grad_(True)
+y5 = orc.styled_conv(sdd, p + "convs.5.", x4, L[:, 0, 6], M, N[6], False, False)
+y5.retain_grad()
+img2 = orc.to_rgb(sdd, p + "to_rgbs.2.", y5, L[:, 0, 7], M, skip.detach(), False)
+(img2 * w_img.to(f64)).sum().backward()
+print("img2 vs img_r", float((img2 - img_r).abs().max()))
+print("x5: mine vs oracle", float((K.nhwc_to_nchw(rec["x"]).cpu().double() - x4).abs().max()), float(x4.abs().max()))
+print("dy5: mine vs oracle", float((dy - y5.grad).abs().max()), float(y5.grad.abs().max()))
