@@ -626,7 +626,7 @@ def test_generator_weight_grads_vs_oracle_f64(size, K, cells):
             for k, v in sd.items()}
     img_r, _ = orc.generator_forward(sd64, lat.to(f64), mask.to(f64), [n.to(f64) for n in noise], size, K)
     (img_r * w_img.to(f64)).sum().backward()
-    checked = 0
+    checked, bad = 0, []
     for name, p in gen.named_parameters():
         ref = sd64["G." + name].grad
         if name.startswith("style."):
@@ -636,14 +636,26 @@ def test_generator_weight_grads_vs_oracle_f64(size, K, cells):
             continue
         assert p.grad is not None, name
         scale = float(ref.abs().max())
-        # fp32 accumulation through the whole backward chain (atomics make the order vary run to run): measured
-        # <= 3e-4 on most parameters, 6e-4..7e-4 on the deepest ones (conv1, the constant input) at 32^2 -- the same
-        # level as the latent gradient, whose pieces are checked tightly in test_styled_conv_backward_vs_oracle_f64
-        tol = 2e-3
+        got = p.grad.detach().cpu().double()
+        rel_l2 = float((got - ref).norm() / ref.norm())
+        # Two error sources, bounded separately.
+        # (1) fp32 accumulation through the whole backward chain (atomics make the order vary run to run): measured
+        #     <= 3e-4 on most parameters, 6e-4..7e-4 on the deepest ones (conv1, the constant input) at 32^2 -> the
+        #     relative L2 error stays under 2e-3.
+        # (2) LeakyReLU gate flips: the fp32 forward and the fp64 oracle disagree on sign(y) for the handful of
+        #     activations with |y| < ~1e-5 (about one in the 1M of a 32^2 layer).  A flipped element changes that pixel's
+        #     contribution by a factor 5, and with only b*H*W = 2048 pixels in the weight-gradient sum one pixel is
+        #     worth up to ~1e-2 of max|dW| (tools/debug_wgrad.py: same x and dy -> HIP dW equals fp64 dW to 2e-6,
+        #     while fp64 dW from the fp64 forward differs by 4.3e-3 of 0.80 on convs.5.conv.weight).  So the max-abs
+        #     bound is looser than the L2 bound, which averages the flips out.
+        tol_l2, tol_max = 2e-3, 1e-2
         if ref.numel() == 1:
             # NoiseInjection.weight: one scalar = a sum of ~1e5 signed terms that cancels to ~1e-4 of sum|terms|, so the
             # fp32 round-off of the incoming gradient shows up amplified (measured 1.1e-2 on convs.0.noise.weight)
-            tol = 5e-2
-        assert maxabs(p.grad, ref) < tol * scale, (name, maxabs(p.grad, ref), scale)
+            tol_l2 = tol_max = 5e-2
+        err = maxabs(p.grad, ref)
+        if not (rel_l2 < tol_l2 and err < tol_max * scale):
+            bad.append((name, rel_l2, err, scale))
         checked += 1
+    assert not bad, bad
     assert checked >= 20
