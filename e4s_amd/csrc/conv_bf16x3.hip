@@ -1,0 +1,292 @@
+// 3x3 stride-1 convolution on the gfx950 bf16 matrix cores at fp32-class accuracy ("bf16x3"):
+// every fp32 operand is split into two bf16 halves, v = hi + lo (hi = rne_bf16(v), lo = rne_bf16(v - hi); the
+// residual is < 2^-17 |v|), and a product is evaluated as  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  in three
+// v_mfma_f32_32x32x16_bf16 with an fp32 accumulator: relative error per product <= ~2^-16, i.e. ~1e-5 on a 4608-term
+// contraction -- inside the path's 1e-3 bound with an order of magnitude to spare -- at 3 bf16 MFMAs (3 x 32 cycles per
+// 32x32x16) instead of 8 fp32 MFMAs (8 x 64 cycles) for the same 32x32x16 block: 5.3x the fp32-MFMA rate.
+//
+// Scope: the natural-order (halo-tiled) 3x3 stride-1 contraction with at most ONE style per sample -- the encoder's
+// Conv2d+PReLU (helpers.py:128-137; ~70 % of the MACs of a face swap) and the generator's unmasked StyledConvs
+// (model.py:655-657).  Masked layers need the style of the OUTPUT pixel's region on the A fragment and stay on
+// e4s_conv_mfma_f32.
+//
+// Block = 256 threads = 4 waves, tile 256 pixels (16x16) x 128 output channels; each wave owns 128 x 64 = 4 x 2 MFMA
+// blocks (128 accumulator registers).  K step = one tap x 32 input channels.
+// LDS (132 KB, one block per CU):
+//   * A: the (16+2)x(16+2) halo of the CURRENT 32-channel chunk, already split, one 144-byte row per halo pixel
+//        [32 hi bf16 | 32 lo bf16 | 16 pad]; the 9 taps are 9 shifted views of it.  Double buffered: while chunk c is
+//        being contracted, 1/9 of chunk c+1's halo is fetched, split and stored per tap stage, so every stage has the
+//        same small load/convert/store footprint and no extra barrier.
+//   * B: weights pre-split on the host side of the ABI (e4s_split_bf16x2_f32) in the same 128-byte row format, so
+//        the B stage is a straight 16-byte copy global -> VGPR -> LDS, double buffered.
+// The 144-byte row stride makes the ds_read_b128 fragment reads (lane -> row, lane half -> +16 B) conflict free, the
+// same argument as conv_mfma.hip.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int NTHR = 256;
+constexpr int KC = 32;                 // input channels per stage
+constexpr int ROWB = 144;              // LDS row bytes
+constexpr int LO = 64;                 // byte offset of the lo half inside a row
+constexpr int BM = 256, BN = 128;
+constexpr int TH = 16, TW = 16, HALO_W = TW + 2, HALO = (TH + 2) * HALO_W;     // 324 halo pixels
+constexpr int WN = 2, TM = 4, TN = 2;                                          // 2 x 2 waves, 4 x 2 blocks each
+constexpr int ITEMS = HALO * 4;        // (halo pixel, 8-channel group) work items of one chunk = 1296
+constexpr int PIECE = ITEMS / 9;       // items fetched per tap stage = 144
+constexpr int A_BYTES = HALO * ROWB, B_BYTES = BN * ROWB;
+constexpr int SMEM_BYTES = 2 * A_BYTES + 2 * B_BYTES + BM * 8;
+static_assert(PIECE * 9 == ITEMS && PIECE <= NTHR, "halo split");
+
+__device__ __forceinline__ void split_store(unsigned char* dst, const f32x8 v) {
+    const bf16x8 h = __builtin_convertvector(v, bf16x8);
+    const f32x8 r = v - __builtin_convertvector(h, f32x8);
+    const bf16x8 l = __builtin_convertvector(r, bf16x8);
+    *reinterpret_cast<bf16x8*>(dst) = h;
+    *reinterpret_cast<bf16x8*>(dst + LO) = l;
+}
+
+template <bool SCALED>
+__global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params p, const int ntn, const int tx_n,
+                                                           const int per_img) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                          // [2][HALO][ROWB]
+    unsigned char* sB = smem + 2 * A_BYTES;            // [2][BN][ROWB]
+    int* s_out = reinterpret_cast<int*>(sB + 2 * B_BYTES);
+    float* s_nz = reinterpret_cast<float*>(s_out + BM);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = logical / ntn, nt = logical - mt * ntn;
+    const int n0 = nt * BN;
+    const int tb = mt / per_img;
+    const int rem = mt - tb * per_img;
+    const int tyb = rem / tx_n, txb = rem - tyb * tx_n;
+
+    // ---- per-row metadata: output offset and noise term of each of the 256 pixels ----
+    {
+        const int ay = tyb * TH + tid / TW, ax = txb * TW + tid % TW;
+        const bool valid = ay < p.Ha && ax < p.Wa;
+        s_out[tid] = valid ? (tb * p.Ho + ay) * p.Wo + ax : -1;
+        float nz = 0.f;
+        if (valid && p.noise) nz = p.noise_w[0] * p.noise[(int64_t)tb * p.noise_bstride + (int64_t)ay * p.Wo + ax];
+        s_nz[tid] = nz;
+    }
+
+    const int nchunk = p.Cin / KC, nstage = nchunk * 9;
+    const float* xb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin;
+    const float* sc = SCALED ? p.in_scale + (size_t)tb * p.Cin : nullptr;
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(p.w);
+    const size_t wrow = (size_t)p.Cin * 4;             // bytes per (tap, cout) row of the split weights
+
+    // halo item -> (global offset in floats or -1, LDS byte offset)
+    auto item_src = [&](int item, bool& ok) -> size_t {
+        const int h = item >> 2, q = item & 3;
+        const int hy = h / HALO_W, hx = h - hy * HALO_W;
+        const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
+        ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        return ok ? ((size_t)iy * p.Wi + ix) * p.Cin + q * 8 : (size_t)(q * 8);
+    };
+    auto item_dst = [&](int item) -> int { return (item >> 2) * ROWB + (item & 3) * 16; };
+    auto load8 = [&](const float* src) -> f32x8 {
+        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+        return f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    };
+
+    // ---- prologue: whole halo of chunk 0 + weights of stage 0 ----
+    for (int item = tid; item < ITEMS; item += NTHR) {
+        bool ok;
+        const size_t off = item_src(item, ok);
+        f32x8 v = load8(xb + off);
+        if (SCALED) v *= load8(sc + (item & 3) * 8);
+        if (!ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        split_store(sA + item_dst(item), v);
+    }
+    const int bq = (tid & 7) * 16, br0 = tid >> 3;       // B staging role: 16-byte piece bq of rows br0 + 32 j
+    f32x4 pb[4];
+    {
+        const unsigned char* wp = wbytes + (size_t)n0 * wrow + bq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + 32 * j) * wrow);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(sB + (br0 + 32 * j) * ROWB + bq) = pb[j];
+    }
+    __syncthreads();
+
+    // ---- fragment addressing ----
+    int arow[TM], brow[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = (wm * TM + tm) * 32 + li;
+        arow[tm] = ((m / TW) * HALO_W + (m % TW)) * ROWB + kh * 16;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) brow[tn] = ((wn * TN + tn) * 32 + li) * ROWB + kh * 16;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    // my halo piece of the next chunk: the same (pixel, channel group) at every tap index, chunk after chunk
+    const bool piece_thr = tid < PIECE;
+
+    int tap = 0, chunk = 0;
+    for (int s = 0; s < nstage; ++s) {
+        // -- global -> VGPR for stage s+1 (branch-free: dummy in-bounds addresses, selects at the LDS store) --
+        int tap1 = tap + 1, chunk1 = chunk;
+        if (tap1 == 9) { tap1 = 0; chunk1 = chunk + 1; }
+        const bool more = (s + 1 < nstage);
+        const int tapw = more ? tap1 : 0, chw = more ? chunk1 : 0;
+        {
+            const unsigned char* wp = wbytes + ((size_t)tapw * p.Cout + n0) * wrow + (size_t)chw * 128 + bq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + 32 * j) * wrow);
+        }
+        const bool have_next = (chunk + 1 < nchunk);
+        const int item = tap * PIECE + (piece_thr ? tid : 0);
+        bool ok;
+        const size_t off = item_src(item, ok);
+        const int cnext = have_next ? (chunk + 1) * KC : 0;
+        f32x8 pa = load8(xb + off + cnext);
+        f32x8 ps;
+        if (SCALED) ps = load8(sc + cnext + (item & 3) * 8);
+
+        // -- MFMAs of stage s --
+        {
+            const unsigned char* Ab = sA + (chunk & 1) * A_BYTES + ((tap / 3) * HALO_W + (tap % 3)) * ROWB;
+            const unsigned char* Bb = sB + (s & 1) * B_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 bh[TN], bl[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    bh[tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32);
+                    bl[tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32 + LO);
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32 + LO);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[tn], acc[tm][tn], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // -- VGPR -> LDS for stage s+1 --
+        if (more) {
+            unsigned char* db = sB + ((s + 1) & 1) * B_BYTES + br0 * ROWB + bq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(db + 32 * j * ROWB) = pb[j];
+        }
+        if (have_next && piece_thr) {
+            if (SCALED) pa *= ps;
+            if (!ok) pa = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            split_store(sA + ((chunk + 1) & 1) * A_BYTES + item_dst(item), pa);
+        }
+        __syncthreads();
+        tap = tap1; chunk = chunk1;
+    }
+
+    // ---- epilogue: demod * acc + noise + bias, activation, NHWC store ----
+    float osc[TN], bsv[TN], slp[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + (wn * TN + tn) * 32 + li;
+        osc[tn] = p.out_scale ? p.out_scale[(size_t)tb * p.Cout + col] : 1.f;
+        bsv[tn] = p.bias ? p.bias[col] : 0.f;
+        slp[tn] = (p.act == 2) ? p.slope[col] : p.alpha;
+    }
+    const float gain = (p.act == 1) ? p.gain : 1.f;
+    const bool do_act = p.act != 0;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int off = s_out[row];
+            if (off < 0) continue;
+            const float nz = s_nz[row];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                float v = acc[tm][tn][r] * osc[tn] + nz + bsv[tn];
+                if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
+                p.y[(size_t)off * p.Cout + n0 + (wn * TN + tn) * 32 + li] = v;
+            }
+        }
+    }
+}
+
+// fp32 rows [rows][cin] -> split rows [rows][cin/32][hi x32 | lo x32] (bf16), same byte size
+__global__ void split_bf16x2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int64_t n8,
+                                    int cin) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 8-channel group
+    if (i >= n8) return;
+    const int g8 = cin / 8;
+    const int64_t row = i / g8;
+    const int c = (int)(i - row * g8) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w + row * cin + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(w + row * cin + c + 4);
+    const f32x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const bf16x8 h = __builtin_convertvector(v, bf16x8);
+    const f32x8 r = v - __builtin_convertvector(h, f32x8);
+    const bf16x8 l = __builtin_convertvector(r, bf16x8);
+    unsigned short* d = out + row * (int64_t)cin * 2 + (c / 32) * 64 + (c % 32);
+    *reinterpret_cast<bf16x8*>(d) = h;
+    *reinterpret_cast<bf16x8*>(d + 32) = l;
+}
+
+template <bool SCALED>
+int launch(const e4s_conv_params& p, hipStream_t st) {
+    auto kern = conv_bf16x3_kernel<SCALED>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int ntn = p.Cout / BN;
+    const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + TH - 1) / TH) * tx_n;
+    const int64_t blocks = (int64_t)p.B * per_img * ntn;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM_BYTES, st, p, ntn, tx_n, per_img);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
+    const e4s_conv_params& p = *pp;
+    if (p.Cin % KC || p.Cout % BN || p.ntaps != 9 || p.ncls != 1 || p.istride != 1 || p.ostride != 1 || p.tiles ||
+        p.labels || p.noise_per_channel || p.Ha != p.Hi || p.Wa != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi)
+        return (int)hipErrorInvalidValue;
+    return p.in_scale ? launch<true>(p, as_stream(stream)) : launch<false>(p, as_stream(stream));
+}
+
+extern "C" int e4s_split_bf16x2_f32(const float* w, void* out, int64_t rows, int cin, void* stream) {
+    if (cin % 32) return (int)hipErrorInvalidValue;
+    const int64_t n8 = rows * (cin / 8);
+    if (n8 <= 0) return 0;
+    hipLaunchKernelGGL(split_bf16x2_kernel, dim3(cdiv(n8, 256)), dim3(256), 0, as_stream(stream), w,
+                       reinterpret_cast<unsigned short*>(out), n8, cin);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}

@@ -36,6 +36,17 @@ def _pack3x3(conv):
     return conv._e4s_pack[1]
 
 
+def _conv3x3(x, conv, cout, **kw):
+    """Stride-1 3x3 conv (+ fused epilogue) in the configured arithmetic: the split-bf16 kernel where it applies and
+    K.PRECISION asks for it, the exact fp32-MFMA kernel otherwise."""
+    w = _pack3x3(conv)
+    if K.PRECISION == "bf16x3" and K.bf16x3_eligible(x.shape[-1], cout):
+        if getattr(conv, "_e4s_split", None) is None or conv._e4s_split[0] != conv._e4s_pack[0]:
+            conv._e4s_split = (conv._e4s_pack[0], K.split_bf16x2(w))
+        return K.conv_mfma(x, w, cout, w_split=conv._e4s_split[1], **kw)
+    return K.conv_mfma(x, w, cout, **kw)
+
+
 class SEModule(Module):
     """helpers.py:56-72 (parameter holder; evaluated by e4s_se_gate_f32)."""
 
@@ -71,8 +82,11 @@ class bottleneck_IR_SE_Ours(Module):
         conv1, prelu, conv2, se = self.res_layer[1], self.res_layer[2], self.res_layer[3], self.res_layer[5]
         st_x, _ = K.instnorm_stats(x)
         xn = K.instnorm_apply(x, st_x)
-        r = K.conv_mfma(xn, _pack3x3(conv1), self.depth, act=2, slope=prelu.weight)
-        r = K.conv_mfma(r, _pack3x3(conv2), self.depth, istride=self.stride)
+        r = _conv3x3(xn, conv1, self.depth, act=2, slope=prelu.weight)
+        if self.stride == 1:
+            r = _conv3x3(r, conv2, self.depth)
+        else:
+            r = K.conv_mfma(r, _pack3x3(conv2), self.depth, istride=self.stride)
         st_r, pooled = K.instnorm_stats(r, want_pooled=True)
         gate = K.se_gate(pooled, se.fc1.weight.view(se.fc1.weight.shape[0], -1),
                          se.fc2.weight.view(se.fc2.weight.shape[0], -1))

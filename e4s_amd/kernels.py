@@ -6,6 +6,7 @@ here computes anything in torch; a missing library or a CPU tensor raises.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -13,6 +14,12 @@ from . import lib
 from .lib import ConvBwdParams, ConvParams, c_p, call, fptr, ptr, stream
 
 BM = 128          # GEMM row tile of e4s_conv_mfma_f32
+# Arithmetic of the contractions that have a split-bf16 kernel (encoder convs, unmasked StyledConvs):
+#   "f32"    exact fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32)
+#   "bf16x3" three bf16 MFMAs per product on hi/lo-split operands (fp32 accumulate, ~2^-16 per product)
+PRECISION = os.environ.get("E4S_PRECISION", "f32")
+if PRECISION not in ("f32", "bf16x3"):
+    raise RuntimeError(f"E4S_PRECISION must be f32 or bf16x3, got {PRECISION!r}")
 LRELU_GAIN = math.sqrt(2.0)
 
 
@@ -197,10 +204,12 @@ def region_plan(labels, num_regions, ha, wa, nphase):
 # ---- the conv --------------------------------------------------------------------------------
 def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, in_scale=None, out_scale=None,
               noise=None, noise_w=None, noise_per_channel=False, bias=None, slope=None, act=0, alpha=0.2,
-              gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1):
+              gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1, w_split=None):
     """x NHWC [B,Hi,Wi,Cin]; w [ncls, ntaps, Cout, Cin] -> y NHWC [B,Ho,Wo,Cout].
     anchors = (Ha, Wa); defaults: up-conv (ncls=4) anchors = input grid, output 2x;
-    strided conv anchors = output grid."""
+    strided conv anchors = output grid.
+    w_split: the split-bf16 image of w (split_bf16x2); when given the contraction runs on e4s_conv_bf16x3_f32
+    (callers check bf16x3_eligible first -- an ineligible shape is an error, not a silent fp32 run)."""
     b, hi, wi, cin = x.shape
     if anchors is None:
         anchors = (hi // istride, wi // istride)
@@ -241,8 +250,31 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
         p.noise_per_channel = 0
     p.bias, p.slope = fptr(bias), fptr(slope)
     p.act, p.alpha, p.gain = act, alpha, gain
-    call("e4s_conv_mfma_f32", ctypes.byref(p), 1 if spatial else 0, stream())
+    if w_split is not None:
+        if not bf16x3_eligible(cin, cout, istride=istride, ostride=ostride, ntaps=ntaps, ncls=ncls,
+                               masked=labels is not None) or not spatial or noise_per_channel:
+            raise RuntimeError("e4s_conv_bf16x3_f32 does not cover this contraction")
+        p.w = fptr(w_split)
+        call("e4s_conv_bf16x3_f32", ctypes.byref(p), stream())
+    else:
+        call("e4s_conv_mfma_f32", ctypes.byref(p), 1 if spatial else 0, stream())
     return y
+
+
+def bf16x3_eligible(cin, cout, *, istride=1, ostride=1, ntaps=9, ncls=1, masked=False):
+    """Shapes e4s_conv_bf16x3_f32 covers (include/e4s_hip.h)."""
+    return (cin % 32 == 0 and cout % 128 == 0 and istride == 1 and ostride == 1 and ntaps == 9 and ncls == 1
+            and not masked)
+
+
+def split_bf16x2(w):
+    """fp32 [..., Cin] -> its split-bf16 image (hi|lo per 32-channel chunk), returned as an opaque fp32-typed tensor of
+    the same shape/byte size (only e4s_conv_bf16x3_f32 reads it)."""
+    w = _f32(w)
+    out = torch.empty_like(w)
+    cin = w.shape[-1]
+    call("e4s_split_bf16x2_f32", fptr(w), ptr(out), w.numel() // cin, cin, stream())
+    return out
 
 
 def upconv_mfma(x, w3, cout, k4, *, in_scale=None, out_scale=None, labels=None, num_regions=1, noise=None,

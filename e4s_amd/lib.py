@@ -59,6 +59,8 @@ SIGNATURES = {
     "e4s_region_plan": [c_p] + [c_i] * 8 + [c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "e4s_conv_mfma_f32": [ctypes.POINTER(ConvParams), c_i, c_p],
     "e4s_upconv_mfma_f32": [ctypes.POINTER(ConvParams), c_p, c_p],
+    "e4s_conv_bf16x3_f32": [ctypes.POINTER(ConvParams), c_p],
+    "e4s_split_bf16x2_f32": [c_p, c_p, c_l, c_i, c_p],
     "e4s_upconv_blocks_per_cu": [],
     "e4s_conv_bwd_mfma_f32": [ctypes.POINTER(ConvBwdParams), c_p],
     "e4s_pack_taps_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_p],

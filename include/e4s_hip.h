@@ -141,6 +141,17 @@ int e4s_conv_mfma_f32(const e4s_conv_params* p, int spatial, void* stream);
 int e4s_upconv_mfma_f32(const e4s_conv_params* p, const float* k4, void* stream);
 int e4s_upconv_blocks_per_cu(void);    /* diagnostic: occupancy of that kernel as the runtime computes it */
 
+/* Split-bf16 ("bf16x3") variant of the natural-order 3x3 stride-1 contraction: every fp32 operand v = hi + lo (two bf16),
+ * product = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with an fp32 accumulator (relative error per
+ * product <= ~2^-16; 5.3x the fp32-MFMA rate).  Same params struct and epilogue as e4s_conv_mfma_f32(spatial = 1) with:
+ * ntaps = 9, ncls = 1, istride = ostride = 1, labels = NULL (at most one style per sample: in_scale/out_scale are
+ * [B][C]), noise_per_channel = 0, Cin % 32 == 0, Cout % 128 == 0, and p->w pointing at the SPLIT weights produced by
+ * e4s_split_bf16x2_f32 from the [9][Cout][Cin] tap-packed fp32 weights.  Used for the encoder's Conv2d(+PReLU)
+ * (helpers.py:128-137) and the unmasked StyledConvs (model.py:655-657). */
+int e4s_conv_bf16x3_f32(const e4s_conv_params* p, void* stream);
+/* w fp32 [rows][cin] -> out [rows][cin/32][32 hi bf16 | 32 lo bf16] (same byte size), cin % 32 == 0 */
+int e4s_split_bf16x2_f32(const float* w, void* out, int64_t rows, int cin, void* stream);
+
 /* ---- backward of the fused generator (configs 3 and 5) -------------------- */
 typedef struct {
     const float* gz;         /* dL/d(out_pre), NHWC [B, Hy, Wy, Cy]  (Cy = forward Cout) */

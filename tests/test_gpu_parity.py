@@ -121,6 +121,48 @@ def test_conv_mfma_1x1_stride2_and_prelu():
     assert maxabs(K.nhwc_to_nchw(y), F.prelu(F.conv2d(x, w3, padding=1), slope)) < 2e-5
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,full", [
+    (2, 32, 32, 64, 128, False), (1, 16, 16, 512, 512, True), (2, 8, 8, 128, 256, False),     # 8x8: partial 16x16 tile
+    (1, 20, 40, 96, 128, True), (3, 4, 4, 32, 128, False),                                    # ragged tiles
+])
+def test_conv_bf16x3_vs_conv2d_f64(b, h, w, cin, cout, full):
+    """Split-bf16 contraction (3 bf16 MFMAs per product, fp32 accumulate) against an fp64 convolution.  Error model:
+    <= ~2^-16 per product, random sign -> ~1e-5 of the output scale; bound 1e-4 of max|y| (the exact fp32-MFMA kernel
+    measures ~1e-6 on the same inputs).  `full` adds the whole epilogue: per-sample style on the input, demodulation,
+    noise, bias and leaky-ReLU."""
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(b, cin, h, w, generator=g, dtype=torch.float64) * 1.3 + 0.2
+    wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) / math.sqrt(cin * 9)
+    wp = _pack(wt.float()).to(DEV)
+    ws = K.split_bf16x2(wp)
+    xd = K.nchw_to_nhwc(x.float().to(DEV))
+    if not full:
+        want = F.conv2d(x.float().double(), wt.float().double(), padding=1)
+        y = K.conv_mfma(xd, wp, cout, w_split=ws)
+    else:
+        s = torch.rand(b, cin, generator=g) + 0.5
+        d = torch.rand(b, cout, generator=g) + 0.5
+        nz = torch.randn(b, 1, h, w, generator=g)
+        nw = torch.tensor([0.3])
+        bias = torch.randn(cout, generator=g) * 0.1
+        pre = F.conv2d(x.float().double() * s.double()[:, :, None, None], wt.float().double(), padding=1)
+        pre = pre * d.double()[:, :, None, None] + 0.3 * nz.double() + bias.double()[None, :, None, None]
+        want = F.leaky_relu(pre, 0.2) * math.sqrt(2.0)
+        y = K.conv_mfma(xd, wp, cout, w_split=ws, in_scale=s.to(DEV), out_scale=d.to(DEV), noise=nz.to(DEV),
+                        noise_w=nw.to(DEV), bias=bias.to(DEV), act=1)
+    err = maxabs(K.nhwc_to_nchw(y), want)
+    assert err < 1e-4 * float(want.abs().max()), (err, float(want.abs().max()))
+
+
+def test_bf16x3_rejects_shapes_it_does_not_cover():
+    from e4s_amd import kernels as K
+    x = torch.zeros(1, 16, 16, 64, device=DEV)
+    w = torch.zeros(1, 9, 64, 64, device=DEV)
+    with pytest.raises(RuntimeError):
+        K.conv_mfma(x, w, 64, w_split=K.split_bf16x2(w))                 # Cout % 128 != 0
+
+
 # ---------------------------------------------------------------------------------------------
 # generator layers against the oracle
 # ---------------------------------------------------------------------------------------------
@@ -307,6 +349,31 @@ def test_net1024_swap_vs_golden(golden):
     assert maxabs(img[:, :, c0:c0 + 128, c0:c0 + 128], g["img_crop"]) < 1e-3
     assert maxabs(img.mean((2, 3)), g["img_mean"]) < 1e-4
     assert maxabs(img.abs().mean((2, 3)), g["img_absmean"]) < 1e-4
+
+
+@torch.no_grad()
+def test_net1024_swap_vs_golden_bf16x3(golden, monkeypatch):
+    """The same 1024^2 swap with the encoder's stride-1 convs on the split-bf16 kernel (E4S_PRECISION=bf16x3): the
+    north-star bound of 1e-3 against the real reference's output must still hold."""
+    from e4s_amd import kernels as K
+    from e4s_amd.networks import face_swap_core
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    g = golden("net1024.pt")
+    net = _net(1024)
+    driven, target, dm, tm, sm = _swap_inputs("face")
+    noise = [n.to(DEV) for n in synth.synth_noise(1024)]
+    sv, _ = net.get_style_vectors(driven.to(DEV), dm.to(DEV))
+    monkeypatch.setattr(K, "PRECISION", "f32")
+    sv32, _ = net.get_style_vectors(driven.to(DEV), dm.to(DEV))
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    sv_err = maxabs(sv, sv32)
+    assert 0.0 < sv_err < 2e-4, sv_err                      # > 0: the split-bf16 kernel really ran
+    img = face_swap_core(net, driven.to(DEV), dm.to(DEV), target.to(DEV), tm.to(DEV), sm.to(DEV), noise=noise)
+    e1 = maxabs(img[:, :, ::8, ::8], g["img_stride8"])
+    c0 = 512 - 64
+    e2 = maxabs(img[:, :, c0:c0 + 128, c0:c0 + 128], g["img_crop"])
+    print(f"bf16x3: style-vector delta vs fp32 path {sv_err:.3e}; image max-abs vs reference {max(e1, e2):.3e}")
+    assert e1 < 1e-3 and e2 < 1e-3, (e1, e2)
 
 
 @torch.no_grad()
