@@ -36,10 +36,11 @@ constexpr int BM = 256, BN = 128;
 constexpr int TH = 16, TW = 16, HALO_W = TW + 2, HALO = (TH + 2) * HALO_W;     // 324 halo pixels
 constexpr int WN = 2, TM = 4, TN = 2;                                          // 2 x 2 waves, 4 x 2 blocks each
 constexpr int ITEMS = HALO * 4;        // (halo pixel, 8-channel group) work items of one chunk = 1296
-constexpr int PIECE = ITEMS / 9;       // items fetched per tap stage = 144
+constexpr int NPIECE = 8;               // the next chunk's halo is fetched during taps 0..7, stored during taps 1..8
+constexpr int PIECE = ITEMS / NPIECE;  // items per piece = 162
 constexpr int A_BYTES = HALO * ROWB, B_BYTES = BN * ROWB;
 constexpr int SMEM_BYTES = 2 * A_BYTES + 2 * B_BYTES + BM * 8;
-static_assert(PIECE * 9 == ITEMS && PIECE <= NTHR, "halo split");
+static_assert(PIECE * NPIECE == ITEMS && PIECE <= NTHR, "halo split");
 
 __device__ __forceinline__ void split_store(unsigned char* dst, const f32x8 v) {
     const bf16x8 h = __builtin_convertvector(v, bf16x8);
@@ -139,29 +140,49 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    // my halo piece of the next chunk: the same (pixel, channel group) at every tap index, chunk after chunk
-    const bool piece_thr = tid < PIECE;
-
-    int tap = 0, chunk = 0;
-    for (int s = 0; s < nstage; ++s) {
-        // -- global -> VGPR for stage s+1 (branch-free: dummy in-bounds addresses, selects at the LDS store) --
-        int tap1 = tap + 1, chunk1 = chunk;
-        if (tap1 == 9) { tap1 = 0; chunk1 = chunk + 1; }
-        const bool more = (s + 1 < nstage);
-        const int tapw = more ? tap1 : 0, chw = more ? chunk1 : 0;
-        {
-            const unsigned char* wp = wbytes + ((size_t)tapw * p.Cout + n0) * wrow + (size_t)chw * 128 + bq;
+    // ---- software pipeline, one stage of delay between a global load and its LDS store: everything stage s+1 needs
+    // (weights of stage s+1; piece tap-1 of the next chunk's halo) was requested during stage s-1 and is written to
+    // LDS at the end of stage s, so a load has a full stage of MFMAs (~1500 cycles) to land before anything waits on
+    // it.  Two register sets alternate (L = being loaded, S = being stored); loads are unconditional with dummy
+    // in-bounds addresses so that the waits stay counted.
+    struct Pref {
+        f32x4 b[4];
+        f32x8 a, s;
+        int dst;
+        bool part, ok;     // part: this thread holds a halo item of a real next chunk; ok: the item is inside the image
+    };
+    Pref P0, P1;
+    P1.part = P1.ok = false;
+    P1.dst = 0;
+    {   // weights of stage 1 (tap 1, chunk 0) -> P1
+        const unsigned char* wp = wbytes + ((size_t)1 * p.Cout + n0) * wrow + bq;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + 32 * j) * wrow);
+        for (int j = 0; j < 4; ++j) P1.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + 32 * j) * wrow);
+    }
+    const bool piece_thr = tid < PIECE;
+    int tap = 0, chunk = 0;          // stage s
+    int t2 = 2, c2 = 0;              // stage s + 2
+
+    auto stage = [&](Pref& L, Pref& S, const int s) {
+        // -- global -> VGPR: weights of stage s+2, halo piece `tap` of chunk+1 --
+        {
+            const bool more2 = (s + 2 < nstage);
+            const unsigned char* wp =
+                wbytes + ((size_t)(more2 ? t2 : 0) * p.Cout + n0) * wrow + (size_t)(more2 ? c2 : 0) * 128 + bq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) L.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + 32 * j) * wrow);
+            const bool doA = (tap < NPIECE) && (chunk + 1 < nchunk);
+            const int item = min(tap, NPIECE - 1) * PIECE + (piece_thr ? tid : 0);
+            bool ok;
+            const size_t off = item_src(item, ok);
+            const int cnext = doA ? (chunk + 1) * KC : 0;
+            L.a = load8(xb + off + cnext);
+            if (SCALED) L.s = load8(sc + cnext + (item & 3) * 8);
+            L.ok = ok;
+            L.part = doA && piece_thr;
+            L.dst = item_dst(item);
         }
-        const bool have_next = (chunk + 1 < nchunk);
-        const int item = tap * PIECE + (piece_thr ? tid : 0);
-        bool ok;
-        const size_t off = item_src(item, ok);
-        const int cnext = have_next ? (chunk + 1) * KC : 0;
-        f32x8 pa = load8(xb + off + cnext);
-        f32x8 ps;
-        if (SCALED) ps = load8(sc + cnext + (item & 3) * 8);
+        __builtin_amdgcn_sched_barrier(0);      // keep the requests above the MFMAs
 
         // -- MFMAs of stage s --
         {
@@ -189,19 +210,25 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
             }
         }
 
-        // -- VGPR -> LDS for stage s+1 --
-        if (more) {
+        // -- VGPR -> LDS: what was requested one stage ago --
+        if (s + 1 < nstage) {
             unsigned char* db = sB + ((s + 1) & 1) * B_BYTES + br0 * ROWB + bq;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(db + 32 * j * ROWB) = pb[j];
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(db + 32 * j * ROWB) = S.b[j];
         }
-        if (have_next && piece_thr) {
-            if (SCALED) pa *= ps;
-            if (!ok) pa = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            split_store(sA + ((chunk + 1) & 1) * A_BYTES + item_dst(item), pa);
+        if (S.part) {
+            f32x8 v = S.a;
+            if (SCALED) v *= S.s;
+            if (!S.ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            split_store(sA + ((chunk + 1) & 1) * A_BYTES + S.dst, v);
         }
         __syncthreads();
-        tap = tap1; chunk = chunk1;
+        if (++tap == 9) { tap = 0; ++chunk; }
+        if (++t2 == 9) { t2 = 0; ++c2; }
+    };
+    for (int s = 0; s < nstage; s += 2) {
+        stage(P0, P1, s);
+        if (s + 1 < nstage) stage(P1, P0, s + 1);
     }
 
     // ---- epilogue: demod * acc + noise + bias, activation, NHWC store ----
