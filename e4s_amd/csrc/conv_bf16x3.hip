@@ -164,6 +164,29 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
     int t2 = 2, c2 = 0;              // stage s + 2
 
     auto stage = [&](Pref& L, Pref& S, const int s) {
+        const unsigned char* Ab = sA + (chunk & 1) * A_BYTES + ((tap / 3) * HALO_W + (tap % 3)) * ROWB;
+        const unsigned char* Bb = sB + (s & 1) * B_BYTES;
+        // One wave per SIMD: nothing else hides an LDS round trip (~120 cycles), so the fragment reads are software
+        // pipelined by hand -- the A fragments of MFMA group g+1 are requested before the 6 MFMAs (192 cycles) of group
+        // g are issued -- and the order is pinned with sched_barriers (left alone, the scheduler sinks each read to
+        // just before its first use and the matrix pipe idles ~90 cycles per group).
+        bf16x8 bh[2][TN], bl[2][TN], ah[2], al[2];
+        auto ldB = [&](int kk) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                bh[kk][tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32);
+                bl[kk][tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32 + LO);
+            }
+        };
+        auto ldA = [&](int g, int slot) {          // group g = (kk, tm)
+            const int kk = g / TM, tm = g % TM;
+            ah[slot] = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32);
+            al[slot] = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32 + LO);
+        };
+        ldB(0);
+        ldA(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+
         // -- global -> VGPR: weights of stage s+2, halo piece `tap` of chunk+1 --
         {
             const bool more2 = (s + 2 < nstage);
@@ -182,32 +205,24 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
             L.part = doA && piece_thr;
             L.dst = item_dst(item);
         }
-        __builtin_amdgcn_sched_barrier(0);      // keep the requests above the MFMAs
+        ldB(1);
+        __builtin_amdgcn_sched_barrier(0);
 
-        // -- MFMAs of stage s --
-        {
-            const unsigned char* Ab = sA + (chunk & 1) * A_BYTES + ((tap / 3) * HALO_W + (tap % 3)) * ROWB;
-            const unsigned char* Bb = sB + (s & 1) * B_BYTES;
+        // -- MFMAs of stage s: 8 groups of 6 --
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 bh[TN], bl[TN];
+        for (int g = 0; g < 2 * TM; ++g) {
+            const int kk = g / TM, tm = g % TM, cur = g & 1;
+            if (g + 1 < 2 * TM) ldA(g + 1, cur ^ 1);
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    bh[tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32);
-                    bl[tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32 + LO);
-                }
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32 + LO);
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[kk][tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[tn], acc[tm][tn], 0, 0, 0);
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[tn], acc[tm][tn], 0, 0, 0);
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[tn], acc[tm][tn], 0, 0, 0);
-                    }
-                }
-            }
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // -- VGPR -> LDS: what was requested one stage ago --
