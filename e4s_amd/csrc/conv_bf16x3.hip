@@ -22,6 +22,7 @@
 // The 144-byte row stride makes the ds_read_b128 fragment reads (lane -> row, lane half -> +16 B) conflict free, the
 // same argument as conv_mfma.hip.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -50,7 +51,9 @@ __device__ __forceinline__ void split_store(unsigned char* dst, const f32x8 v) {
     *reinterpret_cast<bf16x8*>(dst + LO) = l;
 }
 
-template <bool SCALED>
+// ABL: profiling ablations (env E4S_BF16X3_ABL; results are wrong for ABL != 0): 1 no MFMAs, 2 no fragment reads,
+// 3 no global loads / LDS stores in the loop, 4 MFMAs only (no barrier either)
+template <bool SCALED, int ABL>
 __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params p, const int ntn, const int tx_n,
                                                            const int per_img) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -183,12 +186,21 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
             ah[slot] = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32);
             al[slot] = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32 + LO);
         };
-        ldB(0);
-        ldA(0, 0);
+        if (ABL == 2 || ABL == 4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = al[i] = *reinterpret_cast<const bf16x8*>(sA + arow[0]);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bh[i][tn] = bl[i][tn] = ah[i];
+            }
+        } else {
+            ldB(0);
+            ldA(0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
 
         // -- global -> VGPR: weights of stage s+2, halo piece `tap` of chunk+1 --
-        {
+        if (ABL < 3) {
             const bool more2 = (s + 2 < nstage);
             const unsigned char* wp =
                 wbytes + ((size_t)(more2 ? t2 : 0) * p.Cout + n0) * wrow + (size_t)(more2 ? c2 : 0) * 128 + bq;
@@ -205,14 +217,19 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
             L.part = doA && piece_thr;
             L.dst = item_dst(item);
         }
-        ldB(1);
+        if (ABL != 2 && ABL != 4) ldB(1);
         __builtin_amdgcn_sched_barrier(0);
 
         // -- MFMAs of stage s: 8 groups of 6 --
 #pragma unroll
         for (int g = 0; g < 2 * TM; ++g) {
             const int kk = g / TM, tm = g % TM, cur = g & 1;
-            if (g + 1 < 2 * TM) ldA(g + 1, cur ^ 1);
+            if (g + 1 < 2 * TM && ABL != 2 && ABL != 4) ldA(g + 1, cur ^ 1);
+            if (ABL == 1) {
+                acc[tm][0][0] += (float)ah[cur][0] + (float)al[cur][1] + (float)bh[kk][0][0] + (float)bl[kk][1][1];
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
@@ -226,18 +243,18 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
         }
 
         // -- VGPR -> LDS: what was requested one stage ago --
-        if (s + 1 < nstage) {
+        if (ABL < 3 && s + 1 < nstage) {
             unsigned char* db = sB + ((s + 1) & 1) * B_BYTES + br0 * ROWB + bq;
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(db + 32 * j * ROWB) = S.b[j];
         }
-        if (S.part) {
+        if (ABL < 3 && S.part) {
             f32x8 v = S.a;
             if (SCALED) v *= S.s;
             if (!S.ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             split_store(sA + ((chunk + 1) & 1) * A_BYTES + S.dst, v);
         }
-        __syncthreads();
+        if (ABL != 4) __syncthreads();
         if (++tap == 9) { tap = 0; ++chunk; }
         if (++t2 == 9) { t2 = 0; ++c2; }
     };
@@ -294,9 +311,9 @@ __global__ void split_bf16x2_kernel(const float* __restrict__ w, unsigned short*
     *reinterpret_cast<bf16x8*>(d + 32) = l;
 }
 
-template <bool SCALED>
+template <bool SCALED, int ABL = 0>
 int launch(const e4s_conv_params& p, hipStream_t st) {
-    auto kern = conv_bf16x3_kernel<SCALED>;
+    auto kern = conv_bf16x3_kernel<SCALED, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -320,7 +337,16 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     if (p.Cin % KC || p.Cout % BN || p.ntaps != 9 || p.ncls != 1 || p.istride != 1 || p.ostride != 1 || p.tiles ||
         p.labels || p.noise_per_channel || p.Ha != p.Hi || p.Wa != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi)
         return (int)hipErrorInvalidValue;
-    return p.in_scale ? launch<true>(p, as_stream(stream)) : launch<false>(p, as_stream(stream));
+    static const int abl = [] { const char* e = getenv("E4S_BF16X3_ABL"); return e ? atoi(e) : 0; }();
+    hipStream_t st = as_stream(stream);
+    switch (abl) {
+        case 1: return launch<false, 1>(p, st);
+        case 2: return launch<false, 2>(p, st);
+        case 3: return launch<false, 3>(p, st);
+        case 4: return launch<false, 4>(p, st);
+        default: break;
+    }
+    return p.in_scale ? launch<true>(p, st) : launch<false>(p, st);
 }
 
 extern "C" int e4s_split_bf16x2_f32(const float* w, void* out, int64_t rows, int cin, void* stream) {
