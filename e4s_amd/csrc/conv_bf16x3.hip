@@ -37,8 +37,8 @@ constexpr int BM = 256, BN = 128;
 constexpr int TH = 16, TW = 16, HALO_W = TW + 2, HALO = (TH + 2) * HALO_W;     // 324 halo pixels
 constexpr int WN = 2, TM = 4, TN = 2;                                          // 2 x 2 waves, 4 x 2 blocks each
 constexpr int ITEMS = HALO * 4;        // (halo pixel, 8-channel group) work items of one chunk = 1296
-constexpr int NPIECE = 8;               // the next chunk's halo is fetched during taps 0..7, stored during taps 1..8
-constexpr int PIECE = ITEMS / NPIECE;  // items per piece = 162
+constexpr int NPIECE = 9;               // the next chunk's halo is fetched and stored in 9 pieces, one per tap stage
+constexpr int PIECE = ITEMS / NPIECE;  // items per piece = 144
 constexpr int A_BYTES = HALO * ROWB, B_BYTES = BN * ROWB;
 constexpr int SMEM_BYTES = 2 * A_BYTES + 2 * B_BYTES + BM * 8;
 static_assert(PIECE * NPIECE == ITEMS && PIECE <= NTHR, "halo split");
@@ -143,28 +143,20 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    // ---- software pipeline, one stage of delay between a global load and its LDS store: everything stage s+1 needs
-    // (weights of stage s+1; piece tap-1 of the next chunk's halo) was requested during stage s-1 and is written to
-    // LDS at the end of stage s, so a load has a full stage of MFMAs (~1500 cycles) to land before anything waits on
-    // it.  Two register sets alternate (L = being loaded, S = being stored); loads are unconditional with dummy
-    // in-bounds addresses so that the waits stay counted.
+    // ---- stage loop: LDS holds stage s; the global loads of stage s+1 (weights; one piece of the next chunk's halo) are
+    // issued right after the first fragment reads, fly during the 48 MFMAs (~1500 cycles) and are written to the other
+    // LDS buffers at the end of the stage.  Loads are unconditional with dummy in-bounds addresses so that the waits
+    // stay counted.  (A two-register-set variant with the stores delayed by one more stage measured slower: the
+    // unrolled loop made the compiler shuttle the 128 accumulators between AGPRs and VGPRs every iteration.)
     struct Pref {
         f32x4 b[4];
         f32x8 a, s;
         int dst;
         bool part, ok;     // part: this thread holds a halo item of a real next chunk; ok: the item is inside the image
     };
-    Pref P0, P1;
-    P1.part = P1.ok = false;
-    P1.dst = 0;
-    {   // weights of stage 1 (tap 1, chunk 0) -> P1
-        const unsigned char* wp = wbytes + ((size_t)1 * p.Cout + n0) * wrow + bq;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) P1.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + 32 * j) * wrow);
-    }
     const bool piece_thr = tid < PIECE;
     int tap = 0, chunk = 0;          // stage s
-    int t2 = 2, c2 = 0;              // stage s + 2
+    int t2 = 1, c2 = 0;              // stage s + 1
 
     auto stage = [&](Pref& L, Pref& S, const int s) {
         const unsigned char* Ab = sA + (chunk & 1) * A_BYTES + ((tap / 3) * HALO_W + (tap % 3)) * ROWB;
@@ -199,9 +191,9 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
         }
         __builtin_amdgcn_sched_barrier(0);
 
-        // -- global -> VGPR: weights of stage s+2, halo piece `tap` of chunk+1 --
+        // -- global -> VGPR: weights of stage s+1, halo piece `tap` of chunk+1 --
         if (ABL < 3) {
-            const bool more2 = (s + 2 < nstage);
+            const bool more2 = (s + 1 < nstage);
             const unsigned char* wp =
                 wbytes + ((size_t)(more2 ? t2 : 0) * p.Cout + n0) * wrow + (size_t)(more2 ? c2 : 0) * 128 + bq;
 #pragma unroll
@@ -242,7 +234,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        // -- VGPR -> LDS: what was requested one stage ago --
+        // -- VGPR -> LDS --
         if (ABL < 3 && s + 1 < nstage) {
             unsigned char* db = sB + ((s + 1) & 1) * B_BYTES + br0 * ROWB + bq;
 #pragma unroll
@@ -258,10 +250,8 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
         if (++tap == 9) { tap = 0; ++chunk; }
         if (++t2 == 9) { t2 = 0; ++c2; }
     };
-    for (int s = 0; s < nstage; s += 2) {
-        stage(P0, P1, s);
-        if (s + 1 < nstage) stage(P1, P0, s + 1);
-    }
+    Pref P;
+    for (int s = 0; s < nstage; ++s) stage(P, P, s);
 
     // ---- epilogue: demod * acc + noise + bias, activation, NHWC store ----
     float osc[TN], bsv[TN], slp[TN];
