@@ -10,8 +10,11 @@
 // (model.py:655-657).  Masked layers need the style of the OUTPUT pixel's region on the A fragment and stay on
 // e4s_conv_mfma_f32.
 //
-// Block = 256 threads = 4 waves, tile 256 pixels (16x16) x 128 output channels; each wave owns 128 x 64 = 4 x 2 MFMA
-// blocks (128 accumulator registers).  K step = one tap x 32 input channels.
+// Block = 512 threads = 8 waves, tile 256 pixels (16x16) x 128 output channels; each wave owns 64 x 64 = 2 x 2 MFMA
+// blocks (64 accumulator registers), so two waves share a SIMD and one wave's address arithmetic, bf16 conversion, LDS
+// traffic and barrier waits run under the other's MFMAs (a 4-wave / 128x64-per-wave variant left the matrix pipe idle
+// ~45 % of the time: with one wave per SIMD every non-MFMA instruction is serial overhead).  K step = one tap x 32
+// input channels.
 // LDS (132 KB, one block per CU):
 //   * A: the (16+2)x(16+2) halo of the CURRENT 32-channel chunk, already split, one 144-byte row per halo pixel
 //        [32 hi bf16 | 32 lo bf16 | 16 pad]; the 9 taps are 9 shifted views of it.  Double buffered: while chunk c is
@@ -29,13 +32,14 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-constexpr int NTHR = 256;
+constexpr int NTHR = 512;
 constexpr int KC = 32;                 // input channels per stage
 constexpr int ROWB = 144;              // LDS row bytes
 constexpr int LO = 64;                 // byte offset of the lo half inside a row
 constexpr int BM = 256, BN = 128;
 constexpr int TH = 16, TW = 16, HALO_W = TW + 2, HALO = (TH + 2) * HALO_W;     // 324 halo pixels
-constexpr int WN = 2, TM = 4, TN = 2;                                          // 2 x 2 waves, 4 x 2 blocks each
+constexpr int WN = 2, TM = 2, TN = 2;                                          // 4 x 2 waves, 2 x 2 blocks (64x64) each
+constexpr int BSTEP = NTHR / 8, BJ = BN / BSTEP;                               // B staging: rows br0 + BSTEP*j, j < BJ
 constexpr int ITEMS = HALO * 4;        // (halo pixel, 8-channel group) work items of one chunk = 1296
 constexpr int NPIECE = 9;               // the next chunk's halo is fetched and stored in 9 pieces, one per tap stage
 constexpr int PIECE = ITEMS / NPIECE;  // items per piece = 144
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
     const int tyb = rem / tx_n, txb = rem - tyb * tx_n;
 
     // ---- per-row metadata: output offset and noise term of each of the 256 pixels ----
-    {
+    if (tid < BM) {
         const int ay = tyb * TH + tid / TW, ax = txb * TW + tid % TW;
         const bool valid = ay < p.Ha && ax < p.Wa;
         s_out[tid] = valid ? (tb * p.Ho + ay) * p.Wo + ax : -1;
@@ -114,14 +118,14 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
         if (!ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         split_store(sA + item_dst(item), v);
     }
-    const int bq = (tid & 7) * 16, br0 = tid >> 3;       // B staging role: 16-byte piece bq of rows br0 + 32 j
-    f32x4 pb[4];
+    const int bq = (tid & 7) * 16, br0 = tid >> 3;       // B staging role: 16-byte piece bq of rows br0 + BSTEP j
+    f32x4 pb[BJ];
     {
         const unsigned char* wp = wbytes + (size_t)n0 * wrow + bq;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + 32 * j) * wrow);
+        for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(sB + (br0 + 32 * j) * ROWB + bq) = pb[j];
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(sB + (br0 + BSTEP * j) * ROWB + bq) = pb[j];
     }
     __syncthreads();
 
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
     // stay counted.  (A two-register-set variant with the stores delayed by one more stage measured slower: the
     // unrolled loop made the compiler shuttle the 128 accumulators between AGPRs and VGPRs every iteration.)
     struct Pref {
-        f32x4 b[4];
+        f32x4 b[BJ];
         f32x8 a, s;
         int dst;
         bool part, ok;     // part: this thread holds a halo item of a real next chunk; ok: the item is inside the image
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
             const unsigned char* wp =
                 wbytes + ((size_t)(more2 ? t2 : 0) * p.Cout + n0) * wrow + (size_t)(more2 ? c2 : 0) * 128 + bq;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) L.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + 32 * j) * wrow);
+            for (int j = 0; j < BJ; ++j) L.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
             const bool doA = (tap < NPIECE) && (chunk + 1 < nchunk);
             const int item = min(tap, NPIECE - 1) * PIECE + (piece_thr ? tid : 0);
             bool ok;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
         if (ABL < 3 && s + 1 < nstage) {
             unsigned char* db = sB + ((s + 1) & 1) * B_BYTES + br0 * ROWB + bq;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(db + 32 * j * ROWB) = S.b[j];
+            for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(db + BSTEP * j * ROWB) = S.b[j];
         }
         if (ABL < 3 && S.part) {
             f32x8 v = S.a;
