@@ -40,7 +40,7 @@ def _conv3x3(x, conv, cout, **kw):
     """Stride-1 3x3 conv (+ fused epilogue) in the configured arithmetic: the split-bf16 kernel where it applies and
     K.PRECISION asks for it, the exact fp32-MFMA kernel otherwise."""
     w = _pack3x3(conv)
-    if K.PRECISION == "bf16x3" and K.bf16x3_eligible(x.shape[-1], cout):
+    if K.want_bf16x3(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout):
         if getattr(conv, "_e4s_split", None) is None or conv._e4s_split[0] != conv._e4s_pack[0]:
             conv._e4s_split = (conv._e4s_pack[0], K.split_bf16x2(w))
         return K.conv_mfma(x, w, cout, w_split=conv._e4s_split[1], **kw)

@@ -14,12 +14,16 @@ from . import lib
 from .lib import ConvBwdParams, ConvParams, c_p, call, fptr, ptr, stream
 
 BM = 128          # GEMM row tile of e4s_conv_mfma_f32
-# Arithmetic of the contractions that have a split-bf16 kernel (encoder convs, unmasked StyledConvs):
+# Arithmetic of the contractions that have a split-bf16 kernel (the encoder's stride-1 3x3 convs):
 #   "f32"    exact fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32)
-#   "bf16x3" three bf16 MFMAs per product on hi/lo-split operands (fp32 accumulate, ~2^-16 per product)
-PRECISION = os.environ.get("E4S_PRECISION", "f32")
-if PRECISION not in ("f32", "bf16x3"):
-    raise RuntimeError(f"E4S_PRECISION must be f32 or bf16x3, got {PRECISION!r}")
+#   "bf16x3" three bf16 MFMAs per product on hi/lo-split fp32 operands, fp32 accumulate (~2^-16 per product; measured
+#            1.6e-4 max-abs on the 1024^2 image against the reference, bound 1e-3), wherever the kernel applies
+#   "auto"   (default) bf16x3 where it applies AND the launch fills the chip (its 256x128 tiles need >= BF16X3_MIN_BLOCKS
+#            blocks to beat the fp32 kernel's 128-row tiles: batch-1 latency runs stay on fp32)
+PRECISION = os.environ.get("E4S_PRECISION", "auto")
+if PRECISION not in ("f32", "bf16x3", "auto"):
+    raise RuntimeError(f"E4S_PRECISION must be f32, bf16x3 or auto, got {PRECISION!r}")
+BF16X3_MIN_BLOCKS = 128
 LRELU_GAIN = math.sqrt(2.0)
 
 
@@ -265,6 +269,15 @@ def bf16x3_eligible(cin, cout, *, istride=1, ostride=1, ntaps=9, ncls=1, masked=
     """Shapes e4s_conv_bf16x3_f32 covers (include/e4s_hip.h)."""
     return (cin % 32 == 0 and cout % 128 == 0 and istride == 1 and ostride == 1 and ntaps == 9 and ncls == 1
             and not masked)
+
+
+def want_bf16x3(b, h, w, cin, cout):
+    """Policy of PRECISION for a stride-1 3x3 conv on [b,h,w,cin] -> cout."""
+    if PRECISION == "f32" or not bf16x3_eligible(cin, cout):
+        return False
+    if PRECISION == "bf16x3":
+        return True
+    return b * ((h + 15) // 16) * ((w + 15) // 16) * (cout // 128) >= BF16X3_MIN_BLOCKS
 
 
 def split_bf16x2(w):
