@@ -286,6 +286,282 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Region-select variant: masked StyledConvs (model.py:386-400) and the polyphase up-conv (ncls = 4).
+// The style that scales an A element belongs to the OUTPUT pixel's region, and neighbouring taps pair one halo pixel
+// with output pixels of different regions, so the halo cannot be scaled and split once when it is staged.  Here the
+// halo stays fp32 in LDS; each wave multiplies its A fragment by the style fragment s[region(row)][k] (held in
+// registers for the 9 taps of a chunk) and splits the product into hi/lo bf16 on its way into the MFMAs: 32 VALU per
+// 6 MFMAs, which the second wave of the SIMD overlaps.  Weights arrive pre-split as in the kernel above; the
+// demodulation table d[region][co] is applied in the epilogue.
+constexpr int MAXR = 16;
+constexpr int XITEMS = ITEMS + MAXR * 4;           // + the chunk's style slice s[r][32]: 16 regions x 4 groups of 8
+constexpr int XPIECE = (XITEMS + 8) / 9;           // 152 items per tap stage
+constexpr int S_BYTES = MAXR * ROWB;
+constexpr int S_OFF = 2 * A_BYTES + 2 * B_BYTES;
+constexpr int SMEM_REGION = S_OFF + 2 * S_BYTES + BM * 12;
+static_assert(XPIECE * 9 >= XITEMS && XPIECE <= NTHR, "extended halo split");
+
+__global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv_params p, const int ntn,
+                                                                  const int tx_n, const int per_img,
+                                                                  const int tiles_per_cls) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                          // [2][HALO][ROWB]  fp32 x, 32 channels per row
+    unsigned char* sB = smem + 2 * A_BYTES;            // [2][BN][ROWB]    split weights
+    int* s_out = reinterpret_cast<int*>(smem + S_OFF + 2 * S_BYTES);
+    float* s_nz = reinterpret_cast<float*>(s_out + BM);
+    int* s_grp = reinterpret_cast<int*>(s_nz + BM);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = logical / ntn, nt = logical - mt * ntn;
+    const int n0 = nt * BN;
+    const int cls = mt / tiles_per_cls;
+    const int tt = mt - cls * tiles_per_cls;
+    const int tb = tt / per_img;
+    const int rem = tt - tb * per_img;
+    const int tyb = rem / tx_n, txb = rem - tyb * tx_n;
+    const int py = (p.ncls == 4) ? (cls >> 1) : 0, px = (p.ncls == 4) ? (cls & 1) : 0;
+    const int R = p.labels ? p.groups_per_batch : 1;
+
+    if (tid < BM) {
+        const int ay = tyb * TH + tid / TW, ax = txb * TW + tid % TW;
+        const bool valid = ay < p.Ha && ax < p.Wa;
+        const int oy = ay * p.ostride + py, ox = ax * p.ostride + px;
+        s_out[tid] = valid ? (tb * p.Ho + oy) * p.Wo + ox : -1;
+        float nz = 0.f;
+        int r = 0;
+        if (valid) {
+            if (p.noise) nz = p.noise_w[0] * p.noise[(int64_t)tb * p.noise_bstride + (int64_t)oy * p.Wo + ox];
+            if (p.labels) {   // legacy-nearest lookup of the OUTPUT pixel (F.interpolate 'nearest', model.py:391)
+                const int sy = min((int)floorf((float)oy * ((float)p.Hm / (float)p.Ho)), p.Hm - 1);
+                const int sx = min((int)floorf((float)ox * ((float)p.Wm / (float)p.Wo)), p.Wm - 1);
+                r = p.labels[((size_t)tb * p.Hm + sy) * p.Wm + sx];
+            }
+        }
+        s_nz[tid] = nz;
+        s_grp[tid] = r;
+    }
+
+    const int nchunk = p.Cin / KC, nstage = nchunk * 9;
+    const float* xb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin;
+    const float* stab = p.in_scale + (size_t)tb * R * p.Cin;
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(p.w) + (size_t)cls * 9 * p.Cout * p.Cin * 4;
+    const size_t wrow = (size_t)p.Cin * 4;
+
+    // work item -> global source (floats from xb / stab; dummy in-bounds when !ok), LDS byte offset inside buffer 0
+    struct Item {
+        const float* src;
+        int dst, bufstride;
+        bool ok;
+    };
+    auto item_of = [&](int item) -> Item {
+        Item it;
+        if (item < ITEMS) {
+            const int h = item >> 2, q = item & 3;
+            const int hy = h / HALO_W, hx = h - hy * HALO_W;
+            const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
+            it.ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            it.src = xb + (it.ok ? ((size_t)iy * p.Wi + ix) * p.Cin : 0) + q * 8;
+            it.dst = h * ROWB + q * 32;
+            it.bufstride = A_BYTES;
+        } else {
+            const int idx = item - ITEMS, r = idx >> 2, q = idx & 3;
+            it.ok = r < R && item < XITEMS;
+            it.src = stab + (it.ok ? (size_t)r * p.Cin : 0) + q * 8;
+            it.dst = S_OFF + (r & (MAXR - 1)) * ROWB + q * 32;
+            it.bufstride = S_BYTES;
+        }
+        return it;
+    };
+    auto load8 = [&](const float* src) -> f32x8 {
+        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+        return f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    };
+    auto store8 = [&](unsigned char* dst, const f32x8 v) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(dst + 16) = f32x4{v[4], v[5], v[6], v[7]};
+    };
+
+    // ---- prologue: halo + style slice of chunk 0, weights of stage 0 ----
+    for (int item = tid; item < XPIECE * 9; item += NTHR) {
+        const Item it = item_of(item);
+        f32x8 v = load8(it.src);
+        if (!it.ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (item < XITEMS) store8(smem + it.dst, v);
+    }
+    const int bq = (tid & 7) * 16, br0 = tid >> 3;
+    {
+        const unsigned char* wp = wbytes + (size_t)n0 * wrow + bq;
+        f32x4 pb[BJ];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(sB + (br0 + BSTEP * j) * ROWB + bq) = pb[j];
+    }
+    __syncthreads();
+
+    int arow[TM], srow[TM], brow[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = (wm * TM + tm) * 32 + li;
+        arow[tm] = ((m / TW) * HALO_W + (m % TW)) * ROWB + kh * 32;
+        srow[tm] = S_OFF + s_grp[m] * ROWB + kh * 32;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) brow[tn] = ((wn * TN + tn) * 32 + li) * ROWB + kh * 16;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    f32x8 sv[TM][2];                 // style fragments of the current chunk: s[region(row)][kk*16 + kh*8 .. +7]
+    const bool piece_thr = tid < XPIECE;
+    int tap = 0, chunk = 0, t1 = 1, c1 = 0;
+
+    for (int s = 0; s < nstage; ++s) {
+        const unsigned char* Ab = sA + (chunk & 1) * A_BYTES + ((tap / 3) * HALO_W + (tap % 3)) * ROWB;
+        const unsigned char* Bb = sB + (s & 1) * B_BYTES;
+        auto ldraw = [&](int g) -> f32x8 {            // group g = (kk, tm): 8 fp32 of the lane's pixel
+            const int kk = g / TM, tm = g % TM;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + arow[tm] + kk * 64);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + arow[tm] + kk * 64 + 16);
+            return f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        };
+        if (tap == 0) {
+            const unsigned char* Sb = smem + (chunk & 1) * S_BYTES;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(Sb + srow[tm] + kk * 64);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(Sb + srow[tm] + kk * 64 + 16);
+                    sv[tm][kk] = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                }
+        }
+        bf16x8 bh[2][TN], bl[2][TN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                bh[kk][tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32);
+                bl[kk][tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32 + LO);
+            }
+        f32x8 raw = ldraw(0);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // -- global -> VGPR: weights of stage s+1, one piece of chunk+1's halo / style slice --
+        f32x4 pb[BJ];
+        const bool more = (s + 1 < nstage);
+        {
+            const unsigned char* wp =
+                wbytes + ((size_t)(more ? t1 : 0) * p.Cout + n0) * wrow + (size_t)(more ? c1 : 0) * 128 + bq;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
+        }
+        const bool have_next = (chunk + 1 < nchunk);
+        const int item = tap * XPIECE + (piece_thr ? tid : 0);
+        const Item it = item_of(item);
+        f32x8 pa = load8(it.src + (have_next ? (chunk + 1) * KC : 0));
+        __builtin_amdgcn_sched_barrier(0);
+
+        // -- 4 groups of 6 MFMAs; the next group's fp32 fragment is requested before the current one is converted --
+#pragma unroll
+        for (int g = 0; g < 2 * TM; ++g) {
+            const int kk = g / TM, tm = g % TM;
+            const f32x8 v = raw * sv[tm][kk];
+            if (g + 1 < 2 * TM) raw = ldraw(g + 1);
+            const bf16x8 ah = __builtin_convertvector(v, bf16x8);
+            const f32x8 res = v - __builtin_convertvector(ah, f32x8);
+            const bf16x8 al = __builtin_convertvector(res, bf16x8);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kk][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kk][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kk][tn], acc[tm][tn], 0, 0, 0);
+        }
+
+        // -- VGPR -> LDS --
+        if (more) {
+            unsigned char* db = sB + ((s + 1) & 1) * B_BYTES + br0 * ROWB + bq;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(db + BSTEP * j * ROWB) = pb[j];
+        }
+        if (have_next && piece_thr && item < XITEMS) {
+            if (!it.ok) pa = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            store8(smem + ((chunk + 1) & 1) * it.bufstride + it.dst, pa);
+        }
+        __syncthreads();
+        if (++tap == 9) { tap = 0; ++chunk; }
+        if (++t1 == 9) { t1 = 0; ++c1; }
+    }
+
+    // ---- epilogue: d[region][co] * acc + noise + bias, activation, NHWC store ----
+    float* sD = reinterpret_cast<float*>(sA);          // [R][BN]; the loop's last barrier has passed
+    if (p.out_scale) {
+        for (int t = tid; t < R * BN; t += NTHR) {
+            const int r = t / BN, n = t - r * BN;
+            sD[t] = p.out_scale[((size_t)tb * R + r) * p.Cout + n0 + n];
+        }
+        __syncthreads();
+    }
+    float bsv[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bsv[tn] = p.bias ? p.bias[n0 + (wn * TN + tn) * 32 + li] : 0.f;
+    const float gain = (p.act == 1) ? p.gain : 1.f;
+    const bool do_act = p.act != 0, scaled = p.out_scale != nullptr;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int off = s_out[row];
+            if (off < 0) continue;
+            const float nz = s_nz[row];
+            const float* drow = sD + s_grp[row] * BN;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int ncol = (wn * TN + tn) * 32 + li;
+                float v = acc[tm][tn][r] * (scaled ? drow[ncol] : 1.f) + nz + bsv[tn];
+                if (do_act) v = (v > 0.f ? v : v * p.alpha) * gain;
+                p.y[(size_t)off * p.Cout + n0 + ncol] = v;
+            }
+        }
+    }
+}
+
+int launch_region(const e4s_conv_params& p, hipStream_t st) {
+    auto kern = conv_bf16x3_region_kernel;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_REGION);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int ntn = p.Cout / BN;
+    const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + TH - 1) / TH) * tx_n;
+    const int tiles_per_cls = p.B * per_img;
+    const int64_t blocks = (int64_t)tiles_per_cls * p.ncls * ntn;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM_REGION, st, p, ntn, tx_n, per_img, tiles_per_cls);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
 // fp32 rows [rows][cin] -> split rows [rows][cin/32][hi x32 | lo x32] (bf16), same byte size
 __global__ void split_bf16x2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int64_t n8,
                                     int cin) {
@@ -328,11 +604,18 @@ int launch(const e4s_conv_params& p, hipStream_t st) {
 
 extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     const e4s_conv_params& p = *pp;
-    if (p.Cin % KC || p.Cout % BN || p.ntaps != 9 || p.ncls != 1 || p.istride != 1 || p.ostride != 1 || p.tiles ||
-        p.labels || p.noise_per_channel || p.Ha != p.Hi || p.Wa != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi)
+    const bool up = (p.ncls == 4);
+    if (p.Cin % KC || p.Cout % BN || p.ntaps != 9 || (p.ncls != 1 && !up) || p.istride != 1 ||
+        p.ostride != (up ? 2 : 1) || p.tiles || p.noise_per_channel || p.Ha != p.Hi || p.Wa != p.Wi ||
+        p.Ho != p.Hi * p.ostride || p.Wo != p.Wi * p.ostride)
         return (int)hipErrorInvalidValue;
-    static const int abl = [] { const char* e = getenv("E4S_BF16X3_ABL"); return e ? atoi(e) : 0; }();
     hipStream_t st = as_stream(stream);
+    if (p.labels || up) {
+        if (!p.in_scale || p.act == 2 || (p.labels && (p.groups_per_batch < 1 || p.groups_per_batch > MAXR)))
+            return (int)hipErrorInvalidValue;
+        return launch_region(p, st);
+    }
+    static const int abl = [] { const char* e = getenv("E4S_BF16X3_ABL"); return e ? atoi(e) : 0; }();
     switch (abl) {
         case 1: return launch<false, 1>(p, st);
         case 2: return launch<false, 2>(p, st);

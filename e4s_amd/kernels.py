@@ -255,8 +255,8 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     p.bias, p.slope = fptr(bias), fptr(slope)
     p.act, p.alpha, p.gain = act, alpha, gain
     if w_split is not None:
-        if not bf16x3_eligible(cin, cout, istride=istride, ostride=ostride, ntaps=ntaps, ncls=ncls,
-                               masked=labels is not None) or not spatial or noise_per_channel:
+        if not bf16x3_eligible(cin, cout, istride=istride, ostride=ostride, ntaps=ntaps, ncls=ncls) \
+                or not spatial or noise_per_channel or ((labels is not None or ncls == 4) and in_scale is None):
             raise RuntimeError("e4s_conv_bf16x3_f32 does not cover this contraction")
         p.w = fptr(w_split)
         call("e4s_conv_bf16x3_f32", ctypes.byref(p), stream())
@@ -266,18 +266,19 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
 
 
 def bf16x3_eligible(cin, cout, *, istride=1, ostride=1, ntaps=9, ncls=1, masked=False):
-    """Shapes e4s_conv_bf16x3_f32 covers (include/e4s_hip.h)."""
-    return (cin % 32 == 0 and cout % 128 == 0 and istride == 1 and ostride == 1 and ntaps == 9 and ncls == 1
-            and not masked)
+    """Shapes e4s_conv_bf16x3_f32 covers (include/e4s_hip.h): natural-order 3x3, plain or polyphase up-conv, with or
+    without a region label map."""
+    return (cin % 32 == 0 and cout % 128 == 0 and istride == 1 and ntaps == 9
+            and (ncls, ostride) in ((1, 1), (4, 2)))
 
 
-def want_bf16x3(b, h, w, cin, cout):
-    """Policy of PRECISION for a stride-1 3x3 conv on [b,h,w,cin] -> cout."""
-    if PRECISION == "f32" or not bf16x3_eligible(cin, cout):
+def want_bf16x3(b, h, w, cin, cout, ncls=1):
+    """Policy of PRECISION for a natural-order 3x3 conv (ncls = 4: polyphase up-conv) on [b,h,w,cin] -> cout."""
+    if PRECISION == "f32" or not bf16x3_eligible(cin, cout, ncls=ncls, ostride=2 if ncls == 4 else 1):
         return False
     if PRECISION == "bf16x3":
         return True
-    return b * ((h + 15) // 16) * ((w + 15) // 16) * (cout // 128) >= BF16X3_MIN_BLOCKS
+    return b * ((h + 15) // 16) * ((w + 15) // 16) * (cout // 128) * ncls >= BF16X3_MIN_BLOCKS
 
 
 def split_bf16x2(w):

@@ -205,6 +205,14 @@ class ModulatedConv2d(nn.Module):
         self._pack = pack
         return pack
 
+    def split_weights(self):
+        """Split-bf16 image of packed()["w"] for e4s_conv_bf16x3_f32 (built on first use, cached with the pack)."""
+        pk = self.packed()
+        if "w_split" not in pk:
+            with torch.no_grad():
+                pk["w_split"] = K.split_bf16x2(pk["w"])
+        return pk["w_split"]
+
     def forward(self, input, style):
         """Drop-in single-style forward (NCHW in/out), model.py:242-320."""
         b = input.shape[0]
@@ -286,6 +294,14 @@ class StyledConv(nn.Module):
             if per_ch:
                 raise NotImplementedError("backward with per-channel noise maps")
             rec.update(d=d, noise=nz)
+        ncls = 4 if conv.upsample else 1
+        if plan is None and not per_ch and K.want_bf16x3(b, h, w, conv.in_channel, conv.out_channel, ncls):
+            # split-bf16 matrix-core path (polyphase form for up-convs: 4x the MACs of the exact kernel at > 3x its rate)
+            return K.conv_mfma(x, pk["w"], conv.out_channel, labels=labels, num_regions=num_regions, ncls=ncls,
+                               ostride=2 if conv.upsample else 1, in_scale=s, out_scale=d, noise=nz,
+                               noise_w=self.noise.weight, bias=self.activate.bias, act=1,
+                               alpha=self.activate.negative_slope, gain=self.activate.scale,
+                               w_split=conv.split_weights())
         # a masked tile runs one pass per region present: exact only where 12x28 output tiles are mostly uniform
         if conv.upsample and plan is None and UPCONV_EXACT and (labels is None or ho >= UPCONV_EXACT_MIN_RES):
             return K.upconv_mfma(x, pk["w3"], conv.out_channel, conv.blur.kernel, in_scale=s, out_scale=d,

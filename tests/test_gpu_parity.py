@@ -226,6 +226,37 @@ def test_styled_conv_masked_vs_oracle(cin, cout, res, up, cells, use_plan):
     assert maxabs(got, want) < 5e-5
 
 
+@pytest.mark.parametrize("cin,cout,res,up,cells,masked", [
+    (512, 512, 16, False, 16, True), (512, 512, 8, True, 4, True), (256, 256, 32, False, 8, True),
+    (512, 256, 16, True, 32, True), (512, 512, 4, False, 64, True), (512, 512, 4, True, 64, True),
+    (128, 128, 32, False, 64, True), (256, 128, 16, True, 8, False), (128, 128, 16, False, 8, False)])
+def test_styled_conv_bf16x3_vs_oracle(cin, cout, res, up, cells, masked, monkeypatch):
+    """The region-select split-bf16 kernel (per-pixel style applied to the A fragment before the hi/lo split; polyphase
+    form for up-convs) == the reference's 12 passes x one-hot mask, to 1e-4 of the output scale (error model in
+    test_conv_bf16x3_vs_conv2d_f64); the fp32 kernels measure ~1e-6 here."""
+    from e4s_amd import kernels as K
+    from e4s_amd.stylegan2 import StyledConv
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    sd = _styled_sd(cin, cout, up, 12)
+    m = StyledConv(cin, cout, 3, 512, upsample=up, mask_op=masked)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(6)
+    b = 2
+    x = torch.randn(b, cin, res, res, generator=g)
+    style = torch.randn(b, 12, 512, generator=g) if masked else torch.randn(b, 512, generator=g)
+    mask = synth.onehot(synth.synth_labels_blocks(b, 512, cells, seed=7))
+    out_res = res * 2 if up else res
+    noise = torch.randn(b, 1, out_res, out_res, generator=g)
+    want = orc.styled_conv(sd, "", x, style, mask if masked else None, noise, up, masked)
+    got = m(x.to(DEV), style.to(DEV), mask.to(DEV) if masked else None, noise=noise.to(DEV))
+    monkeypatch.setattr(K, "PRECISION", "f32")
+    got32 = m(x.to(DEV), style.to(DEV), mask.to(DEV) if masked else None, noise=noise.to(DEV))
+    scale = float(want.abs().max())
+    assert 0.0 < maxabs(got, got32)                                  # the split-bf16 kernel really ran
+    assert maxabs(got, want) < 1e-4 * scale, (maxabs(got, want), scale)
+
+
 def test_styled_conv_per_channel_noise_and_unmasked():
     from e4s_amd.stylegan2 import StyledConv
     sd = _styled_sd(64, 64, False, 13)
