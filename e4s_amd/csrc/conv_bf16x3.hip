@@ -195,7 +195,11 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
         }
         __builtin_amdgcn_sched_barrier(0);
 
-        // -- global -> VGPR: weights of stage s+1, halo piece `tap` of chunk+1 --
+        // -- global -> VGPR: weights of stage s+1, halo piece `tap` of chunk+1.  Issued after the first MFMA group so the
+        // matrix pipe starts right after the barrier; its ~90 address/SALU instructions are spread between the MFMAs of
+        // groups 0-1 (sched_group_barrier: 1 MFMA, then up to 8 others), because after a barrier all 8 waves are in
+        // the same phase and nothing else would cover them --
+        auto issue_loads = [&]() {
         if (ABL < 3) {
             const bool more2 = (s + 1 < nstage);
             const unsigned char* wp =
@@ -214,17 +218,14 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
             L.dst = item_dst(item);
         }
         if (ABL != 2 && ABL != 4) ldB(1);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // -- MFMAs of stage s: 8 groups of 6 --
-#pragma unroll
-        for (int g = 0; g < 2 * TM; ++g) {
+        };
+        // -- MFMAs of stage s: 4 groups of 6 --
+        auto mfma_group = [&](int g) {
             const int kk = g / TM, tm = g % TM, cur = g & 1;
             if (g + 1 < 2 * TM && ABL != 2 && ABL != 4) ldA(g + 1, cur ^ 1);
             if (ABL == 1) {
                 acc[tm][0][0] += (float)ah[cur][0] + (float)al[cur][1] + (float)bh[kk][0][0] + (float)bl[kk][1][1];
-                __builtin_amdgcn_sched_barrier(0);
-                continue;
+                return;
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
@@ -235,8 +236,22 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        mfma_group(0);
+        issue_loads();
+        mfma_group(1);
+        if (ABL == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x126, 8, 0);      // then up to 8 VALU / SALU / VMEM-read / DS-read
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(3);
+        __builtin_amdgcn_sched_barrier(0);
 
         // -- VGPR -> LDS --
         if (ABL < 3 && s + 1 < nstage) {
@@ -459,24 +474,24 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
         f32x8 raw = ldraw(0);
         __builtin_amdgcn_sched_barrier(0);
 
-        // -- global -> VGPR: weights of stage s+1, one piece of chunk+1's halo / style slice --
+        // -- global -> VGPR: weights of stage s+1, one piece of chunk+1's halo / style slice (issued after the first
+        // MFMA group and spread between the MFMAs of groups 0-1, see the kernel above) --
         f32x4 pb[BJ];
+        f32x8 pa;
         const bool more = (s + 1 < nstage);
-        {
+        const bool have_next = (chunk + 1 < nchunk);
+        const int item = tap * XPIECE + (piece_thr ? tid : 0);
+        const Item it = item_of(item);
+        auto issue_loads = [&]() {
             const unsigned char* wp =
                 wbytes + ((size_t)(more ? t1 : 0) * p.Cout + n0) * wrow + (size_t)(more ? c1 : 0) * 128 + bq;
 #pragma unroll
             for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
-        }
-        const bool have_next = (chunk + 1 < nchunk);
-        const int item = tap * XPIECE + (piece_thr ? tid : 0);
-        const Item it = item_of(item);
-        f32x8 pa = load8(it.src + (have_next ? (chunk + 1) * KC : 0));
-        __builtin_amdgcn_sched_barrier(0);
+            pa = load8(it.src + (have_next ? (chunk + 1) * KC : 0));
+        };
 
         // -- 4 groups of 6 MFMAs; the next group's fp32 fragment is requested before the current one is converted --
-#pragma unroll
-        for (int g = 0; g < 2 * TM; ++g) {
+        auto mfma_group = [&](int g) {
             const int kk = g / TM, tm = g % TM;
             const f32x8 v = raw * sv[tm][kk];
             if (g + 1 < 2 * TM) raw = ldraw(g + 1);
@@ -492,7 +507,24 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kk][tn], acc[tm][tn], 0, 0, 0);
+        };
+        mfma_group(0);
+        issue_loads();
+        mfma_group(1);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x126, 8, 0);      // then up to 8 VALU / SALU / VMEM-read / DS-read
         }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(2);
+        mfma_group(3);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x126, 6, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 
         // -- VGPR -> LDS --
         if (more) {
