@@ -105,10 +105,10 @@ def _gen(key, seed):
 
 def synth_tensor(key, shape, kind, seed=0):
     g = _gen(key, seed)
-    if kind == "blur":
+    if kind in ("blur", "blur1"):               # Blur buffer: x4 when it follows an up-sampling conv (model.py:85-86)
         k = torch.tensor([1.0, 3.0, 3.0, 1.0])
         k = k[None, :] * k[:, None]
-        return k / k.sum() * 4.0
+        return k / k.sum() * (4.0 if kind == "blur" else 1.0)
     x = torch.randn(shape, generator=g, dtype=torch.float32)
     if kind in ("randn", "noisebuf"):
         return x
@@ -131,6 +131,31 @@ def synth_tensor(key, shape, kind, seed=0):
 def synth_state_dict(out_size=1024, remaining_layer_idx=13, num_seg_cls=12, seed=0):
     return {k: synth_tensor(k, s, kind, seed)
             for k, s, kind in net3_param_spec(out_size, remaining_layer_idx, num_seg_cls)}
+
+
+def disc_param_spec(size=64, channel_multiplier=2):
+    """(key, shape, kind) of Discriminator(size) -- src/models/stylegan2/model.py:740-775 (buffers included)."""
+    ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
+          256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+    spec = [("convs.0.0.weight", (ch[size], 3, 1, 1), "randn"), ("convs.0.1.bias", (ch[size],), "bias")]
+    cin = ch[size]
+    log_size = int(math.log2(size))
+    for j, i in enumerate(range(log_size, 2, -1), start=1):
+        cout = ch[2 ** (i - 1)]
+        c = f"convs.{j}."
+        spec += [(c + "conv1.0.weight", (cin, cin, 3, 3), "randn"), (c + "conv1.1.bias", (cin,), "bias"),
+                 (c + "conv2.0.kernel", (4, 4), "blur1"), (c + "conv2.1.weight", (cout, cin, 3, 3), "randn"),
+                 (c + "conv2.2.bias", (cout,), "bias"),
+                 (c + "skip.0.kernel", (4, 4), "blur1"), (c + "skip.1.weight", (cout, cin, 1, 1), "randn")]
+        cin = cout
+    spec += [("final_conv.0.weight", (ch[4], cin + 1, 3, 3), "randn"), ("final_conv.1.bias", (ch[4],), "bias"),
+             ("final_linear.0.weight", (ch[4], ch[4] * 16), "randn"), ("final_linear.0.bias", (ch[4],), "bias"),
+             ("final_linear.1.weight", (1, ch[4]), "randn"), ("final_linear.1.bias", (1,), "bias")]
+    return spec
+
+
+def synth_disc_state_dict(size=64, seed=0):
+    return {k: synth_tensor("D." + k, s, kind, seed) for k, s, kind in disc_param_spec(size)}
 
 
 def synth_latent_avg(out_size=1024, seed=0):

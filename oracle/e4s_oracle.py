@@ -188,6 +188,53 @@ def generator_forward(sd, latent, mask, noise, size, remaining_layer_idx, pfx="G
 
 
 # --------------------------------------------------------------------------
+# Discriminator (config 5 only; second consumer of upfirdn2d mode 1 / fused_bias_act)
+# --------------------------------------------------------------------------
+def _d_conv_layer(sd, pfx, x, kernel_size, downsample, bias=True, activate=True):
+    """ConvLayer.  src/models/stylegan2/model.py:670-716: [Blur pad ((p+1)//2, p//2), p = 2 + (k-1)] ->
+    EqualConv2d(stride 2, padding 0 | stride 1, padding k//2; scale 1/sqrt(Cin*k*k), :97-132) ->
+    FusedLeakyReLU (bias) | ScaledLeakyReLU(0.2) (no bias)."""
+    i = 0
+    if downsample:
+        p = 2 + (kernel_size - 1)
+        x = upfirdn2d(x, sd[pfx + "0.kernel"], pad=((p + 1) // 2, p // 2))
+        i = 1
+    w = sd[pfx + f"{i}.weight"]
+    scale = 1.0 / math.sqrt(w.shape[1] * kernel_size ** 2)
+    cb = sd.get(pfx + f"{i}.bias") if (bias and not activate) else None
+    x = F.conv2d(x, w * scale, cb, stride=2 if downsample else 1, padding=0 if downsample else kernel_size // 2)
+    if activate:
+        if bias:
+            x = fused_leaky_relu(x, sd[pfx + f"{i + 1}.bias"])
+        else:
+            x = F.leaky_relu(x, 0.2) * math.sqrt(2)
+    return x
+
+
+def discriminator_forward(sd, x, size, pfx=""):
+    """Discriminator.forward.  src/models/stylegan2/model.py:740-799.  x [B,3,size,size] -> logits [B,1]."""
+    log_size = int(math.log2(size))
+    out = _d_conv_layer(sd, pfx + "convs.0.", x, 1, False)
+    for j in range(1, log_size - 1):                                 # ResBlock, :719-737
+        c = f"{pfx}convs.{j}."
+        r = _d_conv_layer(sd, c + "conv1.", out, 3, False)
+        r = _d_conv_layer(sd, c + "conv2.", r, 3, True)
+        sk = _d_conv_layer(sd, c + "skip.", out, 1, True, bias=False, activate=False)
+        out = (r + sk) / math.sqrt(2)
+    b, ch, h, w = out.shape                                          # minibatch stddev, :783-790
+    group = min(b, 4)
+    std = out.view(group, -1, 1, ch, h, w)
+    std = torch.sqrt(std.var(0, unbiased=False) + 1e-8)
+    std = std.mean([2, 3, 4], keepdim=True).squeeze(2)
+    out = torch.cat([out, std.repeat(group, 1, h, w)], 1)
+    out = _d_conv_layer(sd, pfx + "final_conv.", out, 3, False)
+    out = out.reshape(b, -1)
+    out = fused_leaky_relu(equal_linear(out, sd[pfx + "final_linear.0.weight"], None),
+                           sd[pfx + "final_linear.0.bias"])         # EqualLinear(activation="fused_lrelu"), :159-164
+    return equal_linear(out, sd[pfx + "final_linear.1.weight"], sd[pfx + "final_linear.1.bias"])
+
+
+# --------------------------------------------------------------------------
 # Regional style encoder
 # --------------------------------------------------------------------------
 ENC_BLOCKS = ((64, 128, 3), (128, 256, 4), (256, 512, 14), (512, 512, 3))    # psp_encoders.py:242-247

@@ -80,8 +80,9 @@ def reference_modules():
     sys.modules["src.models.stylegan2.op"] = op
     sys.modules["src.models.stylegan2.op.conv2d_gradfix"] = gf
     from src.models.networks import Net3                # reference code, unmodified
-    from src.models.stylegan2.model import Generator, ModulatedConv2d, StyledConv, ToRGB
-    ns = types.SimpleNamespace(Net3=Net3, Generator=Generator, ModulatedConv2d=ModulatedConv2d,
+    from src.models.stylegan2.model import Discriminator, Generator, ModulatedConv2d, StyledConv, ToRGB
+    ns = types.SimpleNamespace(Net3=Net3, Generator=Generator, Discriminator=Discriminator,
+                               ModulatedConv2d=ModulatedConv2d,
                                StyledConv=StyledConv, ToRGB=ToRGB,
                                fused_leaky_relu=op.fused_leaky_relu, upfirdn2d=op.upfirdn2d)
     sys.path[:] = saved_path

@@ -11,6 +11,7 @@ What is pinned:
               (block-random mask: every region at every tile)
   net1024.pt  Net3(out_size=1024, K=13): the E4S-core swap (2x encoder, swap, MLPs, generator)
               on a face-like mask; image stored strided (::8) plus a full-res centre crop
+  disc64.pt   Discriminator(64) (config 5): logits and the 4x4 feature map of a seeded batch of 4
 """
 import os
 import sys
@@ -112,14 +113,32 @@ def net_case(out_size, mask_kind):
     return rec
 
 
+@torch.no_grad()
+def disc_case(size=64):
+    """Discriminator(size) of the real reference on a seeded batch of 4 (the minibatch-stddev group)."""
+    ns = ref_shim.reference_modules()
+    sd = synth.synth_disc_state_dict(size)
+    d = ns.Discriminator(size)
+    d.load_state_dict(sd, strict=True)
+    x = synth.synth_image(4, size, tag="disc")
+    feats = d.convs(x)
+    return dict(size=size, logits=d(x), feats=feats.clone())
+
+
 def main():
     torch.manual_seed(0)
+    if "--disc-only" in sys.argv:
+        torch.save(disc_case(64), os.path.join(HERE, "disc64.pt"))
+        print("disc64.pt done")
+        return
     torch.save(ops_cases(), os.path.join(HERE, "ops.pt"))
     print("ops.pt done")
     torch.save(net_case(256, "blocks"), os.path.join(HERE, "net256.pt"))
     print("net256.pt done")
     torch.save(net_case(1024, "face"), os.path.join(HERE, "net1024.pt"))
     print("net1024.pt done")
+    torch.save(disc_case(64), os.path.join(HERE, "disc64.pt"))
+    print("disc64.pt done")
 
 
 if __name__ == "__main__":

@@ -434,17 +434,19 @@ def test_net256_swap_vs_golden_bf16x3(golden, monkeypatch):
     assert maxabs(img, g["img"]) < 1e-3
 
 
-def test_auto_precision_policy(monkeypatch):
-    """auto = split-bf16 only where the kernel applies and the launch fills the chip (>= 128 tiles of 256x128)."""
-    from e4s_amd import kernels as K
-    monkeypatch.setattr(K, "PRECISION", "auto")
-    assert K.want_bf16x3(16, 32, 32, 512, 512)            # bench batch: 2 x 8 images -> 256 tiles
-    assert not K.want_bf16x3(2, 32, 32, 512, 512)         # batch-1 latency run: 32 tiles -> exact fp32 kernel
-    assert not K.want_bf16x3(16, 256, 256, 64, 64)        # Cout % 128 != 0: no split-bf16 kernel
-    monkeypatch.setattr(K, "PRECISION", "f32")
-    assert not K.want_bf16x3(16, 32, 32, 512, 512)
-    monkeypatch.setattr(K, "PRECISION", "bf16x3")
-    assert K.want_bf16x3(1, 16, 16, 512, 512)
+@torch.no_grad()
+def test_discriminator_vs_golden(golden):
+    """Discriminator(64) -- HIP blur (upfirdn2d pad modes of model.py:683-689) and fused
+    bias+leaky-ReLU inside the ResBlock stack -- against the REAL reference's logits and 4x4 feature map."""
+    from e4s_amd.stylegan2 import Discriminator
+    g = golden("disc64.pt")
+    d = Discriminator(64)
+    d.load_state_dict(synth.synth_disc_state_dict(64), strict=True)
+    d = d.to(DEV).eval()
+    x = synth.synth_image(4, 64, tag="disc").to(DEV)
+    feats = d.convs(x)
+    assert maxabs(feats, g["feats"]) < 1e-4 * float(g["feats"].abs().max())
+    assert maxabs(d(x), g["logits"]) < 1e-4
 
 
 @torch.no_grad()

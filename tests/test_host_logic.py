@@ -109,3 +109,51 @@ def test_src_shim_reexports_native_modules():
     lab = torch.randint(0, 12, (2, 1, 8, 8))
     oh = labelMap2OneHot(lab, 12)
     assert oh.shape == (2, 12, 8, 8) and torch.equal(oh.argmax(1, keepdim=True), lab) and float(oh.sum()) == 128.0
+
+
+def test_discriminator_state_dict_matches_reference_layout():
+    """The Discriminator module tree (config 5) has exactly the reference's keys/shapes: the same synthetic state
+    dict was loaded strict=True into the REAL reference Discriminator when tests/golden/disc64.pt was produced."""
+    from e4s_amd.stylegan2 import Discriminator
+    spec = {k: tuple(s) for k, s, _ in synth.disc_param_spec(64)}
+    mine = {k: tuple(v.shape) for k, v in Discriminator(64).state_dict().items()}
+    assert mine == spec
+
+
+def test_auto_precision_policy(monkeypatch):
+    """E4S_PRECISION policy (host logic only): auto = split-bf16 where the kernel applies and the launch fills the
+    chip (>= 128 tiles of 256x128), f32 = never, bf16x3 = wherever the kernel applies."""
+    from e4s_amd import kernels as K
+    monkeypatch.setattr(K, "PRECISION", "auto")
+    assert K.want_bf16x3(16, 32, 32, 512, 512)            # bench batch: 2 x 8 images -> 256 tiles
+    assert not K.want_bf16x3(2, 32, 32, 512, 512)         # batch-1 latency run: 32 tiles -> exact fp32 kernel
+    assert not K.want_bf16x3(16, 256, 256, 64, 64)        # Cout % 128 != 0: no split-bf16 kernel
+    assert K.want_bf16x3(8, 32, 32, 512, 512, ncls=4)     # polyphase up-conv: 4 phases count as tiles
+    monkeypatch.setattr(K, "PRECISION", "f32")
+    assert not K.want_bf16x3(16, 32, 32, 512, 512)
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    assert K.want_bf16x3(1, 16, 16, 512, 512)
+
+
+def test_split_bf16_three_product_error_model():
+    """The arithmetic of e4s_conv_bf16x3_f32, restated on the CPU: v = hi + lo (two round-to-nearest bf16), product =
+    a_hi*b_hi + a_hi*b_lo + a_lo*b_hi.  Claims checked: the split loses < 2^-16 |v|; a 4608-term contraction (the
+    512-channel 3x3 layer) lands within 2e-5 of its own scale of the exact result -- two orders of magnitude inside what
+    one bf16 product gives, and the basis of the per-layer 1e-4 bound in tests/test_gpu_parity.py."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(256, 4608, generator=g, dtype=torch.float32) * 1.3 + 0.2
+    b = torch.randn(4608, 64, generator=g, dtype=torch.float32) / 68.0
+
+    def split(v):
+        hi = v.to(torch.bfloat16).to(torch.float32)
+        lo = (v - hi).to(torch.bfloat16).to(torch.float32)
+        return hi, lo
+    ah, al = split(a)
+    bh, bl = split(b)
+    assert float(((a - ah - al).abs() / a.abs().clamp_min(1e-30)).max()) < 2.0 ** -16
+    exact = a.double() @ b.double()
+    three = ah.double() @ bh.double() + ah.double() @ bl.double() + al.double() @ bh.double()
+    one = ah.double() @ bh.double()
+    scale = float(exact.abs().max())
+    assert float((three - exact).abs().max()) < 2e-5 * scale
+    assert float((one - exact).abs().max()) > 1e-3 * scale      # a single bf16 product is not enough for the 1e-3 path

@@ -69,3 +69,14 @@ def test_net1024_swap_matches_reference(golden):
     c0 = 1024 // 2 - 64
     assert float((img[:, :, c0:c0 + 128, c0:c0 + 128] - g["img_crop"]).abs().max()) < 1e-4
     assert torch.allclose(img.mean((2, 3)), g["img_mean"], atol=1e-5)
+
+
+def test_discriminator_matches_reference(golden):
+    """Discriminator(64) of the real reference (model.py:740-799) on a seeded batch of 4."""
+    g = golden("disc64.pt")
+    sd = synth.synth_disc_state_dict(64)
+    x = synth.synth_image(4, 64, tag="disc")
+    with torch.no_grad():
+        y = orc.discriminator_forward(sd, x, 64)
+    assert tuple(y.shape) == (4, 1)
+    assert float((y - g["logits"]).abs().max()) < 1e-5
