@@ -302,279 +302,6 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Mid-stage-barrier variant of the plain kernel (three weight buffers).  In the kernel above every stage ends with
-// "LDS stores -> barrier -> fragment reads -> first MFMA", a chain that all 8 waves go through in lockstep with the
-// matrix pipe empty.  Here the one barrier of a stage sits in the MIDDLE of its MFMA stream:
-//     groups 0,1 | publish stage s+1 (weights -> third buffer, halo piece) | barrier | request stage s+2 |
-//     group 2 | prefetch the first fragments of stage s+1 | group 3
-// so a wave arrives at the barrier with 12 MFMAs queued behind it, leaves it with the next fragments already in
-// registers, and crosses the stage boundary without synchronising.  Safety: a buffer written before barrier_s was
-// last read in stage s-2 (weights, 3 buffers) / in the previous chunk (halo pieces are only written from tap 1 on),
-// and every wave that has passed barrier_{s-1} has finished those; what stage s+1 reads was written before
-// barrier_s, which the reader has passed.
-constexpr int SMEM_MB = 2 * A_BYTES + 3 * B_BYTES + BM * 8;
-constexpr int MB_NPIECE = 8, MB_PIECE = ITEMS / MB_NPIECE;      // 8 halo pieces of 162 items (taps 0..7)
-static_assert(MB_PIECE * MB_NPIECE == ITEMS && MB_PIECE <= NTHR, "halo split");
-
-template <bool SCALED>
-__global__ __launch_bounds__(NTHR) void conv_bf16x3_mb_kernel(const e4s_conv_params p, const int ntn, const int tx_n,
-                                                              const int per_img) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;                          // [2][HALO][ROWB]
-    unsigned char* sB = smem + 2 * A_BYTES;            // [3][BN][ROWB]
-    int* s_out = reinterpret_cast<int*>(sB + 3 * B_BYTES);
-    float* s_nz = reinterpret_cast<float*>(s_out + BM);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, kh = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = logical / ntn, nt = logical - mt * ntn;
-    const int n0 = nt * BN;
-    const int tb = mt / per_img;
-    const int rem = mt - tb * per_img;
-    const int tyb = rem / tx_n, txb = rem - tyb * tx_n;
-
-    if (tid < BM) {
-        const int ay = tyb * TH + tid / TW, ax = txb * TW + tid % TW;
-        const bool valid = ay < p.Ha && ax < p.Wa;
-        s_out[tid] = valid ? (tb * p.Ho + ay) * p.Wo + ax : -1;
-        float nz = 0.f;
-        if (valid && p.noise) nz = p.noise_w[0] * p.noise[(int64_t)tb * p.noise_bstride + (int64_t)ay * p.Wo + ax];
-        s_nz[tid] = nz;
-    }
-
-    const int nchunk = p.Cin / KC, nstage = nchunk * 9;
-    const float* xb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin;
-    const float* sc = SCALED ? p.in_scale + (size_t)tb * p.Cin : nullptr;
-    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(p.w);
-    const size_t wrow = (size_t)p.Cin * 4;
-
-    auto item_src = [&](int item, bool& ok) -> size_t {
-        const int h = item >> 2, q = item & 3;
-        const int hy = h / HALO_W, hx = h - hy * HALO_W;
-        const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
-        ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        return ok ? ((size_t)iy * p.Wi + ix) * p.Cin + q * 8 : (size_t)(q * 8);
-    };
-    auto item_dst = [&](int item) -> int { return (item >> 2) * ROWB + (item & 3) * 16; };
-    auto load8 = [&](const float* src) -> f32x8 {
-        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
-        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 4);
-        return f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-    };
-
-    // ---- prologue: halo of chunk 0, weights of stage 0 -> LDS; weights of stage 1 -> registers ----
-    for (int item = tid; item < ITEMS; item += NTHR) {
-        bool ok;
-        const size_t off = item_src(item, ok);
-        f32x8 v = load8(xb + off);
-        if (SCALED) v *= load8(sc + (item & 3) * 8);
-        if (!ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        split_store(sA + item_dst(item), v);
-    }
-    const int bq = (tid & 7) * 16, br0 = tid >> 3;
-    f32x4 breg[BJ];
-    {
-        const unsigned char* wp = wbytes + (size_t)n0 * wrow + bq;
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) breg[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(sB + (br0 + BSTEP * j) * ROWB + bq) = breg[j];
-        const unsigned char* wp1 = wbytes + ((size_t)1 * p.Cout + n0) * wrow + bq;          // stage 1 = (tap 1, chunk 0)
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) breg[j] = *reinterpret_cast<const f32x4*>(wp1 + (size_t)(br0 + BSTEP * j) * wrow);
-    }
-    __syncthreads();
-
-    int arow[TM], brow[TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int m = (wm * TM + tm) * 32 + li;
-        arow[tm] = ((m / TW) * HALO_W + (m % TW)) * ROWB + kh * 16;
-    }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) brow[tn] = ((wn * TN + tn) * 32 + li) * ROWB + kh * 16;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-
-    // halo piece in flight: requested after barrier_s, published before barrier_{s+1}
-    f32x8 areg = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, asreg = areg;
-    int adst = 0;
-    bool apart = false, aok = false;
-    const bool piece_thr = tid < MB_PIECE;
-
-    // fragments of the stage's first group, loaded at the end of the previous stage
-    bf16x8 bh[2][TN], bl[2][TN], ah[2], al[2];
-    auto tap_off = [&](int t) -> int { return ((t / 3) * HALO_W + (t % 3)) * ROWB; };
-    {
-        const unsigned char* Ab = sA + tap_off(0);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            bh[0][tn] = *reinterpret_cast<const bf16x8*>(sB + brow[tn]);
-            bl[0][tn] = *reinterpret_cast<const bf16x8*>(sB + brow[tn] + LO);
-        }
-        ah[0] = *reinterpret_cast<const bf16x8*>(Ab + arow[0]);
-        al[0] = *reinterpret_cast<const bf16x8*>(Ab + arow[0] + LO);
-    }
-
-    int tap = 0, chunk = 0;          // stage s
-    int t2 = 2, c2 = 0;              // stage s + 2
-    int bcur = 0;                    // s % 3
-    for (int s = 0; s < nstage; ++s) {
-        const unsigned char* Ab = sA + (chunk & 1) * A_BYTES + tap_off(tap);
-        const unsigned char* Bb = sB + bcur * B_BYTES;
-        const int bnext = (bcur == 2) ? 0 : bcur + 1;
-        auto ldA = [&](int g, int slot) {
-            const int kk = g / TM, tm = g % TM;
-            ah[slot] = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32);
-            al[slot] = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32 + LO);
-        };
-        auto mfma_group = [&](int g) {
-            const int kk = g / TM, tm = g % TM, cur = g & 1;
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[kk][tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
-        };
-        // -- first half --
-        ldA(1, 1);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            bh[1][tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + 32);
-            bl[1][tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + 32 + LO);
-        }
-        mfma_group(0);
-        __builtin_amdgcn_sched_barrier(0);
-        ldA(2, 0);
-        mfma_group(1);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // -- publish what stage s+1 needs, then the stage's only barrier --
-        if (s + 1 < nstage) {
-            unsigned char* db = sB + bnext * B_BYTES + br0 * ROWB + bq;
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(db + BSTEP * j * ROWB) = breg[j];
-        }
-        if (apart) {
-            f32x8 v = areg;
-            if (SCALED) v *= asreg;
-            if (!aok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            split_store(sA + ((chunk + 1) & 1) * A_BYTES + adst, v);
-        }
-        __syncthreads();
-
-        // -- request: weights of stage s+2, halo piece `tap` (< 8) of chunk+1 --
-        {
-            const bool more2 = (s + 2 < nstage);
-            const unsigned char* wp =
-                wbytes + ((size_t)(more2 ? t2 : 0) * p.Cout + n0) * wrow + (size_t)(more2 ? c2 : 0) * 128 + bq;
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) breg[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
-            const bool doA = (tap < MB_NPIECE) && (chunk + 1 < nchunk);
-            const int item = min(tap, MB_NPIECE - 1) * MB_PIECE + (piece_thr ? tid : 0);
-            bool ok;
-            const size_t off = item_src(item, ok);
-            const int cnext = doA ? (chunk + 1) * KC : 0;
-            areg = load8(xb + off + cnext);
-            if (SCALED) asreg = load8(sc + cnext + (item & 3) * 8);
-            aok = ok;
-            apart = doA && piece_thr;
-            adst = item_dst(item);
-        }
-        ldA(3, 1);
-        mfma_group(2);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x126, 12, 0);     // then up to 12 VALU / SALU / VMEM-read / DS-read
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        // -- second half: first fragments of stage s+1 (published before the barrier above), then the last group --
-        int tapn = tap + 1, chunkn = chunk;
-        if (tapn == 9) { tapn = 0; chunkn = chunk + 1; }
-        if (s + 1 < nstage) {
-            const unsigned char* Abn = sA + (chunkn & 1) * A_BYTES + tap_off(tapn);
-            const unsigned char* Bbn = sB + bnext * B_BYTES;
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                bh[0][tn] = *reinterpret_cast<const bf16x8*>(Bbn + brow[tn]);
-                bl[0][tn] = *reinterpret_cast<const bf16x8*>(Bbn + brow[tn] + LO);
-            }
-            ah[0] = *reinterpret_cast<const bf16x8*>(Abn + arow[0]);
-            al[0] = *reinterpret_cast<const bf16x8*>(Abn + arow[0] + LO);
-        }
-        mfma_group(3);
-        __builtin_amdgcn_sched_barrier(0);
-        tap = tapn; chunk = chunkn;
-        bcur = bnext;
-        if (++t2 == 9) { t2 = 0; ++c2; }
-    }
-    __syncthreads();
-
-    // ---- epilogue (as above) ----
-    float osc[TN], bsv[TN], slp[TN];
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int col = n0 + (wn * TN + tn) * 32 + li;
-        osc[tn] = p.out_scale ? p.out_scale[(size_t)tb * p.Cout + col] : 1.f;
-        bsv[tn] = p.bias ? p.bias[col] : 0.f;
-        slp[tn] = (p.act == 2) ? p.slope[col] : p.alpha;
-    }
-    const float gain = (p.act == 1) ? p.gain : 1.f;
-    const bool do_act = p.act != 0;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int off = s_out[row];
-            if (off < 0) continue;
-            const float nz = s_nz[row];
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                float v = acc[tm][tn][r] * osc[tn] + nz + bsv[tn];
-                if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
-                p.y[(size_t)off * p.Cout + n0 + (wn * TN + tn) * 32 + li] = v;
-            }
-        }
-    }
-}
-
-template <bool SCALED>
-int launch_mb(const e4s_conv_params& p, hipStream_t st) {
-    auto kern = conv_bf16x3_mb_kernel<SCALED>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_MB);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int ntn = p.Cout / BN;
-    const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + TH - 1) / TH) * tx_n;
-    const int64_t blocks = (int64_t)p.B * per_img * ntn;
-    if (blocks <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM_MB, st, p, ntn, tx_n, per_img);
-    E4S_CHECK_LAUNCH();
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Region-select variant: masked StyledConvs (model.py:386-400) and the polyphase up-conv (ncls = 4).
 // The style that scales an A element belongs to the OUTPUT pixel's region, and neighbouring taps pair one halo pixel
 // with output pixels of different regions, so the halo cannot be scaled and split once when it is staged.  Here the
@@ -921,8 +648,6 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
         return launch_region(p, st);
     }
     static const int abl = [] { const char* e = getenv("E4S_BF16X3_ABL"); return e ? atoi(e) : 0; }();
-    static const int midbar = [] { const char* e = getenv("E4S_BF16X3_MIDBAR"); return e ? atoi(e) : 0; }();
-    if (midbar && !abl) return p.in_scale ? launch_mb<true>(p, st) : launch_mb<false>(p, st);
     switch (abl) {
         case 1: return launch<false, 1>(p, st);
         case 2: return launch<false, 2>(p, st);
