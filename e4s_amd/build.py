@@ -17,8 +17,15 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _extra_flags():
+    """E4S_BUILD_ABLATIONS=1: profiling build whose conv kernels honour E4S_BF16X3_ABL / E4S_UPCONV_ABL (ablated
+    variants compute wrong results by construction; never enabled in a product build)."""
+    return ["-DE4S_ABLATIONS"] if os.environ.get("E4S_BUILD_ABLATIONS") == "1" else []
+
+
 def _digest():
     h = hashlib.sha256()
+    h.update(" ".join(_extra_flags()).encode())
     files = sources() + [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "e4s_hip.h")]
     for f in files:
         h.update(f.encode())
@@ -41,7 +48,7 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-               "-I" + CSRC, "-c", src, "-o", obj]
+               "-I" + CSRC] + _extra_flags() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

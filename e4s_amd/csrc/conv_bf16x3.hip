@@ -55,7 +55,8 @@ __device__ __forceinline__ void split_store(unsigned char* dst, const f32x8 v) {
     *reinterpret_cast<bf16x8*>(dst + LO) = l;
 }
 
-// ABL: profiling ablations (env E4S_BF16X3_ABL; results are wrong for ABL != 0): 1 no MFMAs, 2 no fragment reads,
+// ABL: profiling ablations (builds with -DE4S_ABLATIONS select them with env E4S_BF16X3_ABL; results are wrong for
+// ABL != 0; product builds only instantiate ABL = 0): 1 no MFMAs, 2 no fragment reads,
 // 3 no global loads / LDS stores in the loop, 4 MFMAs only (no barrier either)
 template <bool SCALED, int ABL>
 __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params p, const int ntn, const int tx_n,
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
     int tap = 0, chunk = 0;          // stage s
     int t2 = 1, c2 = 0;              // stage s + 1
 
-    auto stage = [&](Pref& L, Pref& S, const int s) {
+    Pref P;
+    auto stage = [&](const int s) {
         const unsigned char* Ab = sA + (chunk & 1) * A_BYTES + ((tap / 3) * HALO_W + (tap % 3)) * ROWB;
         const unsigned char* Bb = sB + (s & 1) * B_BYTES;
         // One wave per SIMD: nothing else hides an LDS round trip (~120 cycles), so the fragment reads are software
@@ -205,17 +207,17 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
             const unsigned char* wp =
                 wbytes + ((size_t)(more2 ? t2 : 0) * p.Cout + n0) * wrow + (size_t)(more2 ? c2 : 0) * 128 + bq;
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) L.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
+            for (int j = 0; j < BJ; ++j) P.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
             const bool doA = (tap < NPIECE) && (chunk + 1 < nchunk);
             const int item = min(tap, NPIECE - 1) * PIECE + (piece_thr ? tid : 0);
             bool ok;
             const size_t off = item_src(item, ok);
             const int cnext = doA ? (chunk + 1) * KC : 0;
-            L.a = load8(xb + off + cnext);
-            if (SCALED) L.s = load8(sc + cnext + (item & 3) * 8);
-            L.ok = ok;
-            L.part = doA && piece_thr;
-            L.dst = item_dst(item);
+            P.a = load8(xb + off + cnext);
+            if (SCALED) P.s = load8(sc + cnext + (item & 3) * 8);
+            P.ok = ok;
+            P.part = doA && piece_thr;
+            P.dst = item_dst(item);
         }
         if (ABL != 2 && ABL != 4) ldB(1);
         };
@@ -257,20 +259,19 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
         if (ABL < 3 && s + 1 < nstage) {
             unsigned char* db = sB + ((s + 1) & 1) * B_BYTES + br0 * ROWB + bq;
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(db + BSTEP * j * ROWB) = S.b[j];
+            for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(db + BSTEP * j * ROWB) = P.b[j];
         }
-        if (ABL < 3 && S.part) {
-            f32x8 v = S.a;
-            if (SCALED) v *= S.s;
-            if (!S.ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            split_store(sA + ((chunk + 1) & 1) * A_BYTES + S.dst, v);
+        if (ABL < 3 && P.part) {
+            f32x8 v = P.a;
+            if (SCALED) v *= P.s;
+            if (!P.ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            split_store(sA + ((chunk + 1) & 1) * A_BYTES + P.dst, v);
         }
         if (ABL != 4) __syncthreads();
         if (++tap == 9) { tap = 0; ++chunk; }
         if (++t2 == 9) { t2 = 0; ++c2; }
     };
-    Pref P;
-    for (int s = 0; s < nstage; ++s) stage(P, P, s);
+    for (int s = 0; s < nstage; ++s) stage(s);
 
     // ---- epilogue: demod * acc + noise + bias, activation, NHWC store ----
     float osc[TN], bsv[TN], slp[TN];
@@ -647,6 +648,7 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
             return (int)hipErrorInvalidValue;
         return launch_region(p, st);
     }
+#ifdef E4S_ABLATIONS      // profiling builds only (E4S_BUILD_ABLATIONS=1 python -m e4s_amd.build): tools/bench_abl.py
     static const int abl = [] { const char* e = getenv("E4S_BF16X3_ABL"); return e ? atoi(e) : 0; }();
     switch (abl) {
         case 1: return launch<false, 1>(p, st);
@@ -655,6 +657,7 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
         case 4: return launch<false, 4>(p, st);
         default: break;
     }
+#endif
     return p.in_scale ? launch<true>(p, st) : launch<false>(p, st);
 }
 

@@ -39,7 +39,7 @@ struct UpSmem {
     float buf[UNION_WORDS];                      // K loop: A[2][128][36], B[2][3][32][36];  epilogue: I[17][33][32]
 };
 
-// ABL (ablation, profiling only): 0 full; 1 skip the K loop; 2 skip zero-fill + scatter; 3 skip the blur/store phase
+// ABL (ablation; only builds with -DE4S_ABLATIONS can select != 0): 0 full; 1 skip the K loop; 2 skip zero-fill + scatter; 3 skip the blur/store phase
 template <int ABL>
 __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p, const float* __restrict__ k4,
                                                          const int ntn) {
@@ -276,8 +276,9 @@ extern "C" int e4s_upconv_mfma_f32(const e4s_conv_params* pp, const float* k4, v
     const int ntn = p.Cout / BN;
     const int64_t mtiles = (int64_t)p.B * ((p.Hi + TAH - 1) / TAH) * ((p.Wi + TAW - 1) / TAW);
     if (mtiles <= 0) return 0;
+#ifdef E4S_ABLATIONS      // profiling builds only (E4S_BUILD_ABLATIONS=1 python -m e4s_amd.build): tools/upconv_ablate.py
     static const int abl = getenv("E4S_UPCONV_ABL") ? atoi(getenv("E4S_UPCONV_ABL")) : 0;
-    if (abl) {          // profiling only: wrong results by construction
+    if (abl) {          // wrong results by construction
         auto set = [](const void* f) { hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UpSmem)); };
         dim3 gr((unsigned)(mtiles * ntn)), bl(NTHR);
         if (abl == 1) { set((const void*)upconv_kernel<1>); hipLaunchKernelGGL(upconv_kernel<1>, gr, bl, sizeof(UpSmem), as_stream(stream), p, k4, ntn); }
@@ -286,6 +287,7 @@ extern "C" int e4s_upconv_mfma_f32(const e4s_conv_params* pp, const float* k4, v
         E4S_CHECK_LAUNCH();
         return 0;
     }
+#endif
     hipLaunchKernelGGL(upconv_kernel<0>, dim3((unsigned)(mtiles * ntn)), dim3(NTHR), sizeof(UpSmem), as_stream(stream), p, k4, ntn);
     E4S_CHECK_LAUNCH();
     return 0;

@@ -1,3 +1,5 @@
+"""Ablation timings of the split-bf16 conv kernel.  Needs a profiling build:
+    E4S_BUILD_ABLATIONS=1 python -m e4s_amd.build --force   (rebuild without the variable afterwards)"""
 import os, sys, subprocess, json
 code = r'''
 import os, sys, torch

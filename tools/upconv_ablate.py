@@ -1,4 +1,5 @@
-"""Time e4s_upconv_mfma_f32 on one layer shape; E4S_UPCONV_ABL selects an ablated kernel (profiling only)."""
+"""Time e4s_upconv_mfma_f32 on one layer shape; E4S_UPCONV_ABL selects an ablated kernel (profiling builds only:
+E4S_BUILD_ABLATIONS=1 python -m e4s_amd.build --force)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from e4s_amd import kernels as K
