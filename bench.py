@@ -171,6 +171,9 @@ def main():
                                                             "replaying one captured HIP graph")
     ap.add_argument("--opt-steps", type=int, default=5, help="configs[2] leg: time this many W+ optimisation steps "
                                                              "(cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam)")
+    ap.add_argument("--overlap-gather", action="store_true",
+                    help="N>1: double-buffered asynchronous all-gather (e4s_amd.shard.OverlappedGather) instead of one "
+                         "blocking all-gather per step; off by default until it has been measured on a multi-GPU node")
     ap.add_argument("--steps-only", action="store_true", help="only the timed steps (clean rocprofv3 kernel traces)")
     ap.add_argument("--probe-only", action="store_true", help="run only the headline-kernel probe (for rocprofv3)")
     ap.add_argument("--probe-reps", type=int, default=20)
@@ -216,13 +219,19 @@ def main():
         graphed = GraphedFaceSwap(net, B)
         swap = lambda *a, noise: graphed(*a, noise)          # copies the inputs into the graph's static buffers
 
+    overlap = shard.OverlappedGather(world * B) if (world > 1 and args.overlap_gather) else None
+
     def step():
         img = swap(*inputs[:5], noise=inputs[5])
-        if world > 1:
+        if overlap is not None:
+            overlap.submit(img)                       # step i's gather runs under step i+1's compute
+        elif world > 1:
             shard.gather_outputs(img, world * B)      # RCCL all_gather_into_tensor of [B,3,1024,1024] per rank
         return img
 
     def fence():
+        if overlap is not None:
+            overlap.drain()                           # every submitted gather completes inside the timed region
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -58,6 +58,48 @@ def gather_outputs(local, n_total, group=None):
     return torch.cat(parts, 0)
 
 
+class OverlappedGather:
+    """Asynchronous, double-buffered all-gather of per-step outputs (even shards).
+
+    `submit(local)` copies this rank's [b, ...] shard into a staging slot and starts the all-gather on the collective's
+    own stream (RCCL: its internal stream waits for the producer stream at enqueue), so step i's gather runs while step
+    i+1 computes; only the gather that used the same slot `depth` steps ago is waited for first, because its staging
+    and result buffers are about to be overwritten.  `drain()` waits for everything still in flight and returns the
+    newest gathered [n_total, ...] tensor.  The producer may overwrite `local` as soon as `submit` returns on its
+    stream (that is what a replayed HIP graph does with its static output buffer)."""
+
+    def __init__(self, n_total, group=None, depth=2):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if n_total % self.world:
+            raise ValueError("OverlappedGather needs equal shards (use gather_outputs for ragged batches)")
+        self.n_total, self.group, self.depth = n_total, group, depth
+        self.stage, self.out, self.work = [None] * depth, [None] * depth, [None] * depth
+        self.i = 0
+
+    def submit(self, local):
+        if self.world == 1:
+            self.out[0] = local
+            return
+        k = self.i % self.depth
+        if self.work[k] is not None:
+            self.work[k].wait()                       # slot k is reused: its previous gather must be complete
+        if self.stage[k] is None:
+            self.stage[k] = torch.empty_like(local, memory_format=torch.contiguous_format)
+            self.out[k] = local.new_empty((self.n_total,) + tuple(local.shape[1:]))
+        self.stage[k].copy_(local)
+        self.work[k] = dist.all_gather_into_tensor(self.out[k], self.stage[k], group=self.group, async_op=True)
+        self.i += 1
+
+    def drain(self):
+        if self.world == 1:
+            return self.out[0]
+        for w in self.work:
+            if w is not None:
+                w.wait()
+        self.work = [None] * self.depth
+        return self.out[(self.i - 1) % self.depth] if self.i else None
+
+
 def run_sharded(fn, tensors, group=None):
     """out = gather(fn(*shard(tensors))).  `fn` maps a shard of the inputs to [b_local, ...] outputs
     (e.g. functools.partial(e4s_amd.networks.face_swap_core, net))."""

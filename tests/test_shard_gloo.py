@@ -69,3 +69,39 @@ def test_gloo_world2_even_batch():
 
 def test_gloo_world2_ragged_batch():
     _run(5)
+
+
+def _worker_overlap(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = 3
+    og = shard.OverlappedGather(world * b)
+    static = torch.empty(b, 2, 4)                       # stands in for a replayed graph's static output buffer
+    ok = True
+    for step in range(5):
+        static.copy_(torch.full((b, 2, 4), float(10 * step + rank)))
+        og.submit(static)
+        static.fill_(-1.0)                              # the producer overwrites its buffer right after submit
+    out = og.drain()
+    want = torch.cat([torch.full((b, 2, 4), float(40 + r)) for r in range(world)], 0)
+    ok = ok and tuple(out.shape) == (world * b, 2, 4) and bool(torch.equal(out, want))
+    prev = og.out[(og.i - 2) % og.depth]               # the step before is still intact in the other slot
+    ok = ok and bool(torch.equal(prev, torch.cat([torch.full((b, 2, 4), float(30 + r)) for r in range(world)], 0)))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_overlapped_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
