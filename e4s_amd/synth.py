@@ -158,6 +158,64 @@ def synth_disc_state_dict(size=64, seed=0):
     return {k: synth_tensor("D." + k, s, kind, seed) for k, s, kind in disc_param_spec(size)}
 
 
+def gpen_channels(channel_multiplier=2, narrow=1.0):
+    """src/pretrained/gpen/face_model/gpen_model.py:411-422."""
+    return {4: int(512 * narrow), 8: int(512 * narrow), 16: int(512 * narrow), 32: int(512 * narrow),
+            64: int(256 * channel_multiplier * narrow), 128: int(128 * channel_multiplier * narrow),
+            256: int(64 * channel_multiplier * narrow), 512: int(32 * channel_multiplier * narrow),
+            1024: int(16 * channel_multiplier * narrow), 2048: int(8 * channel_multiplier * narrow)}
+
+
+def gpen_param_spec(size=512, style_dim=512, n_mlp=8, channel_multiplier=2, narrow=1.0):
+    """(key, shape, kind) of GPEN FullGenerator(size, style_dim, n_mlp, isconcat=True) -- gpen_model.py:380-690
+    (SURVEY.md 8(f) N2).  isconcat doubles the channels every StyledConv hands on (feat_multiplier = 2)."""
+    ch = gpen_channels(channel_multiplier, narrow)
+    log_size = int(math.log2(size))
+    g = "generator."
+    spec = []
+    for i in range(n_mlp):
+        spec += [(f"{g}style.{i + 1}.weight", (style_dim, style_dim), "randn_lr"), (f"{g}style.{i + 1}.bias", (style_dim,), "bias")]
+
+    def styled(pfx, cin, cout, up):
+        out = [(pfx + "conv.weight", (1, cout, cin, 3, 3), "randn")]
+        if up:
+            out.append((pfx + "conv.blur.kernel", (4, 4), "blur"))
+        out += [(pfx + "conv.modulation.weight", (cin, style_dim), "randn"), (pfx + "conv.modulation.bias", (cin,), "modbias"),
+                (pfx + "noise.weight", (1,), "noisew"), (pfx + "activate.bias", (2 * cout,), "bias")]
+        return out
+
+    def torgb(pfx, cin, up):
+        out = [(pfx + "bias", (1, 3, 1, 1), "bias")]
+        if up:
+            out.append((pfx + "upsample.kernel", (4, 4), "blur"))
+        out += [(pfx + "conv.weight", (1, 3, cin, 1, 1), "randn"), (pfx + "conv.modulation.weight", (cin, style_dim), "randn"),
+                (pfx + "conv.modulation.bias", (cin,), "modbias")]
+        return out
+    spec.append((g + "input.input", (1, ch[4], 4, 4), "randn"))
+    spec += styled(g + "conv1.", ch[4], ch[4], False) + torgb(g + "to_rgb1.", 2 * ch[4], False)
+    cin = ch[4]
+    for j, i in enumerate(range(3, log_size + 1)):
+        cout = ch[2 ** i]
+        spec += styled(f"{g}convs.{2 * j}.", 2 * cin, cout, True) + styled(f"{g}convs.{2 * j + 1}.", 2 * cout, cout, False)
+        cin = cout
+    cin = ch[4]
+    for j, i in enumerate(range(3, log_size + 1)):
+        spec += torgb(f"{g}to_rgbs.{j}.", 2 * ch[2 ** i], True)
+    spec += [("ecd0.0.0.weight", (ch[size], 3, 1, 1), "randn"), ("ecd0.0.1.bias", (ch[size],), "bias")]
+    cin = ch[size]
+    for j, i in enumerate(range(log_size, 2, -1), start=1):
+        cout = ch[2 ** (i - 1)]
+        spec += [(f"ecd{j}.0.0.kernel", (4, 4), "blur1"), (f"ecd{j}.0.1.weight", (cout, cin, 3, 3), "randn"),
+                 (f"ecd{j}.0.2.bias", (cout,), "bias")]
+        cin = cout
+    spec += [("final_linear.0.weight", (style_dim, ch[4] * 16), "randn"), ("final_linear.0.bias", (style_dim,), "bias")]
+    return spec
+
+
+def synth_gpen_state_dict(size=512, seed=0, **kw):
+    return {k: synth_tensor("GPEN." + k, s, kind, seed) for k, s, kind in gpen_param_spec(size, **kw)}
+
+
 def synth_latent_avg(out_size=1024, seed=0):
     n_latent = int(math.log2(out_size)) * 2 - 2
     return 0.1 * torch.randn(n_latent, 512, generator=_gen("latent_avg", seed))

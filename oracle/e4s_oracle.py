@@ -235,6 +235,52 @@ def discriminator_forward(sd, x, size, pfx=""):
 
 
 # --------------------------------------------------------------------------
+# GPEN FullGenerator (the other consumer of modulated conv / upfirdn2d / fused_bias_act)
+# --------------------------------------------------------------------------
+def gpen_full_generator(sd, x, size, n_mlp=8):
+    """FullGenerator.forward(inputs) with isconcat=True.  src/pretrained/gpen/face_model/gpen_model.py:671-690
+    (encoder + latent), :488-555 (decoder), :318-357 (StyledConv: conv -> cat(out, w*noise) -> FusedLeakyReLU over
+    2C channels), :359-377 (ToRGB).  x [B,3,size,size] -> (image [B,3,size,size], style latent w [B,style_dim]).
+    The "noise" of every decoder layer is the encoder feature map of the same resolution (:684-686)."""
+    log_size = int(math.log2(size))
+    feats = []
+    h = _d_conv_layer(sd, "ecd0.0.", x, 1, False)                       # ConvLayer == the Discriminator's, :558-606
+    feats.append(h)
+    for j in range(1, log_size - 1):
+        h = _d_conv_layer(sd, f"ecd{j}.0.", h, 3, True)
+        feats.append(h)
+    z = fused_leaky_relu(equal_linear(h.reshape(h.shape[0], -1), sd["final_linear.0.weight"], None),
+                         sd["final_linear.0.bias"])
+    noise = [f for f in feats for _ in range(2)][::-1][1:]              # :686-687
+    g = "generator."
+    w = z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)     # PixelNorm, :18-23
+    for i in range(n_mlp):                                              # EqualLinear(lr_mul=0.01, fused_lrelu), :139-172
+        w = fused_leaky_relu(equal_linear(w, sd[f"{g}style.{i + 1}.weight"], None, lr_mul=0.01),
+                             sd[f"{g}style.{i + 1}.bias"] * 0.01)
+
+    def styled(pfx, inp, nz, up):
+        out = modulated_conv2d(inp, w, sd[pfx + "conv.weight"], sd[pfx + "conv.modulation.weight"],
+                               sd[pfx + "conv.modulation.bias"], True, up)
+        out = torch.cat((out, sd[pfx + "noise.weight"] * nz), dim=1)
+        return fused_leaky_relu(out, sd[pfx + "activate.bias"])
+
+    def torgb(pfx, inp, skip):
+        out = modulated_conv2d(inp, w, sd[pfx + "conv.weight"], sd[pfx + "conv.modulation.weight"],
+                               sd[pfx + "conv.modulation.bias"], False, False) + sd[pfx + "bias"]
+        if skip is not None:
+            out = out + upfirdn2d(skip, sd[pfx + "upsample.kernel"], up=2, pad=(2, 1))
+        return out
+    out = sd[g + "input.input"].repeat(x.shape[0], 1, 1, 1)
+    out = styled(g + "conv1.", out, noise[0], False)
+    skip = torgb(g + "to_rgb1.", out, None)
+    for j in range(log_size - 2):
+        out = styled(f"{g}convs.{2 * j}.", out, noise[1 + 2 * j], True)
+        out = styled(f"{g}convs.{2 * j + 1}.", out, noise[2 + 2 * j], False)
+        skip = torgb(f"{g}to_rgbs.{j}.", out, skip)
+    return skip, w
+
+
+# --------------------------------------------------------------------------
 # Regional style encoder
 # --------------------------------------------------------------------------
 ENC_BLOCKS = ((64, 128, 3), (128, 256, 4), (256, 512, 14), (512, 512, 3))    # psp_encoders.py:242-247

@@ -93,6 +93,29 @@ def reference_modules():
     return ns
 
 
+def reference_gpen():
+    """The reference's GPEN model module (src/pretrained/gpen/face_model/gpen_model.py), imported in place; its op
+    package falls back to pure PyTorch on CPU."""
+    if "gpen" in _CACHE:
+        return _CACHE["gpen"]
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    import importlib
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
+    saved_path = list(sys.path)
+    sys.path[:] = [REF_ROOT] + [p for p in saved_path
+                                if not os.path.isfile(os.path.join(p or os.getcwd(), "src", "__init__.py"))]
+    try:
+        mod = importlib.import_module("src.pretrained.gpen.face_model.gpen_model")
+    finally:
+        sys.path[:] = saved_path
+        for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+            del sys.modules[k]
+    _CACHE["gpen"] = mod
+    return mod
+
+
 def make_opts(out_size=1024, remaining_layer_idx=13, num_seg_cls=12):
     return types.SimpleNamespace(fsencoder_type="psp", remaining_layer_idx=remaining_layer_idx,
                                  num_seg_cls=num_seg_cls, out_size=out_size, train_G=False,

@@ -12,6 +12,7 @@ What is pinned:
   net1024.pt  Net3(out_size=1024, K=13): the E4S-core swap (2x encoder, swap, MLPs, generator)
               on a face-like mask; image stored strided (::8) plus a full-res centre crop
   disc64.pt   Discriminator(64) (config 5): logits and the 4x4 feature map of a seeded batch of 4
+  gpen64.pt   GPEN FullGenerator(64, narrow=0.25): restored image of a seeded batch of 2
 """
 import os
 import sys
@@ -125,8 +126,28 @@ def disc_case(size=64):
     return dict(size=size, logits=d(x), feats=feats.clone())
 
 
+GPEN_CFG = dict(size=64, n_mlp=8, narrow=0.25)
+
+
+@torch.no_grad()
+def gpen_case():
+    """GPEN FullGenerator of the real reference at a CPU-sized configuration."""
+    m = ref_shim.reference_gpen()
+    c = GPEN_CFG
+    sd = synth.synth_gpen_state_dict(c["size"], n_mlp=c["n_mlp"], narrow=c["narrow"])
+    net = m.FullGenerator(c["size"], 512, c["n_mlp"], channel_multiplier=2, narrow=c["narrow"], device="cpu")
+    net.load_state_dict(sd, strict=True)
+    x = synth.synth_image(2, c["size"], tag="gpen")
+    img, _ = net(x)
+    return dict(cfg=c, img=img.clone())
+
+
 def main():
     torch.manual_seed(0)
+    if "--gpen-only" in sys.argv:
+        torch.save(gpen_case(), os.path.join(HERE, "gpen64.pt"))
+        print("gpen64.pt done")
+        return
     if "--disc-only" in sys.argv:
         torch.save(disc_case(64), os.path.join(HERE, "disc64.pt"))
         print("disc64.pt done")
@@ -139,6 +160,8 @@ def main():
     print("net1024.pt done")
     torch.save(disc_case(64), os.path.join(HERE, "disc64.pt"))
     print("disc64.pt done")
+    torch.save(gpen_case(), os.path.join(HERE, "gpen64.pt"))
+    print("gpen64.pt done")
 
 
 if __name__ == "__main__":

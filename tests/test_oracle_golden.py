@@ -80,3 +80,17 @@ def test_discriminator_matches_reference(golden):
         y = orc.discriminator_forward(sd, x, 64)
     assert tuple(y.shape) == (4, 1)
     assert float((y - g["logits"]).abs().max()) < 1e-5
+
+
+def test_gpen_full_generator_matches_reference(golden):
+    """SURVEY.md 8(f) N2 (next row): GPEN FullGenerator(64, narrow=0.25) of the real reference
+    (src/pretrained/gpen/face_model/gpen_model.py:628-690) -- the oracle for the widening step is pinned before any
+    HIP code for it exists."""
+    g = golden("gpen64.pt")
+    c = g["cfg"]
+    sd = synth.synth_gpen_state_dict(c["size"], n_mlp=c["n_mlp"], narrow=c["narrow"])
+    x = synth.synth_image(2, c["size"], tag="gpen")
+    with torch.no_grad():
+        y, w = orc.gpen_full_generator(sd, x, c["size"], c["n_mlp"])
+    assert tuple(y.shape) == (2, 3, c["size"], c["size"]) and tuple(w.shape) == (2, 512)
+    assert float((y - g["img"]).abs().max()) < 1e-5
