@@ -265,7 +265,7 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     return y
 
 
-def bf16x3_eligible(cin, cout, *, istride=1, ostride=1, ntaps=9, ncls=1, masked=False):
+def bf16x3_eligible(cin, cout, *, istride=1, ostride=1, ntaps=9, ncls=1):
     """Shapes e4s_conv_bf16x3_f32 covers (include/e4s_hip.h): natural-order 3x3, plain or polyphase up-conv, with or
     without a region label map."""
     return (cin % 32 == 0 and cout % 128 == 0 and istride == 1 and ntaps == 9
