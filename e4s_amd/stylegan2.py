@@ -11,8 +11,11 @@ chain of per-region ATen ops; it drives the fused HIP kernels of libe4s_hip.so
     ---------------------------------------------      -----------------------------------------
     modulation + materialised [B,Cout,Cin,3,3]          e4s_rowdot_f32 x2 on cached sum_k W^2
       weights + demod (276-281)
-    12 x grouped conv * one-hot mask (386-400)          ONE gathered-row MFMA GEMM (region plan)
-    conv_transpose2d + Blur/upfirdn2d (287-300)         4-phase 3x3 polyphase weights, same GEMM
+    12 x grouped conv * one-hot mask (386-400)          ONE implicit-GEMM launch with region-select inside
+                                                        (per-pixel style on the A fragment, d[region] in the
+                                                        epilogue); split-bf16 or exact-fp32 MFMA (E4S_PRECISION)
+    conv_transpose2d + Blur/upfirdn2d (287-300)         4-phase 3x3 polyphase weights on the same GEMM, or the
+                                                        exact tile-fused up-conv kernel
     NoiseInjection + FusedLeakyReLU (329-335, 404)      GEMM epilogue
     ToRGB conv + bias + Upsample(skip) (422-448)        e4s_torgb_f32
 
