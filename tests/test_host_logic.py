@@ -157,3 +157,21 @@ def test_split_bf16_three_product_error_model():
     scale = float(exact.abs().max())
     assert float((three - exact).abs().max()) < 2e-5 * scale
     assert float((one - exact).abs().max()) > 1e-3 * scale      # a single bf16 product is not enough for the 1e-3 path
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/e4s_hip.h must compile as C99 (what a cgo / ctypes-cffi / JNI binding
+    would include) and as C++, with no torch / HIP types in the signatures."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "inc.c"
+    src.write_text('#include "e4s_hip.h"\nint main(void) { return 0; }\n')
+    for cc, flags in (("gcc", ["-std=c99", "-x", "c"]), ("g++", ["-std=c++17", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not installed")
+        res = subprocess.run([cc] + flags + ["-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"),
+                              str(src)], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+    text = open(os.path.join(root, "include", "e4s_hip.h")).read()
+    assert "#include <torch" not in text and "#include <hip" not in text and "at::Tensor" not in text
