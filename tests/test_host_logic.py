@@ -175,3 +175,21 @@ def test_header_is_plain_c(tmp_path):
         assert res.returncode == 0, res.stderr
     text = open(os.path.join(root, "include", "e4s_hip.h")).read()
     assert "#include <torch" not in text and "#include <hip" not in text and "at::Tensor" not in text
+
+
+def test_plain_c_host_program_links_against_the_abi(tmp_path):
+    """examples/c_abi_demo.c -- a C99 host with no Python and no torch -- compiles with gcc and links against
+    libe4s_hip.so + the HIP runtime (it is not executed here: no GPU)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "e4s_amd", "libe4s_hip.so")
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include") or not os.path.isfile(lib):
+        pytest.skip("needs gcc, /opt/rocm and the built library")
+    exe = tmp_path / "c_abi_demo"
+    res = subprocess.run(["gcc", "-std=c99", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                          "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"),
+                          "-L" + os.path.join(root, "e4s_amd"), "-le4s_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                          "-o", str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert exe.is_file()
