@@ -102,6 +102,25 @@ def _pack(w):
     return w.permute(2, 3, 0, 1).reshape(1, kh * kw, cout, cin).contiguous()
 
 
+def test_plain_c_host_reproduces_kats_through_the_abi(tmp_path):
+    """examples/c_abi_demo.c (C99, no Python, no torch) built with gcc against libe4s_hip.so runs SURVEY.md 8(c)'s KAT5
+    and KAT2 on the GPU and checks them itself."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_demo"
+    libdir = os.path.join(root, "e4s_amd")
+    build = subprocess.run(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                            "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"),
+                            "-L" + libdir, "-le4s_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    assert "KAT5 and KAT2 reproduced" in run.stdout
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout,stride,spatial", [
     (2, 16, 16, 64, 128, 1, True), (2, 16, 16, 64, 128, 1, False), (1, 32, 32, 32, 64, 1, True),
     (1, 32, 32, 64, 32, 1, True), (1, 32, 32, 64, 32, 1, False), (2, 32, 32, 64, 64, 2, False),
