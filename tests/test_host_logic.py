@@ -193,3 +193,38 @@ def test_plain_c_host_program_links_against_the_abi(tmp_path):
                           "-o", str(exe)], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert exe.is_file()
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01d_bench_default_line.json is the JSON line `python bench.py` printed on the MI355X: it must carry the
+    driver's keys plus the `roofline` and `cpu_baseline` objects, with internally consistent numbers."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r01d_bench_default_line.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 0.01 * r["achieved"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["unit"] == d["unit"]
+    assert d["parity_max_abs_vs_oracle"] < 1e-3                      # the north-star bound, on the timed batch
+
+
+def test_bench_defaults_are_single_gpu_and_short():
+    """`python bench.py` with no flags: N = 1, a K/W that finish within minutes (the driver's contract)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    m = re.search(r'add_argument\("--gpus", type=int, default=(\d+)\)', src)
+    assert m and int(m.group(1)) == 1
+    steps = int(re.search(r'add_argument\("--steps", type=int, default=(\d+)\)', src).group(1))
+    warm = int(re.search(r'add_argument\("--warmup", type=int, default=(\d+)\)', src).group(1))
+    assert 1 <= steps <= 50 and 0 <= warm <= 10
