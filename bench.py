@@ -6,7 +6,8 @@ mask-guided 1024^2 generator, per swap.  Workload = BASELINE.json configs[3] sha
 names it (batch 64 over 8 GPUs = 8 swaps per GPU; weak scaling: per-GPU batch fixed) -- at N=1 that
 is 8 swaps on one GPU; the single-swap latency of configs[1] is reported alongside (`latency_b1_ms`).
 For N>1 each rank runs its shard and the ranks all-gather the [B/N,3,1024,1024] outputs over RCCL
-(the only collective on the path); timing is barrier+sync bracketed, max over ranks.
+(the only collective on the path; asynchronous and double-buffered, so step i's gather overlaps step i+1, and every
+gather is drained inside the timed region); timing is barrier+sync bracketed, max over ranks.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 ... bench.py --gpus 8
@@ -173,9 +174,10 @@ def main():
                                                             "replaying one captured HIP graph")
     ap.add_argument("--opt-steps", type=int, default=5, help="configs[2] leg: time this many W+ optimisation steps "
                                                              "(cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam)")
-    ap.add_argument("--overlap-gather", action="store_true",
-                    help="N>1: double-buffered asynchronous all-gather (e4s_amd.shard.OverlappedGather) instead of one "
-                         "blocking all-gather per step; off by default until it has been measured on a multi-GPU node")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N>1: one blocking all-gather per step instead of the default double-buffered asynchronous "
+                         "all-gather (e4s_amd.shard.OverlappedGather: step i's gather runs under step i+1's compute; "
+                         "every gather completes inside the timed region)")
     ap.add_argument("--steps-only", action="store_true", help="only the timed steps (clean rocprofv3 kernel traces)")
     ap.add_argument("--probe-only", action="store_true", help="run only the headline-kernel probe (for rocprofv3)")
     ap.add_argument("--probe-reps", type=int, default=20)
@@ -221,7 +223,7 @@ def main():
         graphed = GraphedFaceSwap(net, B)
         swap = lambda *a, noise: graphed(*a, noise)          # copies the inputs into the graph's static buffers
 
-    overlap = shard.OverlappedGather(world * B) if (world > 1 and args.overlap_gather) else None
+    overlap = shard.OverlappedGather(world * B) if (world > 1 and not args.sync_gather) else None
 
     def step():
         img = swap(*inputs[:5], noise=inputs[5])
@@ -263,7 +265,9 @@ def main():
                                     "bf16x3": "encoder stride-1 3x3 convs: 3 bf16 MFMAs per product on hi/lo-split "
                                               "fp32 operands, fp32 accumulate; everything else exact fp32",
                                     "auto": "as bf16x3 where the launch fills the chip (this batch), else exact fp32"
-                                    }[K.PRECISION], "parallelism": f"image-parallel x{world}" + (", RCCL all_gather of outputs" if world > 1 else "")}}
+                                    }[K.PRECISION], "parallelism": f"image-parallel x{world}" + (
+                          (", RCCL all_gather of outputs" + ("" if args.sync_gather else " overlapped with the next step"))
+                          if world > 1 else "")}}
     if rank == 0 and world == 1 and not args.steps_only:
         # configs[1]: single-swap latency
         one = [t[:1].contiguous() if torch.is_tensor(t) else [n[:1].contiguous() for n in t] for t in inputs]
