@@ -16,6 +16,7 @@ from torch import nn
 from torch.nn import Conv2d, InstanceNorm2d, MaxPool2d, Module, PReLU, ReLU, Sequential, Sigmoid, AdaptiveAvgPool2d
 
 from . import kernels as K
+from .packs import param_key
 
 
 class Bottleneck(namedtuple("Block", ["in_channel", "depth", "stride"])):
@@ -29,7 +30,7 @@ def get_block(in_channel, depth, num_units, stride=2):
 def _pack3x3(conv):
     """[Cout,Cin,3,3] -> [1,9,Cout,Cin] (cached on the module, invalidated by in-place updates)."""
     w = conv.weight
-    key = (w.data_ptr(), w._version)
+    key = param_key(w)
     if getattr(conv, "_e4s_pack", None) is None or conv._e4s_pack[0] != key:
         with torch.no_grad():
             conv._e4s_pack = (key, K.pack_taps(w.detach().float().contiguous()))

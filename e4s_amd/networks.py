@@ -12,6 +12,7 @@ from torch import nn
 
 from . import kernels as K
 from .encoders import FSEncoder_PSP
+from .packs import param_key
 from .stylegan2 import EqualLinear, Generator
 
 
@@ -66,7 +67,7 @@ class Net3(nn.Module):
     # ---- stacked LocalMLP weights ([R,O,K]) so the 24 small GEMMs become 2 launches -------------
     def _mlp_weights(self):
         ps = [t for m in self.MLPs for t in (m.mlp[0].weight, m.mlp[0].bias, m.mlp[2].weight, m.mlp[2].bias)]
-        key = tuple((t.data_ptr(), t._version) for t in ps)
+        key = param_key(*ps)
         if self._mlp_pack is None or self._mlp_pack[0] != key:
             with torch.no_grad():
                 w0 = torch.stack([m.mlp[0].weight.detach() for m in self.MLPs]).contiguous()

@@ -158,8 +158,7 @@ def polyphase_upconv_weights(w, blur_kernel):
     return torch.stack(phases, 0).contiguous()
 
 
-def _param_key(*tensors):
-    return tuple((t.data_ptr(), t._version) for t in tensors)
+from .packs import param_key as _param_key  # noqa: E402
 
 
 class ModulatedConv2d(nn.Module):

@@ -1,1 +1,3 @@
+from ..._overlay import extend as _extend
 
+_extend(__path__, "models/stylegan2")
