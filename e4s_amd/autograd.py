@@ -2,8 +2,8 @@
 
 scripts/optimization.py optimises the regional style vectors [1,12,1280] with Adam through
 `cal_style_codes` -> `gen_img` with the generator frozen (`train_G=False`, networks.py:63-66).  These
-Functions provide exactly that gradient: d(loss)/d(latent) for the generator and d/d(style_vectors) for the
-MLPs.  No weight gradients (config 5) yet.  The heavy lifting is native (e4s_conv_bwd_mfma_f32,
+Functions provide that gradient -- d(loss)/d(latent) for the generator and d/d(style_vectors) for the MLPs -- and,
+for config 5 (`train_G=True`), the gradients of every generator / LocalMLP parameter.  The heavy lifting is native (e4s_conv_bwd_mfma_f32,
 e4s_demod_grad_f32, e4s_torgb_bwd_*_f32, e4s_upfirdn2d_f32, e4s_fused_bias_act_f32); the [G,C]x[C,512]
 chain-rule GEMVs of the style prologue and the MLP transposes use torch.matmul (plain library GEMMs).
 """

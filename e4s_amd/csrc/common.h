@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "e4s_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -29,6 +30,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int xcd = bid & 7, slot = bid >> 3;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + slot;
+}
+
+// Kernels that need more than 64 KB of dynamic LDS must raise hipFuncAttributeMaxDynamicSharedMemorySize first.  The
+// attribute belongs to the function as loaded on ONE device, so it is set once per (kernel, device): `mask` (one static
+// per launch site) has a bit per device ordinal; atomics keep concurrent host threads safe.
+static inline int e4s_ensure_dyn_smem(const void* fn, int bytes, std::atomic<uint64_t>& mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    mask.fetch_or(bit, std::memory_order_release);
+    return 0;
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

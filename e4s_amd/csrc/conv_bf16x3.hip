@@ -578,13 +578,8 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
 
 int launch_region(const e4s_conv_params& p, hipStream_t st) {
     auto kern = conv_bf16x3_region_kernel;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_REGION);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> smem_set{0};
+    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), SMEM_REGION, smem_set)) return e;
     const int ntn = p.Cout / BN;
     const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + TH - 1) / TH) * tx_n;
     const int tiles_per_cls = p.B * per_img;
@@ -617,13 +612,8 @@ __global__ void split_bf16x2_kernel(const float* __restrict__ w, unsigned short*
 template <bool SCALED, int ABL = 0>
 int launch(const e4s_conv_params& p, hipStream_t st) {
     auto kern = conv_bf16x3_kernel<SCALED, ABL>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> smem_set{0};
+    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), SMEM_BYTES, smem_set)) return e;
     const int ntn = p.Cout / BN;
     const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + TH - 1) / TH) * tx_n;
     const int64_t blocks = (int64_t)p.B * per_img * ntn;

@@ -259,13 +259,8 @@ __global__ void pack_bwd_kernel(const float* __restrict__ w, float* __restrict__
 
 template <int BN>
 int launch_bwd(const e4s_conv_bwd_params& p, int mtiles, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<BN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BwdSmem<BN>));
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> smem_set{0};
+    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(conv_bwd_kernel<BN>), (int)sizeof(BwdSmem<BN>), smem_set)) return e;
     const int ntn = p.Cx / BN;
     hipLaunchKernelGGL(conv_bwd_kernel<BN>, dim3(mtiles * ntn), dim3(NTHR), sizeof(BwdSmem<BN>), st, p, ntn);
     E4S_CHECK_LAUNCH();

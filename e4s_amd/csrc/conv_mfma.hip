@@ -388,13 +388,8 @@ template <int BM, int BN, int WM, int WN, bool SPATIAL, int PF = 1>
 int launch(const e4s_conv_params& p, hipStream_t st) {
     using L = SmemLayout<BM, BN, SPATIAL>;
     auto kern = conv_mfma_kernel<BM, BN, WM, WN, SPATIAL, PF>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> smem_set{0};
+    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), L::BYTES, smem_set)) return e;
     const int ntn = p.Cout / BN;
     int mtiles, tiles_per_cls = 0;
     if (p.tiles) {

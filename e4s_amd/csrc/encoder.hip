@@ -90,17 +90,25 @@ __global__ void instnorm_partial_kernel(const float* __restrict__ x, double* __r
     if (pg == 0) {
         s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
         q = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-        unsafeAtomicAdd(&ws[((int64_t)b * C + c) * 2 + 0], s);
-        unsafeAtomicAdd(&ws[((int64_t)b * C + c) * 2 + 1], q);
+        // one slot per (b, c, split): the finalize pass adds the slots in split order, so the statistics (and with them
+        // the whole encoder) are bit-reproducible run to run -- no floating-point atomics
+        double* slot = ws + (((int64_t)b * C + c) * nsplit + split) * 2;
+        slot[0] = s;
+        slot[1] = q;
     }
 }
 
 __global__ void instnorm_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats,
-                                         float* __restrict__ pooled, int n, int HW, float eps) {
+                                         float* __restrict__ pooled, int n, int HW, float eps, int nsplit) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double mean = ws[i * 2] / HW;
-    double var = ws[i * 2 + 1] / HW - mean * mean;      // biased variance (InstanceNorm2d)
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nsplit; ++k) {
+        s += ws[((int64_t)i * nsplit + k) * 2];
+        q += ws[((int64_t)i * nsplit + k) * 2 + 1];
+    }
+    const double mean = s / HW;
+    double var = q / HW - mean * mean;                  // biased variance (InstanceNorm2d)
     if (var < 0.0) var = 0.0;
     const float mf = (float)mean;
     const float rstd = rsqrtf((float)var + eps);
@@ -275,21 +283,28 @@ extern "C" int e4s_conv3x3_small_f32(const float* x, const float* w, float* y, i
     return 0;
 }
 
+static int instnorm_nsplit(int B, int HW, int C) {
+    int nsplit = 2048 / (B * (C / 64) > 0 ? B * (C / 64) : 1);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > HW / 64) nsplit = HW / 64 > 0 ? HW / 64 : 1;
+    return nsplit;
+}
+
 extern "C" int e4s_instnorm_stats_f32(const float* x, float* stats, float* pooled, double* ws, int B, int HW, int C,
                                       float eps, void* stream) {
     if (C % 64) return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)B * C, st);
-    if (e != hipSuccess) return (int)e;
-    int nsplit = 2048 / (B * (C / 64));
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > HW / 64) nsplit = HW / 64 > 0 ? HW / 64 : 1;
+    const int nsplit = instnorm_nsplit(B, HW, C);
     hipLaunchKernelGGL(instnorm_partial_kernel, dim3(B * (C / 64) * nsplit), dim3(256), 0, st, x, ws, HW, C, nsplit);
     E4S_CHECK_LAUNCH();
     const int n = B * C;
-    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, stats, pooled, n, HW, eps);
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, stats, pooled, n, HW, eps, nsplit);
     E4S_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int64_t e4s_instnorm_ws_doubles(int B, int HW, int C) {
+    return (int64_t)2 * B * C * instnorm_nsplit(B, HW, C);
 }
 
 extern "C" int e4s_instnorm_apply_f32(const float* x, const float* stats, const float* gate, const float* res,

@@ -266,13 +266,8 @@ extern "C" int e4s_upconv_mfma_f32(const e4s_conv_params* pp, const float* k4, v
     if (p.Ho != 2 * p.Hi || p.Wo != 2 * p.Wi) return (int)hipErrorInvalidValue;
     if ((int64_t)p.B * p.Hi * p.Wi * p.Cin >= (1ll << 31)) return (int)hipErrorInvalidValue;
     if (p.labels && (p.groups_per_batch < 1 || p.groups_per_batch > 16)) return (int)hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UpSmem));
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> smem_set{0};
+    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(upconv_kernel<0>), (int)sizeof(UpSmem), smem_set)) return e;
     const int ntn = p.Cout / BN;
     const int64_t mtiles = (int64_t)p.B * ((p.Hi + TAH - 1) / TAH) * ((p.Wi + TAW - 1) / TAW);
     if (mtiles <= 0) return 0;

@@ -174,12 +174,16 @@ def rgb_weights(w, s, scale):
 
 
 # ---- mask plan -------------------------------------------------------------------------------
+FLAG_SINK = None      # int32[1] device tensor: while set (HIP-graph capture), every mask_labels call ORs its not-one-hot flag
+                      # into it instead of a fresh tensor, so that a replayed graph can still be validated afterwards
+
+
 def mask_labels(mask):
     """one-hot [B,R,Hm,Wm] fp32 -> (labels uint8 [B,Hm,Wm], flags int32[1]); flags!=0 => not one-hot."""
     mask = _f32(mask)
     b, r, hm, wm = mask.shape
     labels = torch.empty(b, hm, wm, device=mask.device, dtype=torch.uint8)
-    flags = torch.zeros(1, device=mask.device, dtype=torch.int32)
+    flags = FLAG_SINK if FLAG_SINK is not None else torch.zeros(1, device=mask.device, dtype=torch.int32)
     call("e4s_mask_labels", fptr(mask), ptr(labels), ptr(flags), b, r, hm, wm, stream())
     return labels, flags
 
@@ -382,7 +386,7 @@ def instnorm_stats(x, want_pooled=False, eps=1e-5):
     b, h, w, c = x.shape
     stats = torch.empty(b, c, 2, device=x.device, dtype=torch.float32)
     pooled = torch.empty(b, c, device=x.device, dtype=torch.float32) if want_pooled else None
-    ws = torch.empty(b * c * 2, device=x.device, dtype=torch.float64)
+    ws = torch.empty(lib.load().e4s_instnorm_ws_doubles(b, h * w, c), device=x.device, dtype=torch.float64)
     call("e4s_instnorm_stats_f32", fptr(x), fptr(stats), fptr(pooled), ptr(ws), b, h * w, c, float(eps), stream())
     return stats, pooled
 

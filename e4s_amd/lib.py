@@ -62,6 +62,7 @@ SIGNATURES = {
     "e4s_conv_bf16x3_f32": [ctypes.POINTER(ConvParams), c_p],
     "e4s_split_bf16x2_f32": [c_p, c_p, c_l, c_i, c_p],
     "e4s_upconv_blocks_per_cu": [],
+    "e4s_instnorm_ws_doubles": [c_i, c_i, c_i],
     "e4s_conv_bwd_mfma_f32": [ctypes.POINTER(ConvBwdParams), c_p],
     "e4s_pack_taps_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_demod_grad_f32": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
@@ -83,6 +84,8 @@ SIGNATURES = {
     "e4s_grouped_linear_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p],
 }
 
+INT64_RETURN = {"e4s_instnorm_ws_doubles"}       # size queries: return a count, not an error code
+
 _lib = None
 
 
@@ -102,7 +105,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_i
+        fn.restype = c_l if name in INT64_RETURN else c_i
     _lib = lib
     return lib
 

@@ -77,16 +77,24 @@ class Net3(nn.Module):
             self._mlp_pack = (key, w0, b0, w2, b2)
         return self._mlp_pack[1:]
 
-    def _require_no_grad(self, *tensors):
-        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-            raise NotImplementedError("autograd through the HIP path (SURVEY.md 8(f) N1) is not built yet; "
-                                      "use torch.no_grad()")
+    def _require_no_encoder_grad(self, img):
+        """The encoder has no backward yet (config 5's remaining piece): refuse loudly instead of detaching silently
+        when a gradient through get_style_vectors would be needed -- w.r.t. the image, or w.r.t. encoder parameters
+        that still require grad (Net3 leaves them trainable, networks.py:48).  Inference scripts call this under
+        torch.no_grad() (face_swap.py:150, optimization.py:186-188)."""
+        if not torch.is_grad_enabled():
+            return
+        if img.requires_grad or any(p.requires_grad for p in self.encoder.parameters()):
+            raise NotImplementedError(
+                "get_style_vectors under autograd: the regional encoder's backward is not built (generator and "
+                "LocalMLP gradients are: e4s_amd/autograd.py).  Call it under torch.no_grad(), or freeze the encoder "
+                "(for p in net.encoder.parameters(): p.requires_grad = False) to train G / the MLPs on fixed codes.")
 
     # ---- API ------------------------------------------------------------------------------------
     def get_style_vectors(self, img, mask):
         """networks.py:121-133: img [B,3,H,W] in [-1,1], one-hot mask [B,R,Hm,Wm] ->
         ([B,R,1280], zeros [B,512,16,16])."""
-        self._require_no_grad(img)
+        self._require_no_encoder_grad(img)
         with torch.no_grad():
             labels, flags = K.mask_labels(mask)
             if self.G.strict_mask and not torch.cuda.is_current_stream_capturing() and bool(flags.item()):
@@ -185,7 +193,14 @@ class GraphedFaceSwap:
     One swap is ~700 short kernel launches; at batch 1 the Python/ctypes enqueue cost (not the GPU) sets
     the latency.  Capture removes it: inputs are copied into static device buffers, the whole schedule
     (encoder x2, style swap, MLPs, generator) replays as one graph launch.  Weight re-packing caches must
-    be warm, so the first call runs eagerly twice before capturing."""
+    be warm, so the first call runs eagerly twice before capturing.
+
+    Preconditions a replay cannot check on the host without a sync: (1) the three parsing masks are one-hot
+    (labelMap2OneHot) -- the captured kernels OR a not-one-hot flag into `self.flags`; call `validate()` (one sync)
+    whenever convenient, it raises if any replay since the last call saw a soft mask (eager calls fall back to the
+    reference's R-pass formulation instead; a graph cannot); (2) the weights have not changed since capture -- the
+    graph bakes in the packed-weight pointers: build a new GraphedFaceSwap after an optimizer step / EMA update /
+    load_state_dict."""
 
     def __init__(self, net, batch, img_size=1024, mask_size=512, noise_batch=None):
         dev = next(net.parameters()).device
@@ -200,6 +215,7 @@ class GraphedFaceSwap:
             m[:, 0] = 1.0                                      # a valid one-hot mask for the warm-up runs
         nb = batch if noise_batch is None else noise_batch
         self.noise = [torch.zeros(nb, 1, n.shape[2], n.shape[3], device=dev) for n in net.G.make_noise()]
+        self.flags = torch.zeros(1, device=dev, dtype=torch.int32)
         self.graph = None
         self.out = None
 
@@ -220,7 +236,19 @@ class GraphedFaceSwap:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = face_swap_core(self.net, *self.static, noise=self.noise)
+            K.FLAG_SINK = self.flags
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.out = face_swap_core(self.net, *self.static, noise=self.noise)
+            finally:
+                K.FLAG_SINK = None
         self.graph.replay()
         return self.out
+
+    def validate(self):
+        """One host sync: raises if any replay since the last validate() was fed a mask that is not one-hot."""
+        bad = bool(self.flags.item())
+        self.flags.zero_()
+        if bad:
+            raise RuntimeError("GraphedFaceSwap was replayed with a parsing mask that is not one-hot: its outputs used "
+                               "hard argmax regions; run face_swap_core eagerly for soft masks")

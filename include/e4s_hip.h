@@ -222,9 +222,11 @@ int e4s_resize_bilinear_f32(const float* x, float* y, int B, int C, int Hi, int 
 int e4s_conv3x3_small_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout, void* stream);
 /* InstanceNorm2d statistics (biased var, eps): stats[b, c] = {mean, rstd}; x NHWC [B,HW,C].
  * pooled (optional) [B,C] = spatial mean of the normalised tensor (what SEModule's avg-pool sees).
- * ws: scratch, 2*B*C doubles (fp64 partial sums). */
+ * ws: scratch of e4s_instnorm_ws_doubles(B, HW, C) doubles: fp64 partial sums, one slot per (b, c, pixel split), added
+ * in a fixed order -- the statistics are bit-reproducible (no floating-point atomics). */
 int e4s_instnorm_stats_f32(const float* x, float* stats, float* pooled, double* ws, int B, int HW, int C,
                            float eps, void* stream);
+int64_t e4s_instnorm_ws_doubles(int B, int HW, int C);
 /* y = ((x - mean)*rstd) [* gate[b,c]] [+ res[b, (y*rs)*Wr + x*rs, c]] ; optional PReLU(slope[c]) last.
  * res is NHWC [B, H*rs, W*rs, C] sampled at stride rs (MaxPool2d(1, stride), helpers.py:125-126). */
 int e4s_instnorm_apply_f32(const float* x, const float* stats, const float* gate, const float* res,

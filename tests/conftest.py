@@ -27,3 +27,10 @@ def golden():
     def load(name):
         return torch.load(os.path.join(GOLDEN, name), map_location="cpu", weights_only=False)
     return load
+
+
+def unz(z):
+    """(zlib bytes, shape) of a uint8 fixture (tests/golden/make_golden.py:_z) -> uint8 tensor."""
+    import zlib
+    import numpy as np
+    return torch.from_numpy(np.frombuffer(zlib.decompress(z[0]), dtype=np.uint8).reshape(z[1]).copy())

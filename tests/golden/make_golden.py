@@ -13,6 +13,13 @@ What is pinned:
               on a face-like mask; image stored strided (::8) plus a full-res centre crop
   disc64.pt   Discriminator(64) (config 5): logits and the 4x4 feature map of a seeded batch of 4
   gpen64.pt   GPEN FullGenerator(64, narrow=0.25): restored image of a seeded batch of 2
+  realmask.pt the 1024^2 swap on the reference's REAL example parsing maps (example/input/faceswap/{source,target}_mask.png,
+              19 CelebAMask-HQ ids remapped to the 12 classes by src/datasets/dataset.py:153-209): thin brow / eye / lip /
+              teeth regions.  Holds the label maps (zlib), the swapped mask + hole map of src/utils/swap_face_mask.py:33-82,
+              the blending masks of scripts/face_swap.py:30-48,278-292 (src/utils/morphology.py dilation / erosion), the
+              swap's style vectors and image (strided + crops), its uint8 image (tensor2im, torch_utils.py:63-69), and the
+              gradient of a crop-sized MSE loss w.r.t. the [1,12,1280] style vectors through cal_style_codes -> gen_img
+              (scripts/optimization.py:209-232) computed by the reference's own autograd.
 """
 import os
 import sys
@@ -142,8 +149,79 @@ def gpen_case():
     return dict(cfg=c, img=img.clone())
 
 
+def _z(t):
+    """uint8 tensor -> (zlib bytes, shape): label maps and binary masks compress ~100x."""
+    import zlib
+    t = t.contiguous().to(torch.uint8)
+    return zlib.compress(t.numpy().tobytes(), 9), tuple(t.shape)
+
+
+def realmask_case():
+    import numpy as np
+    from PIL import Image
+    fs = ref_shim.import_reference_script("face_swap")         # the reference's script, imported as shipped
+    import importlib
+    ds = importlib.import_module("src.datasets.dataset")
+    to12 = getattr(ds, "__celebAHQ_masks_to_faceParser_mask_detailed")
+    ex = os.path.join(ref_shim.REF_ROOT, "example", "input", "faceswap")
+    D_mask = to12(np.array(Image.open(os.path.join(ex, "source_mask.png"))))
+    T_mask = to12(np.array(Image.open(os.path.join(ex, "target_mask.png"))))
+    swapped_msk, hole_map = fs.swap_head_mask_revisit_considerGlass(D_mask, T_mask)
+    K, out_size = 13, 1024
+    sd = synth.synth_state_dict(out_size, K)
+    lat = synth.synth_latent_avg(out_size)
+    net = ref_shim.build_reference_net3(sd, lat, out_size, K)
+    driven = synth.synth_image(1, 1024, tag="driven")
+    target = synth.synth_image(1, 1024, tag="target")
+    lab = lambda a: torch.from_numpy(np.ascontiguousarray(a)).long()[None, None]
+    dm, tm, sm = (synth.onehot(lab(a)) for a in (D_mask, T_mask, swapped_msk))
+    noise = synth.synth_noise(out_size)
+    rec = dict(out_size=out_size, K=K, D_mask=_z(lab(D_mask)[0, 0]), T_mask=_z(lab(T_mask)[0, 0]),
+               swapped_mask=_z(lab(swapped_msk)[0, 0]), hole_map=_z(torch.from_numpy((hole_map != 0).astype(np.uint8))))
+    with torch.no_grad():
+        d_sv, _ = net.get_style_vectors(driven, dm)
+        t_sv, _ = net.get_style_vectors(target, tm)
+        comp = sorted(set(range(12)) - {0, 4, 11, 10})
+        sv = fs.swap_comp_style_vector(t_sv, d_sv, comp)
+        codes = net.cal_style_codes(sv)
+        img, _, _ = net.gen_img(torch.zeros(1, 512, 32, 32), codes, sm, noise=noise)
+    rec.update(driven_sv=d_sv, target_sv=t_sv, swapped_sv=sv, img_stride8=img[:, :, ::8, ::8].clone(),
+               img_mean=img.mean((2, 3)), img_absmean=img.abs().mean((2, 3)))
+    # crops over the thin regions: eyes/brows (rows ~400-530) and mouth/teeth (rows ~620-750) of the 1024^2 image
+    rec["crops"] = {}
+    for name, (y0, x0) in dict(eyes=(400, 448), mouth=(620, 448), edge=(0, 0)).items():
+        rec["crops"][name] = (y0, x0, img[:, :, y0:y0 + 128, x0:x0 + 128].clone())
+    # --- post-processing of scripts/face_swap.py:278-292 by the reference's own code (N4) ---
+    sw = lab(swapped_msk)
+    mask_bg = fs.logical_or_reduce(*[sw == clz for clz in [0, 11, 4]])
+    is_fg = torch.logical_not(mask_bg)
+    is_fg[torch.from_numpy(hole_map == 255)[None][None]] = True
+    fg = is_fg.float()
+    for op in ("dilation", "expansion", "erosion"):
+        content, border, full = fs.create_masks(fg, outer_dilation=5, operation=op)
+        rec["masks_" + op] = dict(border=_z(border[0, 0]), full=_z(full[0, 0]))
+    rec["foreground"] = _z(fg[0, 0])
+    im = fs.torch_utils.tensor2im(img[0])                                    # PIL image, uint8 HWC
+    rec["img_u8_crop"] = (448, 448, torch.from_numpy(np.array(im))[448:576, 448:576].clone())
+    rec["img_u8_sum"] = int(np.array(im).astype(np.int64).sum())
+    # --- gradient of scripts/optimization.py's objective (MSE term on a crop) w.r.t. the style vectors ---
+    latent = t_sv.clone().requires_grad_(True)
+    codes = net.cal_style_codes(latent)
+    recon, _, _ = net.gen_img(torch.zeros(1, 512, 32, 32), codes, tm, noise=noise)
+    y0, x0, hw = 384, 384, 256
+    loss = torch.nn.functional.mse_loss(recon[:, :, y0:y0 + hw, x0:x0 + hw], target[:, :, y0:y0 + hw, x0:x0 + hw])
+    loss.backward()
+    rec["opt"] = dict(crop=(y0, x0, hw), loss=float(loss), grad=latent.grad.clone(),
+                      recon_stride8=recon.detach()[:, :, ::8, ::8].clone())
+    return rec
+
+
 def main():
     torch.manual_seed(0)
+    if "--realmask-only" in sys.argv:
+        torch.save(realmask_case(), os.path.join(HERE, "realmask.pt"))
+        print("realmask.pt done")
+        return
     if "--gpen-only" in sys.argv:
         torch.save(gpen_case(), os.path.join(HERE, "gpen64.pt"))
         print("gpen64.pt done")
@@ -162,6 +240,8 @@ def main():
     print("disc64.pt done")
     torch.save(gpen_case(), os.path.join(HERE, "gpen64.pt"))
     print("gpen64.pt done")
+    torch.save(realmask_case(), os.path.join(HERE, "realmask.pt"))
+    print("realmask.pt done")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,234 @@
+"""GPU parity tests of the path bench.py actually times (VERDICT r1 "next round" item 1):
+
+  * GraphedFaceSwap(net, 8) under the shipped default E4S_PRECISION=auto on 8 DISTINCT swaps -- every sample against
+    the CPU oracle at the north-star 1e-3 bound, sample 0 also against the real reference's golden output, graph
+    replay == eager bitwise;
+  * the masked exact up-conv kernel (e4s_upconv_mfma_f32 with a label map) at the resolutions it is selected for
+    (>= 256^2 outputs), on tiles that hold many regions;
+  * the 1024^2 swap on the reference's REAL example parsing maps (thin brow / eye / lip / teeth regions);
+  * the 1024^2 optimisation-step gradient against the real reference's autograd.
+"""
+import pytest
+import torch
+
+from conftest import unz
+from e4s_amd import synth
+from oracle import e4s_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def maxabs(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def _net(out_size=1024):
+    from e4s_amd.networks import Net3
+    from e4s_amd.options import make_opts
+    net = Net3(make_opts(out_size=out_size))
+    sd = synth.synth_state_dict(out_size, 13)
+    net.load_state_dict(sd, strict=True)
+    lat = synth.synth_latent_avg(out_size)
+    net.latent_avg = lat.to(DEV)
+    return net.to(DEV).eval(), sd, lat
+
+
+def _batch_of_distinct_swaps(n):
+    """Sample 0 = the inputs of tests/golden/net1024.pt; samples 1.. = other seeded images, masks and noise."""
+    driven = torch.cat([synth.synth_image(1, 1024, tag="driven")] +
+                       [synth.synth_image(1, 1024, seed=i, tag="tp_d") for i in range(1, n)])
+    target = torch.cat([synth.synth_image(1, 1024, tag="target")] +
+                       [synth.synth_image(1, 1024, seed=i, tag="tp_t") for i in range(1, n)])
+    masks = []
+    for which in range(3):
+        rows = [synth.synth_labels_face(1, 512, seed=which + 1)]
+        for i in range(1, n):
+            # odd samples: face-like maps; even samples: 16-px block-random maps (every region on every 64^2+ tile)
+            rows.append(synth.synth_labels_face(1, 512, seed=10 * i + which) if i % 2 else
+                        synth.synth_labels_blocks(1, 512, 32, seed=10 * i + which))
+        masks.append(synth.onehot(torch.cat(rows)))
+    per = [synth.synth_noise(1024, seed=i) for i in range(n)]
+    noise = [torch.cat([per[i][l] for i in range(n)]) for l in range(len(per[0]))]
+    return driven, masks[0], target, masks[1], masks[2], noise
+
+
+@torch.no_grad()
+def test_graphed_batch8_auto_precision_every_sample_vs_oracle(golden, monkeypatch):
+    from e4s_amd import kernels as K
+    from e4s_amd.networks import GraphedFaceSwap, face_swap_core
+    monkeypatch.setattr(K, "PRECISION", "auto")
+    n = 8
+    net, sd, lat = _net()
+    cpu_in = _batch_of_distinct_swaps(n)
+    dev_in = [t.to(DEV) if torch.is_tensor(t) else [x.to(DEV) for x in t] for t in cpu_in]
+    assert K.want_bf16x3(2 * n, 32, 32, 512, 512) and K.want_bf16x3(n, 64, 64, 512, 512)   # the policy is live at B=8
+    graphed = GraphedFaceSwap(net, n)
+    out_g = graphed(*dev_in[:5], dev_in[5]).clone()
+    out_g2 = graphed(*dev_in[:5], dev_in[5]).clone()
+    assert torch.equal(out_g, out_g2)                                  # replay is reproducible
+    out_e = face_swap_core(net, *dev_in[:5], noise=dev_in[5])
+    assert torch.equal(out_g, out_e)                                   # graph replay == eager launches, bitwise
+    # a second, different batch through the SAME captured graph (static buffers are really re-read)
+    perm = torch.arange(n - 1, -1, -1)
+    dev_perm = [t[perm.to(DEV)] if torch.is_tensor(t) else [x[perm.to(DEV)] for x in t] for t in dev_in]
+    out_p = graphed(*dev_perm[:5], dev_perm[5])
+    assert torch.equal(out_p, out_g[perm.to(DEV)])                     # also: batch position does not matter, bitwise
+    g = golden("net1024.pt")
+    c0 = 512 - 64
+    assert maxabs(out_g[:1, :, ::8, ::8], g["img_stride8"]) < 1e-3
+    assert maxabs(out_g[:1, :, c0:c0 + 128, c0:c0 + 128], g["img_crop"]) < 1e-3
+    torch.set_num_threads(min(torch.get_num_threads(), 16))
+    worst = 0.0
+    for i in range(n):
+        one = [t[i:i + 1] if torch.is_tensor(t) else [x[i:i + 1] for x in t] for t in cpu_in]
+        want = orc.face_swap_core(sd, *one[:5], lat, one[5], 1024, 13)
+        err = maxabs(out_g[i:i + 1], want)
+        worst = max(worst, err)
+        assert err < 1e-3, (i, err)                                    # north-star bound, every sample
+    print(f"GraphedFaceSwap B=8 auto: worst max-abs over 8 samples vs oracle {worst:.3e}")
+
+
+def _styled_sd(cin, cout, up, seed):
+    spec = [("conv.weight", (1, cout, cin, 3, 3), "randn"), ("conv.modulation.weight", (cin, 512), "randn"),
+            ("conv.modulation.bias", (cin,), "modbias"), ("noise.weight", (1,), "noisew"),
+            ("activate.bias", (cout,), "bias")]
+    sd = {k: synth.synth_tensor(k, s, kind, seed) for k, s, kind in spec}
+    if up:
+        sd["conv.blur.kernel"] = orc.make_blur_kernel() * 4
+    return sd
+
+
+@pytest.mark.parametrize("cin,cout,res,cells", [(64, 32, 128, 128), (128, 64, 128, 64), (256, 128, 128, 128)])
+@torch.no_grad()
+def test_masked_exact_upconv_kernel_at_256_vs_oracle(cin, cout, res, cells, monkeypatch):
+    """e4s_upconv_mfma_f32 WITH labels, output 256^2 (where stylegan2.py selects it), 12 regions in 4- or 8-px cells of the
+    512^2 map = 2- / 4-px cells at 256^2: every 12x28 output tile holds many regions (one pass per region present)."""
+    from e4s_amd import kernels as K
+    from e4s_amd.stylegan2 import StyledConv
+    monkeypatch.setattr(K, "PRECISION", "f32")
+    sd = _styled_sd(cin, cout, True, 21)
+    m = StyledConv(cin, cout, 3, 512, upsample=True, mask_op=True)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(9)
+    b = 2
+    x = torch.randn(b, cin, res, res, generator=g)
+    style = torch.randn(b, 12, 512, generator=g)
+    mask = synth.onehot(synth.synth_labels_blocks(b, 512, cells, seed=23))
+    noise = torch.randn(b, 1, 2 * res, 2 * res, generator=g)
+    want = orc.styled_conv(sd, "", x, style, mask, noise, True, True)
+    # the kernel under test, called directly
+    xd = K.nchw_to_nhwc(x.to(DEV))
+    labels, flags = K.mask_labels(mask.to(DEV))
+    assert int(flags.item()) == 0
+    mod = m.conv.modulation
+    s = K.modulate_vec(style.to(DEV).reshape(b * 12, -1), mod.weight, mod.bias)
+    pk = m.conv.packed()
+    d = K.demod_coefs(s, pk["wsq"], m.conv.scale)
+    got = K.upconv_mfma(xd, pk["w3"], cout, m.conv.blur.kernel, in_scale=s, out_scale=d, labels=labels, num_regions=12,
+                        noise=noise.to(DEV), noise_w=m.noise.weight, bias=m.activate.bias, act=1,
+                        alpha=m.activate.negative_slope, gain=m.activate.scale)
+    got = K.nhwc_to_nchw(got)
+    assert maxabs(got, want) < 5e-5, maxabs(got, want)
+    # the polyphase form of the same function agrees as well (two independent formulations)
+    poly = K.conv_mfma(xd, pk["w"], cout, labels=labels, num_regions=12, ncls=4, ostride=2, in_scale=s, out_scale=d,
+                       noise=noise.to(DEV), noise_w=m.noise.weight, bias=m.activate.bias, act=1,
+                       alpha=m.activate.negative_slope, gain=m.activate.scale)
+    assert maxabs(K.nhwc_to_nchw(poly), want) < 5e-5
+
+
+def _realmask_inputs(g):
+    lab = lambda z: unz(z).long()[None, None]
+    dm, tm, sm = (synth.onehot(lab(g[k])) for k in ("D_mask", "T_mask", "swapped_mask"))
+    driven = synth.synth_image(1, 1024, tag="driven")
+    target = synth.synth_image(1, 1024, tag="target")
+    return driven, dm, target, tm, sm, synth.synth_noise(1024)
+
+
+@pytest.mark.parametrize("precision,tol_sv", [("f32", 1e-4), ("bf16x3", 3e-4), ("auto", 3e-4)])
+@torch.no_grad()
+def test_net1024_swap_on_the_reference_example_masks(golden, monkeypatch, precision, tol_sv):
+    """The reference's own example parsing maps (example/input/faceswap/*_mask.png -> 12 classes): real thin regions
+    (brows 1230 px, eyes 1155 px, teeth 1302 px of 262144), empty regions (glasses; ears/ear-rings in the swapped
+    map), against the REAL reference's swap output."""
+    from e4s_amd import kernels as K
+    from e4s_amd.networks import face_swap_core, swap_comp_style_vector
+    monkeypatch.setattr(K, "PRECISION", precision)
+    g = golden("realmask.pt")
+    net, _, _ = _net()
+    driven, dm, target, tm, sm, noise = [t.to(DEV) if torch.is_tensor(t) else [x.to(DEV) for x in t]
+                                         for t in _realmask_inputs(g)]
+    d_sv, _ = net.get_style_vectors(driven, dm)
+    t_sv, _ = net.get_style_vectors(target, tm)
+    assert maxabs(d_sv, g["driven_sv"]) < tol_sv and maxabs(t_sv, g["target_sv"]) < tol_sv
+    # exact zeros for the empty regions (face_swap.py:132,136 tests them with == 0)
+    for sv, want in ((d_sv, g["driven_sv"]), (t_sv, g["target_sv"])):
+        empty = want.abs().sum(-1) == 0
+        assert bool(empty.any()) and float(sv.cpu()[empty].abs().max()) == 0.0
+    sv = swap_comp_style_vector(t_sv, d_sv, set(range(12)) - {0, 4, 11, 10})
+    assert maxabs(sv, g["swapped_sv"]) < tol_sv
+    img = face_swap_core(net, driven, dm, target, tm, sm, noise=noise)
+    errs = [maxabs(img[:, :, ::8, ::8], g["img_stride8"])]
+    for name, (y0, x0, crop) in g["crops"].items():
+        errs.append(maxabs(img[:, :, y0:y0 + 128, x0:x0 + 128], crop))
+    print(f"realmask {precision}: max-abs vs reference {max(errs):.3e}")
+    assert max(errs) < 1e-3, errs
+    assert maxabs(img.mean((2, 3)), g["img_mean"]) < 2e-4
+
+
+def test_opt_step_gradient_1024_vs_reference_autograd(golden, monkeypatch):
+    """scripts/optimization.py:209-232 at full size: d(MSE on a 256^2 crop)/d(style vectors [1,12,1280]) through
+    cal_style_codes -> gen_img (1024^2, real example mask, fixed noise), HIP backward vs the REAL reference's autograd.
+    Both sides are fp32; the reference's own summation noise at this depth is ~1e-3 of the gradient scale
+    (tests/test_gpu_parity.py::test_generator_backward_vs_oracle_autograd measures it against fp64)."""
+    from e4s_amd import kernels as K
+    monkeypatch.setattr(K, "PRECISION", "f32")
+    g = golden("realmask.pt")
+    net, _, _ = _net()
+    for p in net.parameters():
+        p.requires_grad = False
+    _, _, target, tm, _, noise = _realmask_inputs(g)
+    target, tm, noise = target.to(DEV), tm.to(DEV), [x.to(DEV) for x in noise]
+    latent = g["target_sv"].to(DEV).clone().requires_grad_(True)
+    codes = net.cal_style_codes(latent)
+    recon, _, _ = net.gen_img(None, codes, tm, noise=noise)
+    y0, x0, hw = g["opt"]["crop"]
+    loss = torch.nn.functional.mse_loss(recon[:, :, y0:y0 + hw, x0:x0 + hw], target[:, :, y0:y0 + hw, x0:x0 + hw])
+    loss.backward()
+    assert maxabs(recon[:, :, ::8, ::8], g["opt"]["recon_stride8"]) < 1e-3
+    assert abs(float(loss) - g["opt"]["loss"]) < 1e-4 * g["opt"]["loss"]
+    want = g["opt"]["grad"]
+    scale = float(want.abs().max())
+    err = maxabs(latent.grad, want)
+    print(f"opt-step gradient: max-abs err {err:.3e} of scale {scale:.3e}")
+    assert err < 2e-3 * scale, (err, scale)
+    # rows of empty regions get exactly no gradient through the generator (no pixel carries their style)
+    cos = torch.nn.functional.cosine_similarity(latent.grad.cpu().flatten(), want.flatten(), dim=0)
+    assert float(cos) > 0.99999
+
+
+@torch.no_grad()
+def test_graphed_swap_flags_soft_masks_and_guards_encoder_autograd():
+    from e4s_amd.networks import GraphedFaceSwap
+    net, _, _ = _net(256)
+    driven = synth.synth_image(1, 1024, tag="gs_d").to(DEV)
+    target = synth.synth_image(1, 1024, tag="gs_t").to(DEV)
+    hard = synth.onehot(synth.synth_labels_face(1, 512, seed=5)).to(DEV)
+    noise = [x.to(DEV) for x in synth.synth_noise(256)]
+    graphed = GraphedFaceSwap(net, 1)
+    graphed(driven, hard, target, hard, hard, noise)
+    graphed.validate()                                     # one-hot: fine
+    soft = torch.softmax(torch.randn(1, 12, 512, 512, device=DEV) * 3, 1)
+    graphed(driven, hard, target, hard, soft, noise)
+    with pytest.raises(RuntimeError):
+        graphed.validate()
+    graphed(driven, hard, target, hard, hard, noise)
+    graphed.validate()                                     # the flag was reset
+    with torch.enable_grad():                              # nothing detaches silently
+        with pytest.raises(NotImplementedError):
+            net.get_style_vectors(driven, hard)
+        for p in net.encoder.parameters():
+            p.requires_grad = False
+        sv, _ = net.get_style_vectors(driven, hard)        # frozen encoder: allowed
+        assert not sv.requires_grad
