@@ -32,20 +32,40 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-constexpr int NTHR = 512;
-constexpr int KC = 32;                 // input channels per stage
+constexpr int KC = 32;                 // input channels per chunk
 constexpr int ROWB = 144;              // LDS row bytes
 constexpr int LO = 64;                 // byte offset of the lo half inside a row
-constexpr int BM = 256, BN = 128;
-constexpr int TH = 16, TW = 16, HALO_W = TW + 2, HALO = (TH + 2) * HALO_W;     // 324 halo pixels
-constexpr int WN = 2, TM = 2, TN = 2;                                          // 4 x 2 waves, 2 x 2 blocks (64x64) each
-constexpr int BSTEP = NTHR / 8, BJ = BN / BSTEP;                               // B staging: rows br0 + BSTEP*j, j < BJ
-constexpr int ITEMS = HALO * 4;        // (halo pixel, 8-channel group) work items of one chunk = 1296
-constexpr int NPIECE = 9;               // the next chunk's halo is fetched and stored in 9 pieces, one per tap stage
-constexpr int PIECE = ITEMS / NPIECE;  // items per piece = 144
-constexpr int A_BYTES = HALO * ROWB, B_BYTES = BN * ROWB;
-constexpr int SMEM_BYTES = 2 * A_BYTES + 2 * B_BYTES + BM * 8;
-static_assert(PIECE * NPIECE == ITEMS && PIECE <= NTHR, "halo split");
+constexpr int TW = 16, HALO_W = TW + 2;
+constexpr int PBM = 256, PTH = 16, PHALO = (PTH + 2) * HALO_W;      // 16x16-pixel tiles, 324 halo pixels
+constexpr int PNTHR = 512;
+constexpr int PITEMS = PHALO * 4;      // (halo pixel, 8-channel group) work items of one chunk = 1296
+constexpr int PA_BYTES = PHALO * ROWB;
+
+// Column-tile configurations of the plain (one style per sample) kernel.  BN = GEMM columns per tile; TPS = taps per
+// pipeline stage (a stage = TPS taps x 32 input channels): the narrow tiles take three taps per stage so that a stage
+// still carries >= 18 MFMAs per wave between two barriers.
+//   <128, 4, 2, 1>  Cout % 128 == 0 (and the pixel-shuffled up-convs, N = 4 Cout): waves 64 x 64
+//   < 64, 4, 2, 3>  Cout % 64 == 0: waves 64 x 32        < 32, 8, 1, 3>  Cout % 32 == 0: waves 32 x 32
+template <int BN_, int WM_, int WN_, int TPS_>
+struct PCfg {
+    static constexpr int BN = BN_, WM = WM_, WN = WN_, TPS = TPS_;
+    static constexpr int TM = PBM / (WM * 32), TN = BN / (WN * 32);
+    static constexpr int NSTG = 9 / TPS;                      // stages per chunk
+    static constexpr int PIECE = PITEMS / NSTG;               // halo items of the NEXT chunk fetched per stage
+    static constexpr int BITEMS = TPS * BN * 8;               // 16-byte weight pieces per stage
+    static constexpr int BJ = (BITEMS + PNTHR - 1) / PNTHR;
+    static constexpr int B_BYTES = TPS * BN * ROWB;
+    static_assert(WM * WN * 64 == PNTHR && TM >= 1 && TN >= 1 && NSTG * TPS == 9, "wave layout");
+    static_assert(PIECE * NSTG == PITEMS && PIECE <= PNTHR, "halo split");
+};
+using CfgL = PCfg<128, 4, 2, 1>;
+using CfgM = PCfg<64, 4, 2, 3>;
+using CfgS = PCfg<32, 8, 1, 3>;
+
+template <typename C, bool SHUF>
+constexpr int plain_smem() {      // A x2, B x2, 3 x per-tile metadata {out offset int, noise float x (4 if SHUF)}
+    return 2 * PA_BYTES + 2 * C::B_BYTES + 3 * PBM * 4 * (1 + (SHUF ? 4 : 1));
+}
 
 __device__ __forceinline__ void split_store(unsigned char* dst, const f32x8 v) {
     const bf16x8 h = __builtin_convertvector(v, bf16x8);
@@ -55,78 +75,157 @@ __device__ __forceinline__ void split_store(unsigned char* dst, const f32x8 v) {
     *reinterpret_cast<bf16x8*>(dst + LO) = l;
 }
 
-// ABL: profiling ablations (builds with -DE4S_ABLATIONS select them with env E4S_BF16X3_ABL; results are wrong for
-// ABL != 0; product builds only instantiate ABL = 0): 1 no MFMAs, 2 no fragment reads,
-// 3 no global loads / LDS stores in the loop, 4 MFMAs only (no barrier either)
-template <bool SCALED, int ABL>
-__global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params p, const int ntn, const int tx_n,
-                                                           const int per_img) {
+__device__ __forceinline__ f32x8 load8(const float* src) {
+    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+    return f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+}
+
+struct TileId {          // one 16x16-pixel x BN-column output tile
+    int tb, tyb, txb, n0;
+};
+
+// Plain kernel, PERSISTENT: the grid is one block per CU (or fewer tiles); block b walks tiles b, b + grid, ... and the
+// stage pipeline runs straight through the tile boundary -- while the last chunk of tile t is contracted, the halo of
+// tile t+1's first chunk and the weights of its first stage are fetched, so neither the prologue loads nor the epilogue
+// stores of a tile are exposed (they were ~30 % of a K = 576 layer at one block per CU).
+// XF: what happens to a halo element on its way into LDS (before the hi/lo split):
+//   0 nothing; 1 v * in_scale[b][c] (one style per sample: unmasked StyledConv, model.py:655-657);
+//   2 (v - mean[b][c]) * rstd[b][c] (InstanceNorm2d of the encoder unit folded into its first conv, helpers.py:128-131;
+//     the same two fp32 operations e4s_instnorm_apply_f32 performs, so fused == unfused bitwise)
+// SHUF: polyphase up-conv (model.py:287-300 folded into 4 phase kernels) as ONE GEMM with N = 4 Cout columns
+//   (column n = phase * Cout + co) over the input grid, pixel-shuffled by the epilogue: output pixel (2ay+py, 2ax+px).
+template <typename C, int XF, bool SHUF>
+__global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_params p, const int ntn, const int tx_n,
+                                                            const int per_img, const int ntiles) {
+    constexpr int BM = PBM, BN = C::BN, NTHR = PNTHR, WN = C::WN, TM = C::TM, TN = C::TN, TH = PTH, TPS = C::TPS;
+    constexpr int NSTG = C::NSTG, PIECE = C::PIECE, BITEMS = C::BITEMS, BJ = C::BJ;
+    constexpr int A_BYTES = PA_BYTES, B_BYTES = C::B_BYTES, NZ = SHUF ? 4 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                          // [2][HALO][ROWB]
-    unsigned char* sB = smem + 2 * A_BYTES;            // [2][BN][ROWB]
-    int* s_out = reinterpret_cast<int*>(sB + 2 * B_BYTES);
-    float* s_nz = reinterpret_cast<float*>(s_out + BM);
+    unsigned char* sB = smem + 2 * A_BYTES;            // [2][TPS*BN][ROWB]
+    int* s_out = reinterpret_cast<int*>(sB + 2 * B_BYTES);            // [3][BM]
+    float* s_nz = reinterpret_cast<float*>(s_out + 3 * BM);           // [3][BM][NZ]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);
 
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = logical / ntn, nt = logical - mt * ntn;
-    const int n0 = nt * BN;
-    const int tb = mt / per_img;
-    const int rem = mt - tb * per_img;
-    const int tyb = rem / tx_n, txb = rem - tyb * tx_n;
+    auto decode = [&](int t) -> TileId {
+        TileId id;
+        const int mt = t / ntn, nt = t - mt * ntn;
+        id.n0 = nt * BN;
+        id.tb = mt / per_img;
+        const int rem = mt - id.tb * per_img;
+        id.tyb = rem / tx_n;
+        id.txb = rem - id.tyb * tx_n;
+        return id;
+    };
+    // per-row metadata of a tile: output offset and noise term(s) of each of the BM pixels
+    auto fill_meta = [&](int buf, const TileId& id) {
+        if (tid < BM) {
+            const int ay = id.tyb * TH + tid / TW, ax = id.txb * TW + tid % TW;
+            const bool valid = ay < p.Ha && ax < p.Wa;
+            const int oy = ay * p.ostride, ox = ax * p.ostride;
+            s_out[buf * BM + tid] = valid ? (id.tb * p.Ho + oy) * p.Wo + ox : -1;
+#pragma unroll
+            for (int ph = 0; ph < NZ; ++ph) {
+                float nz = 0.f;
+                if (valid && p.noise)
+                    nz = p.noise_w[0] * p.noise[(int64_t)id.tb * p.noise_bstride + (int64_t)(oy + (ph >> 1)) * p.Wo + ox + (ph & 1)];
+                s_nz[(buf * BM + tid) * NZ + ph] = nz;
+            }
+        }
+    };
 
-    // ---- per-row metadata: output offset and noise term of each of the 256 pixels ----
-    if (tid < BM) {
-        const int ay = tyb * TH + tid / TW, ax = txb * TW + tid % TW;
-        const bool valid = ay < p.Ha && ax < p.Wa;
-        s_out[tid] = valid ? (tb * p.Ho + ay) * p.Wo + ax : -1;
-        float nz = 0.f;
-        if (valid && p.noise) nz = p.noise_w[0] * p.noise[(int64_t)tb * p.noise_bstride + (int64_t)ay * p.Wo + ax];
-        s_nz[tid] = nz;
-    }
-
-    const int nchunk = p.Cin / KC, nstage = nchunk * 9;
-    const float* xb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin;
-    const float* sc = SCALED ? p.in_scale + (size_t)tb * p.Cin : nullptr;
+    const int nchunk = p.Cin / KC;
+    const int ngemm = SHUF ? 4 * p.Cout : p.Cout;
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(p.w);
     const size_t wrow = (size_t)p.Cin * 4;             // bytes per (tap, cout) row of the split weights
+    const size_t img_stride = (size_t)p.Hi * p.Wi * p.Cin;
 
-    // halo item -> (global offset in floats or -1, LDS byte offset)
-    auto item_src = [&](int item, bool& ok) -> size_t {
+    // halo item of tile `id` -> (global offset in floats inside the sample, or a dummy in-bounds one)
+    auto item_src = [&](const TileId& id, int item, bool& ok) -> size_t {
         const int h = item >> 2, q = item & 3;
         const int hy = h / HALO_W, hx = h - hy * HALO_W;
-        const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
+        const int iy = id.tyb * TH + hy - 1, ix = id.txb * TW + hx - 1;
         ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         return ok ? ((size_t)iy * p.Wi + ix) * p.Cin + q * 8 : (size_t)(q * 8);
     };
     auto item_dst = [&](int item) -> int { return (item >> 2) * ROWB + (item & 3) * 16; };
-    auto load8 = [&](const float* src) -> f32x8 {
-        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src);
-        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(src + 4);
-        return f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    // the per-channel transform operands of 8 channels starting at channel c of sample tb
+    struct XOp { f32x8 a, b; };
+    auto load_xop = [&](int tb, int c) -> XOp {
+        XOp o;
+        if (XF == 1) {
+            o.a = load8(p.in_scale + (size_t)tb * p.Cin + c);
+        } else if (XF == 2) {
+            const float* st = p.in_stats + ((size_t)tb * p.Cin + c) * 2;       // {mean, rstd} interleaved
+            const f32x8 s0 = load8(st), s1 = load8(st + 8);
+            o.a = f32x8{s0[0], s0[2], s0[4], s0[6], s1[0], s1[2], s1[4], s1[6]};
+            o.b = f32x8{s0[1], s0[3], s0[5], s0[7], s1[1], s1[3], s1[5], s1[7]};
+        }
+        return o;
     };
+    auto apply_xop = [&](f32x8 v, const XOp& o) -> f32x8 {
+        if (XF == 1) return v * o.a;
+        if (XF == 2) return (v - o.a) * o.b;
+        return v;
+    };
+    const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: whole halo of chunk 0 + weights of stage 0 ----
-    for (int item = tid; item < ITEMS; item += NTHR) {
-        bool ok;
-        const size_t off = item_src(item, ok);
-        f32x8 v = load8(xb + off);
-        if (SCALED) v *= load8(sc + (item & 3) * 8);
-        if (!ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        split_store(sA + item_dst(item), v);
+    // weight staging role: piece i = tid + NTHR*j -> LDS row i/8 (= tap_local*BN + n), 16-byte column i%8
+    int b_dst[BJ];
+    bool b_ok[BJ];
+    // global byte offset of (tap 0 of the stage, tile column 0) for each staged row; SHUF: column n = phase*Cout + co
+    // lives at weight set `phase` ([4][9][Cout][Cin])
+    auto b_src = [&](int j, int n0, int tap0, int chunk) -> size_t {
+        const int i = tid + NTHR * j;
+        const int row = b_ok[j] ? i >> 3 : 0, pc = i & 7;
+        const int tl = row / BN, n = n0 + (row - tl * BN);
+        size_t r;
+        if (SHUF) {
+            const int ph = n / p.Cout, co = n - ph * p.Cout;
+            r = ((size_t)(ph * 9 + tap0 + tl) * p.Cout + co);
+        } else {
+            r = (size_t)(tap0 + tl) * ngemm + n;
+        }
+        return r * wrow + (size_t)chunk * 128 + pc * 16;
+    };
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int i = tid + NTHR * j;
+        b_ok[j] = i < BITEMS;
+        b_dst[j] = b_ok[j] ? (i >> 3) * ROWB + (i & 7) * 16 : 0;
     }
-    const int bq = (tid & 7) * 16, br0 = tid >> 3;       // B staging role: 16-byte piece bq of rows br0 + BSTEP j
-    f32x4 pb[BJ];
+
+    if (first >= ntiles) return;
+    TileId cur = decode(first);
+    int t_next = first + G;
+    bool has_next = t_next < ntiles;
+    TileId nxt = decode(has_next ? t_next : first);
+
+    // ---- prologue: whole halo of tile 0 / chunk 0, weights of its stage 0, its metadata ----
     {
-        const unsigned char* wp = wbytes + (size_t)n0 * wrow + bq;
+        const float* xb = p.x + (size_t)cur.tb * img_stride;
+        for (int item = tid; item < PITEMS; item += NTHR) {
+            bool ok;
+            const size_t off = item_src(cur, item, ok);
+            f32x8 v = load8(xb + off);
+            if (XF) v = apply_xop(v, load_xop(cur.tb, (item & 3) * 8));
+            if (!ok) v = zero8;                                 // zero padding applies AFTER the transform (conv pad)
+            split_store(sA + item_dst(item), v);
+        }
+        f32x4 pb[BJ];
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
+        for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wbytes + b_src(j, cur.n0, 0, 0));
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(sB + (br0 + BSTEP * j) * ROWB + bq) = pb[j];
+        for (int j = 0; j < BJ; ++j)
+            if (b_ok[j]) *reinterpret_cast<f32x4*>(sB + b_dst[j]) = pb[j];
+        fill_meta(0, cur);
     }
     __syncthreads();
 
@@ -141,164 +240,183 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
     for (int tn = 0; tn < TN; ++tn) brow[tn] = ((wn * TN + tn) * 32 + li) * ROWB + kh * 16;
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-
-    // ---- stage loop: LDS holds stage s; the global loads of stage s+1 (weights; one piece of the next chunk's halo) are
-    // issued right after the first fragment reads, fly during the 48 MFMAs (~1500 cycles) and are written to the other
-    // LDS buffers at the end of the stage.  Loads are unconditional with dummy in-bounds addresses so that the waits
-    // stay counted.  (A two-register-set variant with the stores delayed by one more stage measured slower: the
-    // unrolled loop made the compiler shuttle the 128 accumulators between AGPRs and VGPRs every iteration.)
     struct Pref {
         f32x4 b[BJ];
-        f32x8 a, s;
+        f32x8 a;
+        XOp x;
         int dst;
         bool part, ok;     // part: this thread holds a halo item of a real next chunk; ok: the item is inside the image
     };
+    struct BFrag { bf16x8 h[TN], l[TN]; };
+    struct AFrag { bf16x8 h, l; };
     const bool piece_thr = tid < PIECE;
-    int tap = 0, chunk = 0;          // stage s
-    int t2 = 1, c2 = 0;              // stage s + 1
+    unsigned sg = 0, cg = 0;         // running stage / chunk counters: LDS buffer parities continue across tiles
+    int mbuf = 0;                    // metadata buffer of the current tile (3-deep ring)
 
-    Pref P;
-    auto stage = [&](const int s) {
-        const unsigned char* Ab = sA + (chunk & 1) * A_BYTES + ((tap / 3) * HALO_W + (tap % 3)) * ROWB;
-        const unsigned char* Bb = sB + (s & 1) * B_BYTES;
-        // One wave per SIMD: nothing else hides an LDS round trip (~120 cycles), so the fragment reads are software
-        // pipelined by hand -- the A fragments of MFMA group g+1 are requested before the 6 MFMAs (192 cycles) of group
-        // g are issued -- and the order is pinned with sched_barriers (left alone, the scheduler sinks each read to
-        // just before its first use and the matrix pipe idles ~90 cycles per group).
-        bf16x8 bh[2][TN], bl[2][TN], ah[2], al[2];
-        auto ldB = [&](int kk) {
+    for (;;) {
+        // metadata of the NEXT tile -> ring slot mbuf+1 (its previous reader, the epilogue two tiles back, is behind
+        // at least one full tile of barriers; the epilogue one tile back reads slot mbuf-1)
+        const int mnext = (mbuf + 1) % 3;
+        if (has_next) fill_meta(mnext, nxt);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            const bool last_chunk = (chunk + 1 == nchunk);
+            // owner of chunk cg+1 (whose halo is fetched during this chunk) and of the stage after this chunk's last
+            const TileId& own = last_chunk ? nxt : cur;
+            const bool have_nc = !last_chunk || has_next;
+            const float* xb_n = p.x + (size_t)own.tb * img_stride + (last_chunk ? 0 : (chunk + 1) * KC);
+            const int c_n = last_chunk ? 0 : chunk + 1;
+#pragma clang loop unroll_count(NSTG <= 3 ? NSTG : 1)
+            for (int ts = 0; ts < NSTG; ++ts) {
+                const unsigned char* Ab = sA + (cg & 1) * A_BYTES;
+                const unsigned char* Bb = sB + (sg & 1) * B_BYTES;
+                const bool last_ts = (ts + 1 == NSTG);
+                const bool more = !last_ts || have_nc;          // is there a stage after this one (weights to fetch)?
+                Pref P;
+                auto issue_loads = [&]() {
+                    // weights of the next stage: same chunk / next tap group, or tap group 0 of chunk cg+1 (own tile)
+                    const int n0_w = last_ts ? own.n0 : cur.n0;
+                    const int tap_w = last_ts ? 0 : (ts + 1) * TPS;
+                    const int ch_w = last_ts ? c_n : chunk;
+#pragma unroll
+                    for (int j = 0; j < BJ; ++j)
+                        P.b[j] = *reinterpret_cast<const f32x4*>(wbytes + b_src(j, more ? n0_w : cur.n0, more ? tap_w : 0,
+                                                                                more ? ch_w : 0));
+                    // piece `ts` of the halo of chunk cg+1
+                    const int item = ts * PIECE + (piece_thr ? tid : 0);
+                    bool ok;
+                    const size_t off = item_src(own, item, ok);
+                    P.a = load8((have_nc ? xb_n : p.x) + off);
+                    if (XF) P.x = load_xop(have_nc ? own.tb : 0, c_n * KC + (item & 3) * 8);
+                    P.ok = ok;
+                    P.part = have_nc && piece_thr;
+                    P.dst = item_dst(item);
+                };
+                // fragments: B of one sub-step u = (tap_local, kk) double-buffered across sub-steps, A of one MFMA group
+                // g = (u, tm) double-buffered across groups; the next group's reads are requested before the current
+                // group's MFMAs are issued, and the order is pinned (left alone, the scheduler sinks each read to just
+                // before its first use and the matrix pipe idles an LDS round trip per group)
+                auto ldB = [&](BFrag& F, int u) {
+                    const int tl = u >> 1, kk = u & 1;
+                    const unsigned char* Bt = Bb + tl * BN * ROWB + kk * 32;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        F.h[tn] = *reinterpret_cast<const bf16x8*>(Bt + brow[tn]);
+                        F.l[tn] = *reinterpret_cast<const bf16x8*>(Bt + brow[tn] + LO);
+                    }
+                };
+                auto ldA = [&](AFrag& F, int g) {
+                    const int u = g / TM, tm = g - u * TM;
+                    const int tap = ts * TPS + (u >> 1);
+                    const unsigned char* At = Ab + ((tap / 3) * HALO_W + (tap % 3)) * ROWB + (u & 1) * 32 + arow[tm];
+                    F.h = *reinterpret_cast<const bf16x8*>(At);
+                    F.l = *reinterpret_cast<const bf16x8*>(At + LO);
+                };
+                auto mfmas = [&](const AFrag& A, const BFrag& B, int tm) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B.h[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.l[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h[tn], acc[tm][tn], 0, 0, 0);
+                };
+                constexpr int NU = 2 * TPS, NGRP = NU * TM;   // sub-steps / MFMA groups (3*TN MFMAs each) per stage
+                BFrag B0, B1;
+                AFrag A0, A1;
+                ldB(B0, 0);
+                ldA(A0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < NGRP; ++g) {
+                    const int u = g / TM, tm = g - u * TM;
+                    AFrag& Ac = (g & 1) ? A1 : A0;
+                    AFrag& An = (g & 1) ? A0 : A1;
+                    BFrag& Bc = (u & 1) ? B1 : B0;
+                    BFrag& Bn = (u & 1) ? B0 : B1;
+                    if (g + 1 < NGRP) ldA(An, g + 1);
+                    if (tm == 0 && u + 1 < NU) ldB(Bn, u + 1);
+                    if (g == 0) issue_loads();
+                    mfmas(Ac, Bc, tm);
+                    if (g == 0) {
+                        // the global-load block (~100 address/SALU instructions) is spread between this group's MFMAs:
+                        // after a barrier all waves are in the same phase and nothing else would cover it
+#pragma unroll
+                        for (int i = 0; i < 3 * TN; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x126, 16, 0);     // then up to 16 VALU/SALU/VMEM-read/DS-read
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // -- VGPR -> LDS: weights of the next stage, halo piece of the next chunk --
+                if (more) {
+                    unsigned char* db = sB + ((sg + 1) & 1) * B_BYTES;
+#pragma unroll
+                    for (int j = 0; j < BJ; ++j)
+                        if (b_ok[j]) *reinterpret_cast<f32x4*>(db + b_dst[j]) = P.b[j];
+                }
+                if (P.part) {
+                    f32x8 v = P.a;
+                    if (XF) v = apply_xop(v, P.x);
+                    if (!P.ok) v = zero8;
+                    split_store(sA + ((cg + 1) & 1) * A_BYTES + P.dst, v);
+                }
+                __syncthreads();
+                ++sg;
+            }
+            ++cg;
+        }
+
+        // ---- epilogue of the tile: demod * acc + noise + bias, activation, NHWC store (pixel-shuffled if SHUF) ----
+        {
+            const int* so = s_out + mbuf * BM;
+            const float* sn = s_nz + mbuf * BM * NZ;
+            float osc[TN], bsv[TN], slp[TN];
+            int coff[TN], nzi[TN];
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                bh[kk][tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32);
-                bl[kk][tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32 + LO);
+                const int n = cur.n0 + (wn * TN + tn) * 32 + li;
+                int ph = 0, co = n;
+                if (SHUF) { ph = n / p.Cout; co = n - ph * p.Cout; }
+                osc[tn] = p.out_scale ? p.out_scale[(size_t)cur.tb * p.Cout + co] : 1.f;
+                bsv[tn] = p.bias ? p.bias[co] : 0.f;
+                slp[tn] = (p.act == 2) ? p.slope[co] : p.alpha;
+                coff[tn] = ((ph >> 1) * p.Wo + (ph & 1)) * p.Cout + co;
+                nzi[tn] = ph;
             }
-        };
-        auto ldA = [&](int g, int slot) {          // group g = (kk, tm)
-            const int kk = g / TM, tm = g % TM;
-            ah[slot] = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32);
-            al[slot] = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32 + LO);
-        };
-        if (ABL == 2 || ABL == 4) {
+            const float gain = (p.act == 1) ? p.gain : 1.f;
+            const bool do_act = p.act != 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = al[i] = *reinterpret_cast<const bf16x8*>(sA + arow[0]);
+            for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bh[i][tn] = bl[i][tn] = ah[i];
-            }
-        } else {
-            ldB(0);
-            ldA(0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        // -- global -> VGPR: weights of stage s+1, halo piece `tap` of chunk+1.  Issued after the first MFMA group so the
-        // matrix pipe starts right after the barrier; its ~90 address/SALU instructions are spread between the MFMAs of
-        // groups 0-1 (sched_group_barrier: 1 MFMA, then up to 8 others), because after a barrier all 8 waves are in
-        // the same phase and nothing else would cover them --
-        auto issue_loads = [&]() {
-        if (ABL < 3) {
-            const bool more2 = (s + 1 < nstage);
-            const unsigned char* wp =
-                wbytes + ((size_t)(more2 ? t2 : 0) * p.Cout + n0) * wrow + (size_t)(more2 ? c2 : 0) * 128 + bq;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int off = so[row];
+                    if (off < 0) continue;
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) P.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
-            const bool doA = (tap < NPIECE) && (chunk + 1 < nchunk);
-            const int item = min(tap, NPIECE - 1) * PIECE + (piece_thr ? tid : 0);
-            bool ok;
-            const size_t off = item_src(item, ok);
-            const int cnext = doA ? (chunk + 1) * KC : 0;
-            P.a = load8(xb + off + cnext);
-            if (SCALED) P.s = load8(sc + cnext + (item & 3) * 8);
-            P.ok = ok;
-            P.part = doA && piece_thr;
-            P.dst = item_dst(item);
-        }
-        if (ABL != 2 && ABL != 4) ldB(1);
-        };
-        // -- MFMAs of stage s: 4 groups of 6 --
-        auto mfma_group = [&](int g) {
-            const int kk = g / TM, tm = g % TM, cur = g & 1;
-            if (g + 1 < 2 * TM && ABL != 2 && ABL != 4) ldA(g + 1, cur ^ 1);
-            if (ABL == 1) {
-                acc[tm][0][0] += (float)ah[cur][0] + (float)al[cur][1] + (float)bh[kk][0][0] + (float)bl[kk][1][1];
-                return;
-            }
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[kk][tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
-        };
-        mfma_group(0);
-        issue_loads();
-        mfma_group(1);
-        if (ABL == 0) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x126, 8, 0);      // then up to 8 VALU / SALU / VMEM-read / DS-read
+                    for (int tn = 0; tn < TN; ++tn) {
+                        float v = acc[tm][tn][r] * osc[tn] + sn[row * NZ + (SHUF ? nzi[tn] : 0)] + bsv[tn];
+                        if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
+                        p.y[(size_t)off * p.Cout + coff[tn]] = v;
+                    }
+                }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(2);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(3);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // -- VGPR -> LDS --
-        if (ABL < 3 && s + 1 < nstage) {
-            unsigned char* db = sB + ((s + 1) & 1) * B_BYTES + br0 * ROWB + bq;
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(db + BSTEP * j * ROWB) = P.b[j];
-        }
-        if (ABL < 3 && P.part) {
-            f32x8 v = P.a;
-            if (SCALED) v *= P.s;
-            if (!P.ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            split_store(sA + ((chunk + 1) & 1) * A_BYTES + P.dst, v);
-        }
-        if (ABL != 4) __syncthreads();
-        if (++tap == 9) { tap = 0; ++chunk; }
-        if (++t2 == 9) { t2 = 0; ++c2; }
-    };
-    for (int s = 0; s < nstage; ++s) stage(s);
-
-    // ---- epilogue: demod * acc + noise + bias, activation, NHWC store ----
-    float osc[TN], bsv[TN], slp[TN];
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int col = n0 + (wn * TN + tn) * 32 + li;
-        osc[tn] = p.out_scale ? p.out_scale[(size_t)tb * p.Cout + col] : 1.f;
-        bsv[tn] = p.bias ? p.bias[col] : 0.f;
-        slp[tn] = (p.act == 2) ? p.slope[col] : p.alpha;
-    }
-    const float gain = (p.act == 1) ? p.gain : 1.f;
-    const bool do_act = p.act != 0;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int off = s_out[row];
-            if (off < 0) continue;
-            const float nz = s_nz[row];
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                float v = acc[tm][tn][r] * osc[tn] + nz + bsv[tn];
-                if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
-                p.y[(size_t)off * p.Cout + n0 + (wn * TN + tn) * 32 + li] = v;
-            }
-        }
+        if (!has_next) break;
+        cur = nxt;
+        mbuf = mnext;
+        t_next += G;
+        has_next = t_next < ntiles;
+        if (has_next) nxt = decode(t_next);
     }
 }
 
@@ -310,6 +428,13 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_kernel(const e4s_conv_params
 // registers for the 9 taps of a chunk) and splits the product into hi/lo bf16 on its way into the MFMAs: 32 VALU per
 // 6 MFMAs, which the second wave of the SIMD overlaps.  Weights arrive pre-split as in the kernel above; the
 // demodulation table d[region][co] is applied in the epilogue.
+constexpr int NTHR = 512;
+constexpr int BM = 256, BN = 128;
+constexpr int TH = 16, HALO = (TH + 2) * HALO_W;                               // 324 halo pixels
+constexpr int WN = 2, TM = 2, TN = 2;                                          // 4 x 2 waves, 2 x 2 blocks (64x64) each
+constexpr int BSTEP = NTHR / 8, BJ = BN / BSTEP;                               // B staging: rows br0 + BSTEP*j, j < BJ
+constexpr int ITEMS = HALO * 4;
+constexpr int A_BYTES = HALO * ROWB, B_BYTES = BN * ROWB;
 constexpr int MAXR = 16;
 constexpr int XITEMS = ITEMS + MAXR * 4;           // + the chunk's style slice s[r][32]: 16 regions x 4 groups of 8
 constexpr int XPIECE = (XITEMS + 8) / 9;           // 152 items per tap stage
@@ -609,18 +734,41 @@ __global__ void split_bf16x2_kernel(const float* __restrict__ w, unsigned short*
     *reinterpret_cast<bf16x8*>(d + 32) = l;
 }
 
-template <bool SCALED, int ABL = 0>
+int num_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (!cus[dev & 63]) {
+        hipDeviceProp_t prop;
+        cus[dev & 63] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                            ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev & 63];
+}
+
+template <typename C, int XF, bool SHUF>
 int launch(const e4s_conv_params& p, hipStream_t st) {
-    auto kern = conv_bf16x3_kernel<SCALED, ABL>;
+    auto kern = conv_bf16x3_kernel<C, XF, SHUF>;
+    constexpr int SMEM = plain_smem<C, SHUF>();
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
     static std::atomic<uint64_t> smem_set{0};
-    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), SMEM_BYTES, smem_set)) return e;
-    const int ntn = p.Cout / BN;
-    const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + TH - 1) / TH) * tx_n;
-    const int64_t blocks = (int64_t)p.B * per_img * ntn;
-    if (blocks <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM_BYTES, st, p, ntn, tx_n, per_img);
+    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), SMEM, smem_set)) return e;
+    const int ngemm = SHUF ? 4 * p.Cout : p.Cout;
+    const int ntn = ngemm / C::BN;
+    const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + PTH - 1) / PTH) * tx_n;
+    const int64_t ntiles = (int64_t)p.B * per_img * ntn;
+    if (ntiles <= 0) return 0;
+    if (ntiles >= (1ll << 31)) return (int)hipErrorInvalidValue;
+    const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());        // persistent: one block per CU
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PNTHR), SMEM, st, p, ntn, tx_n, per_img, (int)ntiles);
     E4S_CHECK_LAUNCH();
     return 0;
+}
+
+template <typename C, bool SHUF>
+int launch_xf(const e4s_conv_params& p, hipStream_t st) {
+    if (p.in_stats) return SHUF ? (int)hipErrorInvalidValue : launch<C, 2, false>(p, st);
+    return p.in_scale ? launch<C, 1, SHUF>(p, st) : launch<C, 0, SHUF>(p, st);
 }
 
 }  // namespace
@@ -628,27 +776,25 @@ int launch(const e4s_conv_params& p, hipStream_t st) {
 extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     const e4s_conv_params& p = *pp;
     const bool up = (p.ncls == 4);
-    if (p.Cin % KC || p.Cout % BN || p.ntaps != 9 || (p.ncls != 1 && !up) || p.istride != 1 ||
+    if (p.Cin % KC || p.Cout % 32 || p.ntaps != 9 || (p.ncls != 1 && !up) || p.istride != 1 ||
         p.ostride != (up ? 2 : 1) || p.tiles || p.noise_per_channel || p.Ha != p.Hi || p.Wa != p.Wi ||
-        p.Ho != p.Hi * p.ostride || p.Wo != p.Wi * p.ostride)
+        p.Ho != p.Hi * p.ostride || p.Wo != p.Wi * p.ostride || (p.in_stats && p.in_scale))
         return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
-    if (p.labels || up) {
-        if (!p.in_scale || p.act == 2 || (p.labels && (p.groups_per_batch < 1 || p.groups_per_batch > MAXR)))
+    if (p.labels) {                       // per-pixel regions: the region-select kernel (128-wide column tiles only)
+        if (!p.in_scale || p.in_stats || p.act == 2 || p.Cout % BN || p.groups_per_batch < 1 || p.groups_per_batch > MAXR)
             return (int)hipErrorInvalidValue;
         return launch_region(p, st);
     }
-#ifdef E4S_ABLATIONS      // profiling builds only (E4S_BUILD_ABLATIONS=1 python -m e4s_amd.build): tools/bench_abl.py
-    static const int abl = [] { const char* e = getenv("E4S_BF16X3_ABL"); return e ? atoi(e) : 0; }();
-    switch (abl) {
-        case 1: return launch<false, 1>(p, st);
-        case 2: return launch<false, 2>(p, st);
-        case 3: return launch<false, 3>(p, st);
-        case 4: return launch<false, 4>(p, st);
-        default: break;
+    // one style per sample (or none): the persistent plain kernel.  The polyphase up-conv (ncls = 4) is ONE GEMM with
+    // N = 4 Cout columns over the input grid + a pixel-shuffling epilogue.
+    if (up) {
+        if ((4 * p.Cout) % 128) return (int)hipErrorInvalidValue;
+        return launch_xf<CfgL, true>(p, st);
     }
-#endif
-    return p.in_scale ? launch<true>(p, st) : launch<false>(p, st);
+    if (p.Cout % 128 == 0) return launch_xf<CfgL, false>(p, st);
+    if (p.Cout % 64 == 0) return launch_xf<CfgM, false>(p, st);
+    return launch_xf<CfgS, false>(p, st);
 }
 
 extern "C" int e4s_split_bf16x2_f32(const float* w, void* out, int64_t rows, int cin, void* stream) {

@@ -37,14 +37,18 @@ def _pack3x3(conv):
     return conv._e4s_pack[1]
 
 
-def _conv3x3(x, conv, cout, **kw):
+def _conv3x3(x, conv, cout, in_stats=None, **kw):
     """Stride-1 3x3 conv (+ fused epilogue) in the configured arithmetic: the split-bf16 kernel where it applies and
-    K.PRECISION asks for it, the exact fp32-MFMA kernel otherwise."""
+    K.PRECISION asks for it, the exact fp32-MFMA kernel otherwise.  in_stats: InstanceNorm statistics of x -- the
+    normalisation (helpers.py:128-131) is folded into the split-bf16 kernel's halo staging, or runs as its own pass
+    (e4s_instnorm_apply_f32; the same two fp32 operations per element) in front of the fp32 kernel."""
     w = _pack3x3(conv)
     if K.want_bf16x3(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout):
         if getattr(conv, "_e4s_split", None) is None or conv._e4s_split[0] != conv._e4s_pack[0]:
             conv._e4s_split = (conv._e4s_pack[0], K.split_bf16x2(w))
-        return K.conv_mfma(x, w, cout, w_split=conv._e4s_split[1], **kw)
+        return K.conv_mfma(x, w, cout, w_split=conv._e4s_split[1], in_stats=in_stats, **kw)
+    if in_stats is not None:
+        x = K.instnorm_apply(x, in_stats)
     return K.conv_mfma(x, w, cout, **kw)
 
 
@@ -82,8 +86,7 @@ class bottleneck_IR_SE_Ours(Module):
         """x NHWC [B,H,W,Cin] -> NHWC [B,H/stride,W/stride,depth]."""
         conv1, prelu, conv2, se = self.res_layer[1], self.res_layer[2], self.res_layer[3], self.res_layer[5]
         st_x, _ = K.instnorm_stats(x)
-        xn = K.instnorm_apply(x, st_x)
-        r = _conv3x3(xn, conv1, self.depth, act=2, slope=prelu.weight)
+        r = _conv3x3(x, conv1, self.depth, in_stats=st_x, act=2, slope=prelu.weight)
         if self.stride == 1:
             r = _conv3x3(r, conv2, self.depth)
         else:

@@ -212,12 +212,14 @@ def region_plan(labels, num_regions, ha, wa, nphase):
 # ---- the conv --------------------------------------------------------------------------------
 def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, in_scale=None, out_scale=None,
               noise=None, noise_w=None, noise_per_channel=False, bias=None, slope=None, act=0, alpha=0.2,
-              gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1, w_split=None):
+              gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1, w_split=None, in_stats=None):
     """x NHWC [B,Hi,Wi,Cin]; w [ncls, ntaps, Cout, Cin] -> y NHWC [B,Ho,Wo,Cout].
     anchors = (Ha, Wa); defaults: up-conv (ncls=4) anchors = input grid, output 2x;
     strided conv anchors = output grid.
     w_split: the split-bf16 image of w (split_bf16x2); when given the contraction runs on e4s_conv_bf16x3_f32
-    (callers check bf16x3_eligible first -- an ineligible shape is an error, not a silent fp32 run)."""
+    (callers check bf16x3_eligible first -- an ineligible shape is an error, not a silent fp32 run).
+    in_stats: [B,Cin,2] InstanceNorm statistics of x; the normalisation is applied while the input is staged (split-bf16
+    kernel only)."""
     b, hi, wi, cin = x.shape
     if anchors is None:
         anchors = (hi // istride, wi // istride)
@@ -258,31 +260,39 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
         p.noise_per_channel = 0
     p.bias, p.slope = fptr(bias), fptr(slope)
     p.act, p.alpha, p.gain = act, alpha, gain
+    p.in_stats = fptr(in_stats)
     if w_split is not None:
-        if not bf16x3_eligible(cin, cout, istride=istride, ostride=ostride, ntaps=ntaps, ncls=ncls) \
-                or not spatial or noise_per_channel or ((labels is not None or ncls == 4) and in_scale is None):
+        if not bf16x3_eligible(cin, cout, istride=istride, ostride=ostride, ntaps=ntaps, ncls=ncls,
+                               masked=labels is not None) \
+                or not spatial or noise_per_channel or (labels is not None and in_scale is None) \
+                or (in_stats is not None and (in_scale is not None or labels is not None)):
             raise RuntimeError("e4s_conv_bf16x3_f32 does not cover this contraction")
         p.w = fptr(w_split)
         call("e4s_conv_bf16x3_f32", ctypes.byref(p), stream())
+    elif in_stats is not None:
+        raise RuntimeError("fused InstanceNorm staging exists only in e4s_conv_bf16x3_f32")
     else:
         call("e4s_conv_mfma_f32", ctypes.byref(p), 1 if spatial else 0, stream())
     return y
 
 
-def bf16x3_eligible(cin, cout, *, istride=1, ostride=1, ntaps=9, ncls=1):
-    """Shapes e4s_conv_bf16x3_f32 covers (include/e4s_hip.h): natural-order 3x3, plain or polyphase up-conv, with or
-    without a region label map."""
-    return (cin % 32 == 0 and cout % 128 == 0 and istride == 1 and ntaps == 9
+def bf16x3_eligible(cin, cout, *, istride=1, ostride=1, ntaps=9, ncls=1, masked=False):
+    """Shapes e4s_conv_bf16x3_f32 covers (include/e4s_hip.h): natural-order 3x3, plain or polyphase up-conv; column
+    tiles of 128 / 64 / 32 without a label map, 128 with one (region-select kernel)."""
+    return (cin % 32 == 0 and cout % (128 if masked else 32) == 0 and istride == 1 and ntaps == 9
             and (ncls, ostride) in ((1, 1), (4, 2)))
 
 
-def want_bf16x3(b, h, w, cin, cout, ncls=1):
+def want_bf16x3(b, h, w, cin, cout, ncls=1, masked=False):
     """Policy of PRECISION for a natural-order 3x3 conv (ncls = 4: polyphase up-conv) on [b,h,w,cin] -> cout."""
-    if PRECISION == "f32" or not bf16x3_eligible(cin, cout, ncls=ncls, ostride=2 if ncls == 4 else 1):
+    if PRECISION == "f32" or not bf16x3_eligible(cin, cout, ncls=ncls, ostride=2 if ncls == 4 else 1, masked=masked):
         return False
     if PRECISION == "bf16x3":
         return True
-    return b * ((h + 15) // 16) * ((w + 15) // 16) * (cout // 128) * ncls >= BF16X3_MIN_BLOCKS
+    # 256-pixel x 128/64/32-column tiles (unmasked polyphase up-conv: ONE GEMM with 4*Cout columns)
+    n = 4 * cout if (ncls == 4 and not masked) else cout
+    bn = 128 if n % 128 == 0 else 64 if n % 64 == 0 else 32
+    return b * ((h + 15) // 16) * ((w + 15) // 16) * (n // bn) * (ncls if masked else 1) >= BF16X3_MIN_BLOCKS
 
 
 def split_bf16x2(w):

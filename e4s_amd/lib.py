@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe4s_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -32,6 +32,7 @@ class ConvParams(ctypes.Structure):
         ("labels", c_p), ("Hm", c_i), ("Wm", c_i),
         ("noise", c_p), ("noise_w", c_p), ("noise_bstride", c_l), ("noise_per_channel", c_i),
         ("bias", c_p), ("slope", c_p), ("act", c_i), ("alpha", c_f), ("gain", c_f),
+        ("in_stats", c_p),
     ]
 
 

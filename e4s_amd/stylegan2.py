@@ -297,7 +297,8 @@ class StyledConv(nn.Module):
                 raise NotImplementedError("backward with per-channel noise maps")
             rec.update(d=d, noise=nz)
         ncls = 4 if conv.upsample else 1
-        if plan is None and not per_ch and K.want_bf16x3(b, h, w, conv.in_channel, conv.out_channel, ncls):
+        if plan is None and not per_ch and K.want_bf16x3(b, h, w, conv.in_channel, conv.out_channel, ncls,
+                                                         masked=labels is not None):
             # split-bf16 matrix-core path (polyphase form for up-convs: 4x the MACs of the exact kernel at > 3x its rate)
             return K.conv_mfma(x, pk["w"], conv.out_channel, labels=labels, num_regions=num_regions, ncls=ncls,
                                ostride=2 if conv.upsample else 1, in_scale=s, out_scale=d, noise=nz,

@@ -123,6 +123,9 @@ typedef struct {
     const float* slope;      /* [Cout] PReLU slopes (act == 2) */
     int act;                 /* 0 none, 1 leaky-relu(alpha)*gain, 2 PReLU */
     float alpha, gain;
+    const float* in_stats;   /* e4s_conv_bf16x3_f32 only: [B][Cin][2] {mean, rstd} (e4s_instnorm_stats_f32): the input is
+                                InstanceNorm-ed, (x - mean) * rstd, while it is staged (helpers.py:128-131 folded into the
+                                unit's first conv); excludes in_scale.  NULL elsewhere */
 } e4s_conv_params;
 
 /* y = epilogue( sum_{tap,ci} x[anchor*istride + tap - 1, ci] * in_scale[g,ci] * w[cls,tap,co,ci] )
@@ -144,10 +147,14 @@ int e4s_upconv_blocks_per_cu(void);    /* diagnostic: occupancy of that kernel a
 /* Split-bf16 ("bf16x3") variant of the natural-order 3x3 stride-1 contraction: every fp32 operand v = hi + lo (two bf16),
  * product = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with an fp32 accumulator (relative error per
  * product <= ~2^-16; 5.3x the fp32-MFMA rate).  Same params struct and epilogue as e4s_conv_mfma_f32(spatial = 1) with:
- * ntaps = 9, ncls = 1, istride = ostride = 1, labels = NULL (at most one style per sample: in_scale/out_scale are
- * [B][C]), noise_per_channel = 0, Cin % 32 == 0, Cout % 128 == 0, and p->w pointing at the SPLIT weights produced by
- * e4s_split_bf16x2_f32 from the [9][Cout][Cin] tap-packed fp32 weights.  Used for the encoder's Conv2d(+PReLU)
- * (helpers.py:128-137) and the unmasked StyledConvs (model.py:655-657). */
+ * ntaps = 9, istride = 1, noise_per_channel = 0, Cin % 32 == 0, Cout % 32 == 0, and p->w pointing at the SPLIT weights
+ * produced by e4s_split_bf16x2_f32 from the tap-packed fp32 weights ([9][Cout][Cin], or the polyphase [4][9][Cout][Cin]
+ * with ncls = 4, ostride = 2).  Variants:
+ *   labels == NULL  one style per sample at most (in_scale/out_scale [B][C]) or in_stats (fused InstanceNorm): the
+ *                   encoder's Conv2d(+PReLU) (helpers.py:128-137) and the unmasked StyledConvs incl. the 512^2 / 1024^2
+ *                   up-convs (model.py:655-657); column tile 128 / 64 / 32 by Cout
+ *   labels != NULL  region-select (per-pixel style on the A fragment): masked StyledConvs (model.py:386-400), plain or
+ *                   polyphase; Cout % 128 == 0, in_scale required, act != 2 */
 int e4s_conv_bf16x3_f32(const e4s_conv_params* p, void* stream);
 /* w fp32 [rows][cin] -> out [rows][cin/32][32 hi bf16 | 32 lo bf16] (same byte size), cin % 32 == 0 */
 int e4s_split_bf16x2_f32(const float* w, void* out, int64_t rows, int cin, void* stream);

@@ -153,6 +153,8 @@ def test_conv_mfma_1x1_stride2_and_prelu():
 @pytest.mark.parametrize("b,h,w,cin,cout,full", [
     (2, 32, 32, 64, 128, False), (1, 16, 16, 512, 512, True), (2, 8, 8, 128, 256, False),     # 8x8: partial 16x16 tile
     (1, 20, 40, 96, 128, True), (3, 4, 4, 32, 128, False),                                    # ragged tiles
+    (2, 32, 32, 64, 64, True), (1, 24, 40, 32, 32, True), (2, 16, 16, 128, 64, False), (1, 12, 20, 64, 32, False),
+    (1, 8, 16, 96, 96, True),                                      # 64- / 32-wide column tiles, 128-pixel tiles
 ])
 def test_conv_bf16x3_vs_conv2d_f64(b, h, w, cin, cout, full):
     """Split-bf16 contraction (3 bf16 MFMAs per product, fp32 accumulate) against an fp64 convolution.  Error model:
@@ -187,9 +189,57 @@ def test_conv_bf16x3_vs_conv2d_f64(b, h, w, cin, cout, full):
 def test_bf16x3_rejects_shapes_it_does_not_cover():
     from e4s_amd import kernels as K
     x = torch.zeros(1, 16, 16, 64, device=DEV)
-    w = torch.zeros(1, 9, 64, 64, device=DEV)
+    w = torch.zeros(1, 9, 48, 64, device=DEV)
     with pytest.raises(RuntimeError):
-        K.conv_mfma(x, w, 64, w_split=K.split_bf16x2(w))                 # Cout % 128 != 0
+        K.conv_mfma(x, w, 48, w_split=K.split_bf16x2(w))                 # Cout % 32 != 0
+    w = torch.zeros(1, 9, 64, 64, device=DEV)
+    labels = torch.zeros(1, 16, 16, device=DEV, dtype=torch.uint8)
+    s = torch.ones(12, 64, device=DEV)
+    with pytest.raises(RuntimeError):                                    # region-select needs 128-wide column tiles
+        K.conv_mfma(x, w, 64, w_split=K.split_bf16x2(w), labels=labels, num_regions=12, in_scale=s, out_scale=s)
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout", [(2, 32, 32, 64, 128), (1, 16, 48, 128, 128), (2, 8, 8, 256, 512)])
+def test_conv_bf16x3_fused_instnorm_equals_unfused_bitwise(b, h, w, cin, cout):
+    """in_stats: InstanceNorm folded into the halo staging == e4s_instnorm_apply_f32 followed by the same kernel, bit
+    for bit (the same (x - mean) * rstd in fp32 before the hi/lo split), incl. the zero padding of the NORMALISED map."""
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(33)
+    x = (torch.randn(b, h, w, cin, generator=g) * 2.0 + 0.7).to(DEV)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    slope = (torch.rand(cout, generator=g) * 0.5).to(DEV)
+    wp = _pack(wt).to(DEV)
+    ws = K.split_bf16x2(wp)
+    st, _ = K.instnorm_stats(x)
+    fused = K.conv_mfma(x, wp, cout, w_split=ws, in_stats=st, act=2, slope=slope)
+    unfused = K.conv_mfma(K.instnorm_apply(x, st), wp, cout, w_split=ws, act=2, slope=slope)
+    assert torch.equal(fused, unfused)
+    xn = F.instance_norm(x.permute(0, 3, 1, 2).double().cpu(), eps=1e-5)
+    want = F.prelu(F.conv2d(xn, wt.double(), padding=1), slope.double().cpu())
+    assert maxabs(K.nhwc_to_nchw(fused), want) < 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,res", [(128, 64, 32), (64, 32, 48), (256, 128, 16)])
+def test_unmasked_polyphase_upconv_bf16x3_vs_oracle(cin, cout, res, monkeypatch):
+    """Unmasked up-sampling StyledConv (the 512^2 / 1024^2 layers, model.py:655-657) on the plain split-bf16 kernel in
+    polyphase form (ncls = 4) with 128- / 64- / 32-wide column tiles, against the oracle's conv_transpose2d + blur."""
+    from e4s_amd import kernels as K
+    from e4s_amd.stylegan2 import StyledConv
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    sd = _styled_sd(cin, cout, True, 14)
+    m = StyledConv(cin, cout, 3, 512, upsample=True, mask_op=False)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, cin, res, res, generator=g)
+    style = torch.randn(2, 512, generator=g)
+    noise = torch.randn(2, 1, 2 * res, 2 * res, generator=g)
+    want = orc.styled_conv(sd, "", x, style, None, noise, True, False)
+    got = m(x.to(DEV), style.to(DEV), None, noise=noise.to(DEV))
+    monkeypatch.setattr(K, "PRECISION", "f32")
+    got32 = m(x.to(DEV), style.to(DEV), None, noise=noise.to(DEV))
+    assert 0.0 < maxabs(got, got32)
+    assert maxabs(got, want) < 1e-4 * float(want.abs().max())
 
 
 # ---------------------------------------------------------------------------------------------

@@ -127,7 +127,10 @@ def test_auto_precision_policy(monkeypatch):
     monkeypatch.setattr(K, "PRECISION", "auto")
     assert K.want_bf16x3(16, 32, 32, 512, 512)            # bench batch: 2 x 8 images -> 256 tiles
     assert not K.want_bf16x3(2, 32, 32, 512, 512)         # batch-1 latency run: 32 tiles -> exact fp32 kernel
-    assert not K.want_bf16x3(16, 256, 256, 64, 64)        # Cout % 128 != 0: no split-bf16 kernel
+    assert K.want_bf16x3(8, 512, 512, 64, 64)             # Cout 64 / 32: 128-pixel tiles, 64- / 32-wide column tiles
+    assert K.want_bf16x3(8, 512, 512, 64, 32, ncls=4)
+    assert not K.want_bf16x3(1, 64, 64, 64, 64)           # ... only where >= 512 of them exist
+    assert not K.want_bf16x3(8, 64, 64, 64, 64, masked=True)   # region-select kernel: 128-wide column tiles only
     assert K.want_bf16x3(8, 32, 32, 512, 512, ncls=4)     # polyphase up-conv: 4 phases count as tiles
     monkeypatch.setattr(K, "PRECISION", "f32")
     assert not K.want_bf16x3(16, 32, 32, 512, 512)
