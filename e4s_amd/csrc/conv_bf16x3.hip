@@ -715,6 +715,197 @@ int launch_region(const e4s_conv_params& p, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Gather variant: the encoder's stride-2 3x3 convs and 1x1 stride-2 shortcut convs (helpers.py:125-137).  With stride 2 an
+// input pixel feeds at most four outputs, so there is no halo to reuse: every stage (one tap x 32 channels) gathers its
+// own A tile -- 256 output pixels x 32 channels, one 128-byte segment per row -- splits it to hi/lo bf16 and stores it
+// next to the weights, both double buffered; the MFMA side is the plain kernel's.  Tile 256 pixels x 128 channels,
+// natural pixel order (tiles may straddle rows and samples), one block per CU.
+constexpr int GA_BYTES = BM * ROWB;                         // one A stage: 256 rows
+constexpr int SMEM_GATHER = 2 * GA_BYTES + 2 * B_BYTES + BM * 4;
+
+__global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv_params p, const int ntn,
+                                                                  const int npix) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                          // [2][BM][ROWB]
+    unsigned char* sB = smem + 2 * GA_BYTES;           // [2][BN][ROWB]
+    int* s_out = reinterpret_cast<int*>(sB + 2 * B_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = logical / ntn, nt = logical - mt * ntn;
+    const int n0 = nt * BN;
+    const int hw = p.Ha * p.Wa;
+
+    if (tid < BM) {
+        const int a = mt * BM + tid;
+        s_out[tid] = a < npix ? a : -1;                // ostride == 1: the output pixel index IS the anchor index
+    }
+    // A staging role: rows ar0 + 128 j (j < 2), 8-channel group aq
+    const int aq = tid & 3, ar0 = tid >> 2;
+    int a_base[2], a_yx[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int a = mt * BM + ar0 + 128 * j;
+        const bool valid = a < npix;
+        const int aa = valid ? a : 0;
+        const int b = aa / hw, rem = aa - b * hw;
+        const int ay = rem / p.Wa, ax = rem - ay * p.Wa;
+        const int by = ay * p.istride, bx = ax * p.istride;
+        a_base[j] = (b * p.Hi + by) * p.Wi + bx;
+        a_yx[j] = valid ? ((by << 16) | bx) : 0x7fff7fff;
+    }
+    const int ntaps = p.ntaps, nchunk = p.Cin / KC, nstage = ntaps * nchunk;
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(p.w);
+    const size_t wrow = (size_t)p.Cin * 4;
+    const int bq = (tid & 7) * 16, br0 = tid >> 3;
+    const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    struct Pref {
+        f32x4 b[BJ];
+        f32x8 a[2];
+        unsigned ok;
+    };
+    auto fetch = [&](Pref& P, int tap, int chunk) {
+        const unsigned char* wp = wbytes + ((size_t)tap * p.Cout + n0) * wrow + (size_t)chunk * 128 + bq;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) P.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
+        const int oy = (ntaps == 9) ? tap / 3 - 1 : 0, ox = (ntaps == 9) ? tap % 3 - 1 : 0;
+        unsigned okm = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int iy = (a_yx[j] >> 16) + oy, ix = (a_yx[j] & 0xffff) + ox;
+            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const size_t off = ok ? (size_t)(a_base[j] + oy * p.Wi + ox) * p.Cin : 0;
+            P.a[j] = load8(p.x + off + chunk * KC + aq * 8);
+            okm |= (ok ? 1u : 0u) << j;
+        }
+        P.ok = okm;
+    };
+    auto store = [&](const Pref& P, int buf) {
+        unsigned char* db = sB + buf * B_BYTES + br0 * ROWB + bq;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(db + BSTEP * j * ROWB) = P.b[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            split_store(sA + buf * GA_BYTES + (ar0 + 128 * j) * ROWB + aq * 16, ((P.ok >> j) & 1u) ? P.a[j] : zero8);
+    };
+
+    int arow[TM], brow[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) arow[tm] = ((wm * TM + tm) * 32 + li) * ROWB + kh * 16;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) brow[tn] = ((wn * TN + tn) * 32 + li) * ROWB + kh * 16;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    Pref P;
+    fetch(P, 0, 0);
+    store(P, 0);
+    __syncthreads();
+    int t1 = 0, c1 = 0;                      // stage s + 1
+    if (++t1 == ntaps) { t1 = 0; ++c1; }
+    for (int s = 0; s < nstage; ++s) {
+        const unsigned char* Ab = sA + (s & 1) * GA_BYTES;
+        const unsigned char* Bb = sB + (s & 1) * B_BYTES;
+        const bool more = s + 1 < nstage;
+        bf16x8 bh[2][TN], bl[2][TN], ah[2], al[2];
+        auto ldB = [&](int kk) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                bh[kk][tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32);
+                bl[kk][tn] = *reinterpret_cast<const bf16x8*>(Bb + brow[tn] + kk * 32 + LO);
+            }
+        };
+        auto ldA = [&](int g, int slot) {
+            const int kk = g / TM, tm = g % TM;
+            ah[slot] = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32);
+            al[slot] = *reinterpret_cast<const bf16x8*>(Ab + arow[tm] + kk * 32 + LO);
+        };
+        auto mfma_group = [&](int g) {
+            const int kk = g / TM, tm = g % TM, cur = g & 1;
+            if (g + 1 < 2 * TM) ldA(g + 1, cur ^ 1);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[kk][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
+        };
+        ldB(0);
+        ldA(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0);
+        fetch(P, more ? t1 : 0, more ? c1 : 0);       // unconditional (dummy stage 0 at the end): waits stay counted
+        ldB(1);
+        mfma_group(1);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x126, 10, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store(P, (s + 1) & 1);
+        __syncthreads();
+        if (++t1 == ntaps) { t1 = 0; ++c1; }
+    }
+
+    // ---- epilogue: bias, activation, NHWC store ----
+    float bsv[TN], slp[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + (wn * TN + tn) * 32 + li;
+        bsv[tn] = p.bias ? p.bias[col] : 0.f;
+        slp[tn] = (p.act == 2) ? p.slope[col] : p.alpha;
+    }
+    const float gain = (p.act == 1) ? p.gain : 1.f;
+    const bool do_act = p.act != 0;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int off = s_out[row];
+            if (off < 0) continue;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                float v = acc[tm][tn][r] + bsv[tn];
+                if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
+                p.y[(size_t)off * p.Cout + n0 + (wn * TN + tn) * 32 + li] = v;
+            }
+        }
+    }
+}
+
+int launch_gather(const e4s_conv_params& p, hipStream_t st) {
+    auto kern = conv_bf16x3_gather_kernel;
+    static std::atomic<uint64_t> smem_set{0};
+    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), SMEM_GATHER, smem_set)) return e;
+    const int ntn = p.Cout / BN;
+    const int64_t npix = (int64_t)p.B * p.Ha * p.Wa;
+    if (npix <= 0) return 0;
+    if (npix * ntn >= (1ll << 31)) return (int)hipErrorInvalidValue;
+    const int64_t blocks = ((npix + BM - 1) / BM) * ntn;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM_GATHER, st, p, ntn, (int)npix);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
 // fp32 rows [rows][cin] -> split rows [rows][cin/32][hi x32 | lo x32] (bf16), same byte size
 __global__ void split_bf16x2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int64_t n8,
                                     int cin) {
@@ -776,6 +967,13 @@ int launch_xf(const e4s_conv_params& p, hipStream_t st) {
 extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     const e4s_conv_params& p = *pp;
     const bool up = (p.ncls == 4);
+    if (p.istride == 2 || p.ntaps == 1) {      // encoder stride-2 3x3 / 1x1 shortcut convs: per-tap gather kernel
+        if (p.Cin % KC || p.Cout % BN || (p.ntaps != 9 && p.ntaps != 1) || p.ncls != 1 || p.ostride != 1 || p.tiles ||
+            p.labels || p.in_scale || p.out_scale || p.in_stats || p.noise || p.Ho != p.Ha || p.Wo != p.Wa ||
+            p.Hi >= 32767 || p.Wi >= 32767 || (p.Ha - 1) * p.istride >= p.Hi || (p.Wa - 1) * p.istride >= p.Wi)
+            return (int)hipErrorInvalidValue;
+        return launch_gather(p, as_stream(stream));
+    }
     if (p.Cin % KC || p.Cout % 32 || p.ntaps != 9 || (p.ncls != 1 && !up) || p.istride != 1 ||
         p.ostride != (up ? 2 : 1) || p.tiles || p.noise_per_channel || p.Ha != p.Hi || p.Wa != p.Wi ||
         p.Ho != p.Hi * p.ostride || p.Wo != p.Wi * p.ostride || (p.in_stats && p.in_scale))

@@ -52,6 +52,19 @@ def _conv3x3(x, conv, cout, in_stats=None, **kw):
     return K.conv_mfma(x, w, cout, **kw)
 
 
+def _conv_strided(x, conv, cout, stride, ntaps):
+    """The unit's stride-2 3x3 conv / 1x1 shortcut conv (helpers.py:125-137): per-tap gather kernels -- split-bf16 where
+    K.PRECISION asks for it and the launch has enough 256-pixel tiles, exact fp32 otherwise."""
+    w = _pack3x3(conv)
+    b, h, wd, _ = x.shape
+    tiles = (b * (h // stride) * (wd // stride) + 255) // 256 * (cout // 128 if cout % 128 == 0 else 0)
+    if K.PRECISION != "f32" and cout % 128 == 0 and (K.PRECISION == "bf16x3" or tiles >= K.BF16X3_MIN_BLOCKS):
+        if getattr(conv, "_e4s_split", None) is None or conv._e4s_split[0] != conv._e4s_pack[0]:
+            conv._e4s_split = (conv._e4s_pack[0], K.split_bf16x2(w))
+        return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps, w_split=conv._e4s_split[1])
+    return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps)
+
+
 class SEModule(Module):
     """helpers.py:56-72 (parameter holder; evaluated by e4s_se_gate_f32)."""
 
@@ -90,13 +103,13 @@ class bottleneck_IR_SE_Ours(Module):
         if self.stride == 1:
             r = _conv3x3(r, conv2, self.depth)
         else:
-            r = K.conv_mfma(r, _pack3x3(conv2), self.depth, istride=self.stride)
+            r = _conv_strided(r, conv2, self.depth, self.stride, 9)
         st_r, pooled = K.instnorm_stats(r, want_pooled=True)
         gate = K.se_gate(pooled, se.fc1.weight.view(se.fc1.weight.shape[0], -1),
                          se.fc2.weight.view(se.fc2.weight.shape[0], -1))
         if self.in_channel == self.depth:
             return K.instnorm_apply(r, st_r, gate=gate, res=x, rs=self.stride)      # MaxPool2d(1, stride)
-        sc = K.conv_mfma(x, _pack3x3(self.shortcut_layer[0]), self.depth, istride=self.stride, ntaps=1)
+        sc = _conv_strided(x, self.shortcut_layer[0], self.depth, self.stride, 1)
         st_sc, _ = K.instnorm_stats(sc)
         return K.instnorm_apply(r, st_r, gate=gate, res=sc, res_stats=st_sc)
 

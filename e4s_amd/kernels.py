@@ -229,7 +229,7 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
         spatial = plan is None and istride == 1 and ntaps == 9
     if labels is not None and not spatial:
         raise RuntimeError("per-pixel region labels need the spatial (halo-tiled) mode")
-    if plan is None and not spatial and (ha * wa) % BM != 0:
+    if plan is None and not spatial and (ha * wa) % BM != 0 and w_split is None:
         # natural-order tiles must not straddle samples: tiny grids go through a trivial one-region plan
         plan = region_plan(torch.zeros(b, 1, 1, device=x.device, dtype=torch.uint8), 1, ha, wa, ncls)
     y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32)
@@ -262,10 +262,14 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     p.act, p.alpha, p.gain = act, alpha, gain
     p.in_stats = fptr(in_stats)
     if w_split is not None:
-        if not bf16x3_eligible(cin, cout, istride=istride, ostride=ostride, ntaps=ntaps, ncls=ncls,
-                               masked=labels is not None) \
-                or not spatial or noise_per_channel or (labels is not None and in_scale is None) \
-                or (in_stats is not None and (in_scale is not None or labels is not None)):
+        gather_ok = (istride == 2 or ntaps == 1) and cin % 32 == 0 and cout % 128 == 0 and ncls == 1 and ostride == 1 \
+            and plan is None and labels is None and in_scale is None and out_scale is None and noise is None \
+            and in_stats is None
+        if not gather_ok and (
+                not bf16x3_eligible(cin, cout, istride=istride, ostride=ostride, ntaps=ntaps, ncls=ncls,
+                                    masked=labels is not None)
+                or not spatial or noise_per_channel or (labels is not None and in_scale is None)
+                or (in_stats is not None and (in_scale is not None or labels is not None))):
             raise RuntimeError("e4s_conv_bf16x3_f32 does not cover this contraction")
         p.w = fptr(w_split)
         call("e4s_conv_bf16x3_f32", ctypes.byref(p), stream())

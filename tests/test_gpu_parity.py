@@ -186,6 +186,27 @@ def test_conv_bf16x3_vs_conv2d_f64(b, h, w, cin, cout, full):
     assert err < 1e-4 * float(want.abs().max()), (err, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,ntaps", [(2, 32, 32, 128, 128, 9), (1, 16, 48, 256, 256, 9), (3, 8, 8, 64, 128, 1),
+                                                   (1, 20, 12, 128, 256, 1), (2, 6, 10, 512, 512, 9)])
+def test_conv_bf16x3_gather_stride2_vs_conv2d_f64(b, h, w, cin, cout, ntaps):
+    """The encoder's stride-2 3x3 convs and 1x1 stride-2 shortcut convs on the per-tap gather split-bf16 kernel (ragged
+    pixel counts: tiles straddle rows and samples) against an fp64 convolution, 1e-4 of the output scale."""
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(35)
+    k = 3 if ntaps == 9 else 1
+    x = torch.randn(b, cin, h, w, generator=g, dtype=torch.float64) * 1.1 - 0.1
+    wt = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64) / math.sqrt(cin * k * k)
+    wp = _pack(wt.float()).to(DEV)
+    xd = K.nchw_to_nhwc(x.float().to(DEV))
+    want = F.conv2d(x.float().double(), wt.float().double(), stride=2, padding=k // 2)
+    y = K.conv_mfma(xd, wp, cout, istride=2, ntaps=ntaps, w_split=K.split_bf16x2(wp))
+    y32 = K.conv_mfma(xd, wp, cout, istride=2, ntaps=ntaps)
+    assert tuple(y.shape) == (b, h // 2, w // 2, cout)
+    assert 0.0 < maxabs(y, y32)
+    err = maxabs(K.nhwc_to_nchw(y), want)
+    assert err < 1e-4 * float(want.abs().max()), (err, float(want.abs().max()))
+
+
 def test_bf16x3_rejects_shapes_it_does_not_cover():
     from e4s_amd import kernels as K
     x = torch.zeros(1, 16, 16, 64, device=DEV)

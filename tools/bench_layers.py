@@ -33,11 +33,28 @@ CASES = [("enc 64->128@256", 16, 256, 64, 128, "enc"), ("enc 128->128@128", 16, 
          ("enc 512->512@16", 16, 16, 512, 512, "enc"),
          ("gen 64->64@512", 8, 512, 64, 64, "same"), ("gen 32->32@1024", 8, 1024, 32, 32, "same"),
          ("gen up 128->64 ->512", 8, 256, 128, 64, "up"), ("gen up 64->32 ->1024", 8, 512, 64, 32, "up")]
+CASES += [("s2 128->128 @256->128", 16, 256, 128, 128, "s2"), ("s2 256->256 @128->64", 16, 128, 256, 256, "s2"),
+          ("s2 512->512 @64->32", 16, 64, 512, 512, "s2"), ("s2 512->512 @32->16", 16, 32, 512, 512, "s2"),
+          ("sc 64->128 @256->128", 16, 256, 64, 128, "sc"), ("sc 128->256 @128->64", 16, 128, 128, 256, "sc"),
+          ("sc 256->512 @64->32", 16, 64, 256, 512, "sc")]
 only = sys.argv[1:]
 for tag, b, res, cin, cout, kind in CASES:
     if only and not any(o in tag for o in only):
         continue
     x = torch.randn(b, res, res, cin, device=dev)
+    if kind in ("s2", "sc"):
+        nt = 9 if kind == "s2" else 1
+        w = torch.randn(1, nt, cout, cin, device=dev) / (nt * cin) ** 0.5
+        ws = K.split_bf16x2(w)
+        row = {"layer": tag, "gflop_alg": 2.0 * b * (res // 2) ** 2 * cin * cout * nt / 1e9,
+               "hbm_floor_ms": (x.numel() + b * (res // 2) ** 2 * cout) * 4 / 6.0e12 * 1e3}
+        row["f32_ms"] = timeit(lambda: K.conv_mfma(x, w, cout, istride=2, ntaps=nt))
+        row["bf16x3_ms"] = timeit(lambda: K.conv_mfma(x, w, cout, istride=2, ntaps=nt, w_split=ws))
+        row = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items()}
+        row["bf16x3_tflops_alg"] = round(row["gflop_alg"] / row["bf16x3_ms"], 1)
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+        continue
     ro = res * 2 if kind == "up" else res
     ncls = 4 if kind == "up" else 1
     w = torch.randn(ncls, 9, cout, cin, device=dev) / (3 * cin ** 0.5)
