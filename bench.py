@@ -172,8 +172,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the ~700 launches per step eagerly instead of "
                                                             "replaying one captured HIP graph")
-    ap.add_argument("--opt-steps", type=int, default=5, help="configs[2] leg: time this many W+ optimisation steps "
-                                                             "(cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam)")
+    ap.add_argument("--opt-steps", type=int, default=200,
+                    help="configs[2] leg: run this many W+ optimisation steps (scripts/optimization.py runs 200: "
+                         "cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam each) and report the measured total")
+    ap.add_argument("--f32-steps", type=int, default=5, help="also time this many steps with E4S_PRECISION=f32 (exact "
+                                                             "fp32 MFMA everywhere) and report value_f32 / ms_per_step_f32")
+    ap.add_argument("--gather-fp32", action="store_true",
+                    help="N>1: all-gather the fp32 [B,3,H,W] images (100 MB per 8 swaps) instead of the default uint8 HWC "
+                         "images the pipeline ends with (torch_utils.tensor2im, packed on the device: 25 MB)")
     ap.add_argument("--sync-gather", action="store_true",
                     help="N>1: one blocking all-gather per step instead of the default double-buffered asynchronous "
                          "all-gather (e4s_amd.shard.OverlappedGather: step i's gather runs under step i+1's compute; "
@@ -223,14 +229,16 @@ def main():
         graphed = GraphedFaceSwap(net, B)
         swap = lambda *a, noise: graphed(*a, noise)          # copies the inputs into the graph's static buffers
 
-    overlap = shard.OverlappedGather(world * B) if (world > 1 and not args.sync_gather) else None
+    from e4s_amd import postproc
+    pack = None if args.gather_fp32 else postproc.tensor2im
+    overlap = shard.OverlappedGather(world * B, pack=pack) if (world > 1 and not args.sync_gather) else None
 
     def step():
         img = swap(*inputs[:5], noise=inputs[5])
         if overlap is not None:
             overlap.submit(img)                       # step i's gather runs under step i+1's compute
-        elif world > 1:
-            shard.gather_outputs(img, world * B)      # RCCL all_gather_into_tensor of [B,3,1024,1024] per rank
+        elif world > 1:                               # RCCL all_gather_into_tensor of the rank's shard
+            shard.gather_outputs(img if pack is None else pack(img), world * B)
         return img
 
     def fence():
@@ -248,6 +256,8 @@ def main():
         img = step()
     fence()
     dt = time.perf_counter() - t0
+    if not args.no_graph:
+        graphed.validate()                            # the one-hot precondition of the replayed graph (one sync, untimed)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -266,7 +276,8 @@ def main():
                                               "fp32 operands, fp32 accumulate; everything else exact fp32",
                                     "auto": "as bf16x3 where the launch fills the chip (this batch), else exact fp32"
                                     }[K.PRECISION], "parallelism": f"image-parallel x{world}" + (
-                          (", RCCL all_gather of outputs" + ("" if args.sync_gather else " overlapped with the next step"))
+                          (", RCCL all_gather of the " + ("fp32 [B,3,H,W]" if args.gather_fp32 else "uint8 [B,H,W,3]")
+                           + " outputs" + ("" if args.sync_gather else " overlapped with the next step"))
                           if world > 1 else "")}}
     if rank == 0 and world == 1 and not args.steps_only:
         # configs[1]: single-swap latency
@@ -284,8 +295,31 @@ def main():
         torch.cuda.synchronize()
         out["latency_b1_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
         out["roofline"] = headline_probe(net, B, inputs[4], args.probe_reps)
+        if args.f32_steps > 0 and K.PRECISION != "f32" and not args.no_graph:
+            # the same step in exact fp32 (v_mfma_f32_32x32x2_f32 everywhere): a second captured graph under the f32 policy
+            saved = K.PRECISION
+            K.PRECISION = "f32"
+            try:
+                g32 = GraphedFaceSwap(net, B)
+                for _ in range(2):
+                    g32(*inputs[:5], inputs[5])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.f32_steps):
+                    img32 = g32(*inputs[:5], inputs[5])
+                torch.cuda.synchronize()
+                dt32 = (time.perf_counter() - t0) / args.f32_steps
+            finally:
+                K.PRECISION = saved
+            out["value_f32"] = round(B / dt32, 3)
+            out["ms_per_step_f32"] = round(dt32 * 1e3, 3)
+            out["max_abs_default_vs_f32"] = float((img32 - img).abs().max())
+            del g32
         if args.opt_steps > 0:
-            out["config3_opt_step_ms"] = optimisation_leg(net, one, args.opt_steps)
+            ms = optimisation_leg(net, one, args.opt_steps)
+            out["config3_opt_step_ms"] = ms
+            out["config3_steps_run"] = args.opt_steps
+            out["config3_total_s"] = round(ms * args.opt_steps / 1e3, 3)
         if not args.no_cpu_baseline:
             cb, err = cpu_baseline(sd, lat, inputs, img[0:1], img1[0:1])
             out["cpu_baseline"] = cb

@@ -82,6 +82,13 @@ SIGNATURES = {
     "e4s_instnorm_apply_f32": [c_p] * 7 + [c_i] * 5 + [c_p],
     "e4s_se_gate_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_region_mean_f32": [c_p, c_p, c_i, c_i, c_p] + [c_i] * 7 + [c_p],
+    "e4s_onehot_u8_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_swap_head_mask_u8": [c_p, c_p, c_p, c_p, c_l, c_p],
+    "e4s_foreground_mask_f32": [c_p, c_p, c_p, c_l, c_p],
+    "e4s_morph_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_create_masks_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "e4s_tensor2im_u8": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "e4s_paste_u8": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_grouped_linear_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p],
 }
 

@@ -68,25 +68,36 @@ class OverlappedGather:
     newest gathered [n_total, ...] tensor.  The producer may overwrite `local` as soon as `submit` returns on its
     stream (that is what a replayed HIP graph does with its static output buffer)."""
 
-    def __init__(self, n_total, group=None, depth=2):
+    def __init__(self, n_total, group=None, depth=2, pack=None):
+        """pack: optional callable (local, out=None) -> packed tensor written straight into the staging slot -- e.g.
+        e4s_amd.postproc.tensor2im, which turns the fp32 [b,3,H,W] shard into the uint8 [b,H,W,3] image the pipeline
+        ends with (scripts/face_swap.py:276, torch_utils.tensor2im): the collective then moves a quarter of the bytes
+        and the fp32 -> staging copy disappears (the pack kernel IS the copy)."""
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if n_total % self.world:
             raise ValueError("OverlappedGather needs equal shards (use gather_outputs for ragged batches)")
-        self.n_total, self.group, self.depth = n_total, group, depth
+        self.n_total, self.group, self.depth, self.pack = n_total, group, depth, pack
         self.stage, self.out, self.work = [None] * depth, [None] * depth, [None] * depth
         self.i = 0
 
     def submit(self, local):
         if self.world == 1:
-            self.out[0] = local
+            self.out[0] = self.pack(local) if self.pack is not None else local
             return
         k = self.i % self.depth
         if self.work[k] is not None:
             self.work[k].wait()                       # slot k is reused: its previous gather must be complete
-        if self.stage[k] is None:
-            self.stage[k] = torch.empty_like(local, memory_format=torch.contiguous_format)
-            self.out[k] = local.new_empty((self.n_total,) + tuple(local.shape[1:]))
-        self.stage[k].copy_(local)
+        if self.pack is not None:
+            if self.stage[k] is None:
+                self.stage[k] = self.pack(local)      # first use of the slot allocates it
+                self.out[k] = self.stage[k].new_empty((self.n_total,) + tuple(self.stage[k].shape[1:]))
+            else:
+                self.pack(local, out=self.stage[k])
+        else:
+            if self.stage[k] is None:
+                self.stage[k] = torch.empty_like(local, memory_format=torch.contiguous_format)
+                self.out[k] = local.new_empty((self.n_total,) + tuple(local.shape[1:]))
+            self.stage[k].copy_(local)
         self.work[k] = dist.all_gather_into_tensor(self.out[k], self.stage[k], group=self.group, async_op=True)
         self.i += 1
 

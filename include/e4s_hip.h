@@ -216,6 +216,29 @@ int e4s_noise_bias_act_nhwc_f32(const float* x, const float* noise, const float*
                                 const float* bias, float* y, int B, int HW, int C, float alpha, float gain,
                                 void* stream);
 
+/* ---- device pre/post-processing of the face-swap pipeline ------------------------------- */
+/* labelMap2OneHot (src/utils/torch_utils.py:166-172): labels u8 [B,H,W] -> one-hot fp32 [B,R,H,W] */
+int e4s_onehot_u8_f32(const uint8_t* labels, float* out, int B, int R, int H, int W, void* stream);
+/* swap_head_mask_revisit_considerGlass(source, target, hair_first=True) (src/utils/swap_face_mask.py:33-82) on n label
+ * pixels of the 12-class maps: out = swapped label, hole = 255 where a hole was filled with skin, else 0 */
+int e4s_swap_head_mask_u8(const uint8_t* src, const uint8_t* tgt, uint8_t* out, uint8_t* hole, int64_t n, void* stream);
+/* fg = not(label in {0, 11, 4}) or hole == 255   (scripts/face_swap.py:280-284) */
+int e4s_foreground_mask_f32(const uint8_t* labels, const uint8_t* hole, float* fg, int64_t n, void* stream);
+/* Flat (2*radius+1)^2 structuring element, geodesic border (src/utils/morphology.py:23-198 with kernel = ones):
+ * dil = window max, ero = window min of x [N,H,W]; either output may be NULL; radius <= 16 */
+int e4s_morph_f32(const float* x, float* dil, float* ero, int N, int H, int W, int radius, void* stream);
+/* create_masks (scripts/face_swap.py:30-48): operation 0 'dilation', 1 'erosion', 2 'expansion'; mask/border/full
+ * [N,H,W]; ws = 2*N*H*W floats of scratch */
+int e4s_create_masks_f32(const float* mask, float* border, float* full, float* ws, int N, int H, int W, int radius,
+                         int operation, void* stream);
+/* tensor2im (src/utils/torch_utils.py:63-69): NCHW fp32 [B,3,H,W] in [-1,1] -> HWC uint8 [B,H,W,3] (4x fewer bytes to
+ * all-gather than the fp32 image) */
+int e4s_tensor2im_u8(const float* img, uint8_t* out, int B, int H, int W, void* stream);
+/* out = uint8(face * m + target * (1 - m)), m = bilinear(align_corners=False) resize of mask [B,Hm,Wm] to [H,W]
+ * (scripts/face_swap.py:291-292,301-303); face/target/out HWC uint8 [B,H,W,3] */
+int e4s_paste_u8(const uint8_t* face, const uint8_t* target, const float* mask, uint8_t* out, int B, int H, int W,
+                 int Hm, int Wm, void* stream);
+
 /* ---- layout helpers ------------------------------------------------------------------------ */
 int e4s_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int H, int W, void* stream);
 int e4s_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, void* stream);

@@ -399,3 +399,55 @@ def face_swap_core(sd, driven, driven_mask, target, target_mask, swapped_mask, l
     codes = cal_style_codes(sd, sv, latent_avg, remaining_layer_idx)
     img, _ = gen_img(sd, codes, swapped_mask, noise, size, remaining_layer_idx)
     return img
+
+
+# ---- pre/post-processing of scripts/face_swap.py, CPU restatements --------------------------------
+def morph_flat(x, radius, op):
+    """src/utils/morphology.py:23-198 for a flat (2r+1)^2 structuring element with the default geodesic border: samples
+    outside the image never win (they are padded with -/+1e4).  x [B,C,H,W]; op 'dilation' (max) | 'erosion' (min)."""
+    k = 2 * radius + 1
+    if op == "dilation":
+        return F.max_pool2d(F.pad(x, (radius,) * 4, value=-1e4), k, stride=1)
+    return -F.max_pool2d(F.pad(-x, (radius,) * 4, value=-1e4), k, stride=1)
+
+
+def create_masks(mask, outer_dilation=0, operation="dilation"):
+    """scripts/face_swap.py:30-48."""
+    if operation == "dilation":
+        full = morph_flat(mask, outer_dilation, "dilation")
+        border = full - mask
+    elif operation == "erosion":
+        full = morph_flat(mask, outer_dilation, "erosion")
+        border = mask - full
+    else:
+        full = morph_flat(mask, outer_dilation, "dilation")
+        border = full - morph_flat(mask, outer_dilation, "erosion")
+    return mask, border.clip(0, 1), full
+
+
+def swap_head_mask(source, target):
+    """src/utils/swap_face_mask.py:33-82 (hair_first=True) on integer label tensors; returns (swapped, hole 0/255)."""
+    res = torch.zeros_like(target)
+    res[target == 0] = 99
+    for c in (8, 7, 11, 4):
+        res[target == c] = c
+    for c in (1, 2, 3, 5, 6, 9):
+        res[(source == c) & (res != 99)] = c
+    res[target == 10] = 10
+    hole = (res == 0).to(target.dtype) * 255
+    res[res == 0] = 6
+    res[res == 99] = 0
+    return res, hole
+
+
+def tensor2im_u8(img):
+    """src/utils/torch_utils.py:63-69 without the PIL wrapper: [B,3,H,W] fp32 -> uint8 [B,H,W,3]."""
+    v = ((img.permute(0, 2, 3, 1) + 1) / 2).clamp(0, 1) * 255
+    return v.to(torch.uint8)
+
+
+def paste_u8(face_u8, target_u8, content_mask):
+    """scripts/face_swap.py:291-292,301-303: bilinear resize of the mask, float32 lerp, np.uint8 truncation."""
+    h, w = face_u8.shape[1:3]
+    m = F.interpolate(content_mask, (h, w), mode="bilinear", align_corners=False)[:, 0, :, :, None]
+    return (face_u8.float() * m + target_u8.float() * (1 - m)).to(torch.uint8)

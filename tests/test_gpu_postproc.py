@@ -1,0 +1,98 @@
+"""GPU parity of the device pre/post-processing kernels (e4s_amd/postproc.py) against outputs of the
+REAL reference on its own example parsing maps (tests/golden/realmask.pt: swap_face_mask.py, face_swap.py:create_masks,
+morphology.py, torch_utils.tensor2im) and against the CPU restatements in oracle/e4s_oracle.py.  Integer / comparison /
+single-rounding arithmetic: everything here is bit-exact."""
+import pytest
+import torch
+
+from conftest import unz
+from e4s_amd import synth
+from oracle import e4s_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_mask_swap_onehot_and_blend_masks_vs_reference_outputs(golden):
+    from e4s_amd import postproc as PP
+    g = golden("realmask.pt")
+    d, t = unz(g["D_mask"]).to(DEV), unz(g["T_mask"]).to(DEV)
+    swapped, hole = PP.swap_head_mask_revisit_considerGlass(d, t)
+    assert torch.equal(swapped.cpu(), unz(g["swapped_mask"]))
+    assert torch.equal((hole.cpu() != 0).to(torch.uint8), unz(g["hole_map"])) and set(hole.unique().tolist()) <= {0, 255}
+    oh = PP.labelMap2OneHot(swapped[None, None], 12)
+    assert torch.equal(oh.cpu(), synth.onehot(unz(g["swapped_mask"]).long()[None, None]))
+    oh64 = PP.labelMap2OneHot(swapped[None, None].long(), 12)                   # int64 ids, as the scripts pass them
+    assert torch.equal(oh64, oh)
+    fg = PP.foreground_mask(swapped, hole)
+    assert torch.equal(fg.cpu(), unz(g["foreground"]).float())
+    for op in ("dilation", "expansion", "erosion"):
+        content, border, full = PP.create_masks(fg[None, None], outer_dilation=5, operation=op)
+        assert torch.equal(content[0, 0], fg)
+        assert torch.equal(border[0, 0].cpu(), unz(g["masks_" + op]["border"]).float()), op
+        assert torch.equal(full[0, 0].cpu(), unz(g["masks_" + op]["full"]).float()), op
+
+
+@pytest.mark.parametrize("b,c,h,w,r", [(2, 3, 40, 70, 2), (1, 1, 33, 9, 5), (1, 2, 8, 8, 0), (1, 1, 64, 64, 16)])
+def test_morphology_on_grey_images_vs_oracle(b, c, h, w, r):
+    from e4s_amd import postproc as PP
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(b, c, h, w, generator=g)
+    k = torch.ones(2 * r + 1, 2 * r + 1)
+    assert torch.equal(PP.dilation(x.to(DEV), k.to(DEV)).cpu(), orc.morph_flat(x, r, "dilation"))
+    assert torch.equal(PP.erosion(x.to(DEV), k.to(DEV)).cpu(), orc.morph_flat(x, r, "erosion"))
+    rnd = (torch.rand(b, c, h, w, generator=g) > 0.6).float()
+    for op in ("dilation", "erosion", "expansion"):
+        got = PP.create_masks(rnd.to(DEV), r, op)
+        want = orc.create_masks(rnd, r, op)
+        assert torch.equal(got[1].cpu(), want[1]) and torch.equal(got[2].cpu(), want[2])
+    with pytest.raises(NotImplementedError):
+        PP.dilation(x.to(DEV), torch.tensor([[0., 1., 0.], [1., 1., 1.], [0., 1., 0.]], device=DEV))
+
+
+def test_mask_swap_all_label_pairs_vs_oracle():
+    from e4s_amd import postproc as PP
+    s, t = torch.meshgrid(torch.arange(12), torch.arange(12), indexing="ij")
+    s, t = s.reshape(1, -1).to(torch.uint8), t.reshape(1, -1).to(torch.uint8)
+    got, hole = PP.swap_head_mask_revisit_considerGlass(s.to(DEV), t.to(DEV))
+    want, whole = orc.swap_head_mask(s.long(), t.long())
+    assert torch.equal(got.cpu().long(), want) and torch.equal(hole.cpu().long(), whole)
+
+
+def test_tensor2im_and_paste_bit_exact():
+    from e4s_amd import postproc as PP
+    g = torch.Generator().manual_seed(4)
+    img = torch.randn(2, 3, 96, 128, generator=g) * 0.8
+    img[0, :, :2] = torch.tensor([-1.0, 1.0, 0.99999994, -0.99999994, 1.5, -2.0, 0.0, 1e-8]).repeat(16)[None, None, :128]
+    u8 = PP.tensor2im(img.to(DEV))
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (2, 96, 128, 3)
+    assert torch.equal(u8.cpu(), orc.tensor2im_u8(img))
+    tgt = torch.randint(0, 256, (2, 96, 128, 3), generator=g, dtype=torch.uint8)
+    mask = torch.rand(2, 1, 48, 64, generator=g)
+    mask[:, :, :8] = 1.0
+    mask[:, :, -8:] = 0.0
+    got = PP.paste(u8, tgt.to(DEV), mask.to(DEV))
+    assert torch.equal(got.cpu(), orc.paste_u8(u8.cpu(), tgt, mask))
+
+
+@torch.no_grad()
+def test_swap_image_to_uint8_vs_reference_tensor2im(golden):
+    """The real-mask swap (tests/test_gpu_timed_path.py) converted on the device vs the reference's tensor2im of ITS
+    image: the fp32 images differ by <= 1e-4, so a pixel may fall on the other side of a 1/255 step -- never by more."""
+    from e4s_amd import kernels as K, postproc as PP
+    from e4s_amd.networks import Net3, face_swap_core
+    from e4s_amd.options import make_opts
+    g = golden("realmask.pt")
+    net = Net3(make_opts(out_size=1024))
+    net.load_state_dict(synth.synth_state_dict(1024, 13), strict=True)
+    net.latent_avg = synth.synth_latent_avg(1024).to(DEV)
+    net = net.to(DEV).eval()
+    lab = lambda z: unz(z).to(DEV)[None, None]
+    dm, tm, sm = (PP.labelMap2OneHot(lab(g[k]), 12) for k in ("D_mask", "T_mask", "swapped_mask"))
+    driven, target = synth.synth_image(1, 1024, tag="driven").to(DEV), synth.synth_image(1, 1024, tag="target").to(DEV)
+    img = face_swap_core(net, driven, dm, target, tm, sm, noise=[x.to(DEV) for x in synth.synth_noise(1024)])
+    u8 = PP.tensor2im(img)[0].cpu()
+    y0, x0, want = g["img_u8_crop"]
+    diff = (u8[y0:y0 + 128, x0:x0 + 128].int() - want.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff == 0).float().mean()) > 0.995
+    assert abs(int(u8.long().sum()) - g["img_u8_sum"]) < 3e-5 * g["img_u8_sum"]

@@ -105,3 +105,56 @@ def test_gloo_world2_overlapped_gather():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _pack_u8(local, out=None):
+    """CPU stand-in with the contract of e4s_amd.postproc.tensor2im (the oracle's restatement of torch_utils.tensor2im)."""
+    from oracle import e4s_oracle as orc
+    packed = orc.tensor2im_u8(local)
+    if out is None:
+        return packed
+    out.copy_(packed)
+    return out
+
+
+def _worker_overlap_u8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = 2
+    og = shard.OverlappedGather(world * b, pack=_pack_u8)
+    static = torch.empty(b, 3, 4, 6)
+    imgs = []
+    for step in range(4):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        img = torch.randn(b, 3, 4, 6, generator=g)
+        imgs.append(img)
+        static.copy_(img)
+        og.submit(static)
+        static.fill_(7.0)                               # overwritten right after submit, like a replayed graph's output
+    out = og.drain()
+    want = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 * 3 + r)
+        want.append(_pack_u8(torch.randn(b, 3, 4, 6, generator=g)))
+    want = torch.cat(want, 0)
+    ok = out.dtype == torch.uint8 and tuple(out.shape) == (world * b, 4, 6, 3) and bool(torch.equal(out, want))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_overlapped_gather_of_uint8_images():
+    """N4: the shard is packed to the uint8 HWC image (tensor2im) straight into the staging slot; the collective moves a
+    quarter of the bytes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap_u8, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
