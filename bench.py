@@ -124,7 +124,8 @@ def optimisation_leg(net, one, steps):
     with torch.no_grad():
         sv, _ = net.get_style_vectors(target, tm)
     latent = sv.clone().requires_grad_(True)
-    opt = torch.optim.Adam([latent], lr=1e-2)
+    from e4s_amd.optim import FusedAdam
+    opt = FusedAdam([latent], lr=1e-2)          # torch.optim.Adam's update as one kernel (e4s_adam_step_f32)
 
     def one_step():
         opt.zero_grad()

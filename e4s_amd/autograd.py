@@ -4,8 +4,11 @@ scripts/optimization.py optimises the regional style vectors [1,12,1280] with Ad
 `cal_style_codes` -> `gen_img` with the generator frozen (`train_G=False`, networks.py:63-66).  These
 Functions provide that gradient -- d(loss)/d(latent) for the generator and d/d(style_vectors) for the MLPs -- and,
 for config 5 (`train_G=True`), the gradients of every generator / LocalMLP parameter.  The heavy lifting is native (e4s_conv_bwd_mfma_f32,
-e4s_demod_grad_f32, e4s_torgb_bwd_*_f32, e4s_upfirdn2d_f32, e4s_fused_bias_act_f32); the [G,C]x[C,512]
-chain-rule GEMVs of the style prologue and the MLP transposes use torch.matmul (plain library GEMMs).
+e4s_demod_grad_f32, e4s_torgb_bwd_*_f32, e4s_upfirdn2d_f32, e4s_fused_bias_act_f32), including the transposed
+contractions of the style prologue's chain rule and of the LocalMLP backward (e4s_grouped_linear_t_f32,
+e4s_grouped_outer_f32); every split reduction adds its partial sums in a fixed order, so gradients are bit-reproducible.
+Only the generator's conv weight gradients (config 5) still build their operands natively and contract them with the
+BLAS (`styled_conv_weight_grad`), as do the tiny modulation-weight outer products.
 """
 import math
 
@@ -29,7 +32,9 @@ def styled_conv_backward(rec, dy, num_regions, extras=None):
     dx, ds = K.conv_bwd(gz, pk["wt"], rec["x"], s, d, labels, num_regions, 4 if conv.upsample else 1)
     # d = scale * rsqrt(scale^2 sum_ci s^2 Wsq + eps)  =>  dd/ds_ci = -d^3 s_ci Wsq[co,ci]
     dd3 = dd * d * d * d
-    ds = ds - s * (dd3 @ pk["wsq"])
+    # ds - s * (dd3 @ Wsq): the [G,Cout] x [Cout,Cin] contraction on e4s_grouped_linear_t_f32 with the combine fused
+    ds = K.grouped_linear_t(dd3.unsqueeze(1), pk["wsq"].unsqueeze(0), -1.0, base=ds.unsqueeze(1),
+                            mul=s.unsqueeze(1)).squeeze(1)
     if extras is not None:
         extras.update(gz=gz, dd3=dd3)
     return dx, ds
@@ -128,7 +133,8 @@ class GeneratorFn(torch.autograd.Function):
 
         def add_style_grad(rec, ds_total):
             mod = rec["layer"].conv.modulation
-            dstyle = (ds_total @ mod.weight.detach()) * mod.scale            # [G,512]
+            dstyle = K.grouped_linear_t(ds_total.unsqueeze(1).contiguous(), mod.weight.detach().unsqueeze(0),
+                                        mod.scale).squeeze(1)               # [G,Cin] x [Cin,512] -> [G,512]
             if rec["masked"]:
                 dlat[:, :, rec["idx"]] += dstyle.view(b, r, -1)
             else:
@@ -183,8 +189,8 @@ class GeneratorFn(torch.autograd.Function):
 
 class StyleCodesFn(torch.autograd.Function):
     """cal_style_codes (networks.py:135-158): the two stacked LocalMLP layers on e4s_grouped_linear_f32.
-    Backward w.r.t. the style vectors (config 3) and the stacked weights/biases (config 5); the transposed
-    contractions are plain batched GEMMs (torch.bmm)."""
+    Backward w.r.t. the style vectors (config 3) and the stacked weights/biases (config 5) on the native transposed /
+    outer-product kernels (e4s_grouped_linear_t_f32, e4s_grouped_outer_f32, e4s_batch_sum_f32)."""
 
     @staticmethod
     def forward(ctx, style_vectors, w0, b0, w2, b2, add):
@@ -199,14 +205,13 @@ class StyleCodesFn(torch.autograd.Function):
     def backward(ctx, dcodes):
         sv, h, w0, w2 = ctx.saved_tensors
         s0, s2 = 1.0 / math.sqrt(w0.shape[2]), 1.0 / math.sqrt(w2.shape[2])
-        g = dcodes.to(torch.float32).transpose(0, 1).contiguous()                 # [R,B,O]
-        hT = h.transpose(0, 1).contiguous()                                      # [R,B,512]
-        dh = torch.bmm(g, w2) * s2                                               # [R,B,512]
-        dh = dh * torch.where(hT > 0, 1.0, 0.01)
+        g = dcodes.to(torch.float32).contiguous()                                 # [B,R,O]
+        # dh = (g @ W2) * s2 * lrelu'(h): 163 MB of W2 streamed once, the activation gate fused into the second stage
+        dh = K.grouped_linear_t(g, w2, s2, ref=h, alpha=0.01)                     # [B,R,512]
         need = ctx.needs_input_grad
-        dsv = (torch.bmm(dh, w0) * s0).transpose(0, 1).contiguous() if need[0] else None
-        dw0 = torch.bmm(dh.transpose(1, 2), sv.transpose(0, 1)) * s0 if need[1] else None      # [R,512,1280]
-        db0 = dh.sum(1) if need[2] else None
-        dw2 = torch.bmm(g.transpose(1, 2), hT) * s2 if need[3] else None                        # [R,O,512]
-        db2 = g.sum(1) if need[4] else None
+        dsv = K.grouped_linear_t(dh, w0, s0) if need[0] else None                 # [B,R,1280]
+        dw0 = K.grouped_outer(dh, sv, s0) if need[1] else None                    # [R,512,1280]
+        db0 = K.batch_sum(dh) if need[2] else None
+        dw2 = K.grouped_outer(g, h, s2) if need[3] else None                      # [R,O,512]
+        db2 = K.batch_sum(g) if need[4] else None
         return dsv, dw0, db0, dw2, db2, None

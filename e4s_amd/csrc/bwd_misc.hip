@@ -17,7 +17,7 @@ __global__ void demod_grad_kernel(const float* __restrict__ gz, const float* __r
                                   const float* __restrict__ noise, const float* __restrict__ noise_w,
                                   int64_t noise_bstride, const float* __restrict__ bias, float alpha, float gain,
                                   const uint8_t* __restrict__ labels, int Hm, int Wm, int R,
-                                  float* __restrict__ dd, int H, int W, int C, int nsplit) {
+                                  float* __restrict__ dd, int H, int W, int C, int nsplit, int64_t pstride) {
     extern __shared__ float sums[];        // [NPG][R][64]
     const int cw = C >= 64 ? 64 : C;       // channels per slab (C = 32 at the 1024^2 layers)
     const int slabs = C / cw;
@@ -50,14 +50,14 @@ __global__ void demod_grad_kernel(const float* __restrict__ gz, const float* __r
         if (cc >= cw) continue;
         float s = 0.f;
         for (int j = 0; j < NPG; ++j) s += sums[(j * R + r) * 64 + cc];
-        if (s != 0.f) unsafeAtomicAdd(&dd[((int64_t)b * R + r) * C + slab * cw + cc], s);
+        dd[(int64_t)split * pstride + ((int64_t)b * R + r) * C + slab * cw + cc] = s;     // slot of this pixel split
     }
 }
 
 // dws[b*R+r, c, ci] += sum_{p in r} drgb[b,c,p] * x[p,ci]
 __global__ void torgb_bwd_w_kernel(const float* __restrict__ drgb, const float* __restrict__ x,
                                    const uint8_t* __restrict__ labels, int Hm, int Wm, int R,
-                                   float* __restrict__ dws, int H, int W, int C, int nsplit) {
+                                   float* __restrict__ dws, int H, int W, int C, int nsplit, int64_t pstride) {
     extern __shared__ float sums[];        // [NPG][R][3][64]
     const int cw = C >= 64 ? 64 : C;
     const int slabs = C / cw;
@@ -87,7 +87,7 @@ __global__ void torgb_bwd_w_kernel(const float* __restrict__ drgb, const float* 
         if (cc >= cw) continue;
         float s = 0.f;
         for (int j = 0; j < NPG; ++j) s += sums[((j * R + r) * 3 + ch) * 64 + cc];
-        if (s != 0.f) unsafeAtomicAdd(&dws[(((int64_t)b * R + r) * 3 + ch) * C + slab * cw + cc], s);
+        dws[(int64_t)split * pstride + (((int64_t)b * R + r) * 3 + ch) * C + slab * cw + cc] = s;
     }
 }
 
@@ -151,7 +151,18 @@ __global__ void shift_scale_kernel(const float* __restrict__ in, const float* __
     *reinterpret_cast<f32x4*>(out + i * 4) = v;
 }
 
+int seg_nsplit(int B, int H, int W, int C) {
+    const int slabs = C >= 64 ? C / 64 : 1;
+    int nsplit = 1024 / (B * slabs);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > (H * W) / 64) nsplit = (H * W) / 64 > 0 ? (H * W) / 64 : 1;
+    return nsplit;
+}
+
 }  // namespace
+
+/* number of pixel splits (= partial slots per output element) of e4s_demod_grad_f32 / e4s_torgb_bwd_w_f32 */
+extern "C" int e4s_seg_reduce_nsplit(int B, int H, int W, int C) { return seg_nsplit(B, H, W, C); }
 
 extern "C" int e4s_shift_scale_f32(const float* in, const float* tab, const uint8_t* labels, int Hm, int Wm, int R,
                                    float* out, int B, int Ha, int Wa, int Hi, int Wi, int C, int istride, int dy, int dx,
@@ -167,36 +178,32 @@ extern "C" int e4s_shift_scale_f32(const float* in, const float* tab, const uint
 
 extern "C" int e4s_demod_grad_f32(const float* gz, const float* y, const float* noise, const float* noise_w,
                                   int64_t noise_bstride, const float* bias, float alpha, float gain,
-                                  const uint8_t* labels, int Hm, int Wm, int R, float* dd, int B, int H, int W, int C,
-                                  void* stream) {
+                                  const uint8_t* labels, int Hm, int Wm, int R, float* dd, float* ws, int B, int H,
+                                  int W, int C, void* stream) {
     if (C % 32 || (C > 64 && C % 64) || R < 1 || R > 16) return (int)hipErrorInvalidValue;
+    if (!ws) return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(dd, 0, sizeof(float) * (size_t)B * R * C, st);
-    if (e != hipSuccess) return (int)e;
     const int slabs = C >= 64 ? C / 64 : 1;
-    int nsplit = 1024 / (B * slabs);
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > (H * W) / 64) nsplit = (H * W) / 64 > 0 ? (H * W) / 64 : 1;
-    hipLaunchKernelGGL(demod_grad_kernel, dim3(B * slabs * nsplit), dim3(64 * NPG), sizeof(float) * NPG * R * 64, st,
-                       gz, y, noise, noise_w, noise_bstride, bias, alpha, gain, labels, Hm, Wm, R, dd, H, W, C, nsplit);
+    const int nsplit = seg_nsplit(B, H, W, C);
+    const int64_t n = (int64_t)B * R * C;
+    hipLaunchKernelGGL(demod_grad_kernel, dim3(B * slabs * nsplit), dim3(64 * NPG), sizeof(float) * NPG * R * 64,
+                       st, gz, y, noise, noise_w, noise_bstride, bias, alpha, gain, labels, Hm, Wm, R, ws, H, W, C, nsplit, n);
     E4S_CHECK_LAUNCH();
-    return 0;
+    return e4s_reduce_parts_f32(ws, dd, nsplit, n, 1.f, stream);
 }
 
 extern "C" int e4s_torgb_bwd_w_f32(const float* drgb, const float* x, const uint8_t* labels, int Hm, int Wm, int R,
-                                   float* dws, int B, int H, int W, int C, void* stream) {
+                                   float* dws, float* ws, int B, int H, int W, int C, void* stream) {
     if (C % 32 || (C > 64 && C % 64) || R < 1 || R > 16) return (int)hipErrorInvalidValue;
+    if (!ws) return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(dws, 0, sizeof(float) * (size_t)B * R * 3 * C, st);
-    if (e != hipSuccess) return (int)e;
     const int slabs = C >= 64 ? C / 64 : 1;
-    int nsplit = 1024 / (B * slabs);
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > (H * W) / 64) nsplit = (H * W) / 64 > 0 ? (H * W) / 64 : 1;
-    hipLaunchKernelGGL(torgb_bwd_w_kernel, dim3(B * slabs * nsplit), dim3(64 * NPG), sizeof(float) * NPG * R * 3 * 64,
-                       st, drgb, x, labels, Hm, Wm, R, dws, H, W, C, nsplit);
+    const int nsplit = seg_nsplit(B, H, W, C);
+    const int64_t n = (int64_t)B * R * 3 * C;
+    hipLaunchKernelGGL(torgb_bwd_w_kernel, dim3(B * slabs * nsplit), dim3(64 * NPG),
+                       sizeof(float) * NPG * R * 3 * 64, st, drgb, x, labels, Hm, Wm, R, ws, H, W, C, nsplit, n);
     E4S_CHECK_LAUNCH();
-    return 0;
+    return e4s_reduce_parts_f32(ws, dws, nsplit, n, 1.f, stream);
 }
 
 extern "C" int e4s_torgb_bwd_x_f32(const float* drgb, const float* ws, const uint8_t* labels, int Hm, int Wm, int R,

@@ -239,7 +239,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < 128 / BN; ++j) v += sm.dS[j][t];
-            if (v != 0.f) unsafeAtomicAdd(&p.ds[((size_t)tb * R + t / BN) * p.Cx + n0 + (t % BN)], v);
+            // one slot per (tile of the sample, region, channel); e4s_conv_bwd_mfma_f32 adds the tiles in order afterwards
+            p.ds_ws[(size_t)rem0 * ((size_t)p.B * R * p.Cx) + ((size_t)tb * R + t / BN) * p.Cx + n0 + (t % BN)] = v;
         }
     }
 }
@@ -274,11 +275,20 @@ extern "C" int e4s_conv_bwd_mfma_f32(const e4s_conv_bwd_params* pp, void* stream
     if (p.Cx % 32 || p.Cy % KC || (p.ncls != 1 && p.ncls != 4)) return (int)hipErrorInvalidValue;
     if (p.labels && (p.R < 1 || p.R > MAXR)) return (int)hipErrorInvalidValue;
     if (p.Hy != p.Hx * (p.ncls == 4 ? 2 : 1) || p.Wy != p.Wx * (p.ncls == 4 ? 2 : 1)) return (int)hipErrorInvalidValue;
-    if (p.ds && !p.x) return (int)hipErrorInvalidValue;
-    const int mtiles = p.B * ((p.Hx + TH - 1) / TH) * ((p.Wx + TW - 1) / TW);
+    if (p.ds && (!p.x || !p.ds_ws)) return (int)hipErrorInvalidValue;
+    const int per_img = ((p.Hx + TH - 1) / TH) * ((p.Wx + TW - 1) / TW);
+    const int mtiles = p.B * per_img;
     if (mtiles <= 0) return 0;
-    if (p.Cx % 64 == 0) return launch_bwd<64>(p, mtiles, as_stream(stream));
-    return launch_bwd<32>(p, mtiles, as_stream(stream));
+    const int rc = (p.Cx % 64 == 0) ? launch_bwd<64>(p, mtiles, as_stream(stream)) : launch_bwd<32>(p, mtiles, as_stream(stream));
+    if (rc || !p.ds) return rc;
+    const int R = p.labels ? p.R : 1;
+    return e4s_reduce_parts_f32(p.ds_ws, p.ds, per_img, (int64_t)p.B * R * p.Cx, 1.f, stream);
+}
+
+extern "C" int64_t e4s_conv_bwd_ws_floats(const e4s_conv_bwd_params* pp) {
+    const e4s_conv_bwd_params& p = *pp;
+    const int per_img = ((p.Hx + TH - 1) / TH) * ((p.Wx + TW - 1) / TW);
+    return (int64_t)per_img * p.B * (p.labels ? p.R : 1) * p.Cx;
 }
 
 extern "C" int e4s_pack_taps_bwd_f32(const float* w, float* wt, int ncls, int cout, int cin, void* stream) {

@@ -225,7 +225,9 @@ __global__ void region_mean_kernel(const float* __restrict__ feats, const uint8_
 
 // ---- LocalMLP layer: one wave per (r, o) output neuron, all B samples at once; the weight row is
 // streamed once (this op is bound by reading 12 x 16 MB of fp32 weights) ---------------------------
-constexpr int MAXB = 16;
+// One wave per (region, output row): the weight row (K <= 4096 floats) is read ONCE into registers and dotted with
+// every sample's input row, so the weights are streamed once per call whatever the batch.
+constexpr int MAXKV = 16;            // f32x4 per lane: K <= 64 * 4 * 16
 __global__ void grouped_linear_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
                                       const float* __restrict__ bias, const float* __restrict__ add,
                                       float* __restrict__ y, int B, int R, int K, int O, float scale, int act,
@@ -235,29 +237,30 @@ __global__ void grouped_linear_kernel(const float* __restrict__ x, const float* 
     if (wid >= (int64_t)R * O) return;
     const int r = (int)(wid / O), o = (int)(wid % O);
     const float* wrow = Wt + ((int64_t)r * O + o) * K;
-    float acc[MAXB];
+    f32x4 w[MAXKV];
 #pragma unroll
-    for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
-    for (int i = lane * 4; i < K; i += 256) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + i);
+    for (int j = 0; j < MAXKV; ++j) {
+        const int i = (j * 64 + lane) * 4;
+        w[j] = i < K ? *reinterpret_cast<const f32x4*>(wrow + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float bs = bias ? bias[(int64_t)r * O + o] : 0.f;
+    const float ad = add ? add[o] : 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* xr = x + ((int64_t)b * R + r) * K;
+        float acc = 0.f;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            if (b < B) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((int64_t)b * R + r) * K + i);
-                acc[b] += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+        for (int j = 0; j < MAXKV; ++j) {
+            const int i = (j * 64 + lane) * 4;
+            if (i < K) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
+                acc += w[j][0] * v[0] + w[j][1] * v[1] + w[j][2] * v[2] + w[j][3] * v[3];
             }
         }
-    }
-#pragma unroll
-    for (int b = 0; b < MAXB; ++b) {
-        if (b < B) {
-            float a = wave_sum(acc[b]);
-            if (lane == 0) {
-                a = a * scale + (bias ? bias[(int64_t)r * O + o] : 0.f);
-                if (act == 1) a = a > 0.f ? a : a * alpha;
-                if (add) a += add[o];
-                y[((int64_t)b * R + r) * O + o] = a;
-            }
+        float a = wave_sum(acc);
+        if (lane == 0) {
+            a = a * scale + bs;
+            if (act == 1) a = a > 0.f ? a : a * alpha;
+            y[((int64_t)b * R + r) * O + o] = a + ad;
         }
     }
 }
@@ -336,7 +339,7 @@ extern "C" int e4s_region_mean_f32(const float* feats, const uint8_t* labels, in
 
 extern "C" int e4s_grouped_linear_f32(const float* x, const float* W, const float* bias, const float* add, float* y,
                                       int B, int R, int K, int O, float scale, int act, float alpha, void* stream) {
-    if (B > MAXB || K % 4) return (int)hipErrorInvalidValue;
+    if (K % 4 || K > 64 * 4 * MAXKV) return (int)hipErrorInvalidValue;
     const int64_t nw = (int64_t)R * O;
     if (nw <= 0 || B <= 0) return 0;
     hipLaunchKernelGGL(grouped_linear_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, as_stream(stream), x, W, bias, add, y, B, R, K, O, scale, act, alpha);

@@ -1,0 +1,179 @@
+// Native pieces of the optimisation / training step around the generator backward (SURVEY.md 8(f) N1,
+// scripts/optimization.py:209-232): the transposed LocalMLP / style-prologue contractions (x @ W, reducing over W's
+// ROW index -- the weights are streamed once, coalesced), the LocalMLP weight-gradient outer products, a fused Adam
+// update, and the ordered second stage of every split reduction of the backward (no floating-point atomics anywhere:
+// gradients are bit-reproducible run to run).
+#include "common.h"
+
+namespace {
+
+constexpr int TB = 16;      // samples (rows of g) whose partial sums a thread keeps in registers
+
+// part[split][b][r][k] = sum_{o in split} g[b,r,o] * w[r,o,k]      (k contiguous in w: lanes walk k, 16 B per lane)
+// grid = (R * nsplit, ceil(K / 256)); block = 4 waves, each wave takes every 4th o of the split.
+template <int NB>
+__global__ void grouped_linear_t_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                        float* __restrict__ part, int B, int R, int O, int K, int nsplit) {
+    __shared__ f32x4 red[3][NB][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x / nsplit, split = blockIdx.x - r * nsplit;
+    const int k = (blockIdx.y * 64 + lane) * 4;
+    const bool live = k < K;
+    const int per = (O + nsplit - 1) / nsplit;
+    const int o0 = split * per, o1 = min(o0 + per, O);
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wr = w + (int64_t)r * O * K + (live ? k : 0);
+    for (int o = o0 + wv; o < o1; o += 4) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + (int64_t)o * K);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (b < B) acc[b] += g[((int64_t)b * R + r) * O + o] * w4;      // wave-uniform scalar
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) red[wv - 1][b][lane] = acc[b];
+    }
+    __syncthreads();
+    if (wv == 0 && live) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b < B) {
+                const f32x4 v = ((acc[b] + red[0][b][lane]) + red[1][b][lane]) + red[2][b][lane];
+                *reinterpret_cast<f32x4*>(part + (((int64_t)split * B + b) * R + r) * K + k) = v;
+            }
+        }
+    }
+}
+
+// out[i] = base[i] + mul[i] * scale * gate(i) * sum_{s < nparts} part[s * n + i]      (parts added in order)
+// gate: ref ? (ref[i] > 0 ? 1 : alpha) : 1  (leaky-ReLU derivative keyed on the saved activation)
+__global__ void reduce_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int64_t n,
+                                    float scale, const float* __restrict__ base, const float* __restrict__ mul,
+                                    const float* __restrict__ ref, float alpha) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + i];
+    s *= scale;
+    if (ref) s *= ref[i] > 0.f ? 1.f : alpha;
+    if (mul) s *= mul[i];
+    if (base) s += base[i];
+    out[i] = s;
+}
+
+// dw[r,o,k] = scale * sum_b g[b,r,o] * h[b,r,k]   (LocalMLP weight gradients: B outer products per region)
+__global__ void grouped_outer_kernel(const float* __restrict__ g, const float* __restrict__ h, float* __restrict__ dw,
+                                     int B, int R, int O, int K, float scale) {
+    const int K4 = K / 4;
+    const int64_t n = (int64_t)R * O * K4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = (int)(i % K4) * 4;
+    const int64_t ro = i / K4;
+    const int o = (int)(ro % O), r = (int)(ro / O);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b)
+        acc += g[((int64_t)b * R + r) * O + o] * *reinterpret_cast<const f32x4*>(h + ((int64_t)b * R + r) * K + k);
+    *reinterpret_cast<f32x4*>(dw + i * 4) = acc * scale;
+}
+
+// out[i] = sum_b x[b*n + i]
+__global__ void batch_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += x[(int64_t)b * n + i];
+    out[i] = s;
+}
+
+// torch.optim.Adam (no amsgrad, maximize=False), one fused pass: the arithmetic of its single-tensor path
+//   g += wd * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float step_size, float b1, float b2, float eps, float wd,
+                            float omb1, float omb2, float bc2_sqrt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float g = grad[i];
+    const float pv = p[i];
+    if (wd != 0.f) g += wd * pv;
+    const float mi = m[i] + omb1 * (g - m[i]);                  // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + omb2 * g * g;                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pv - step_size * (mi / denom);                       // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+int linear_t_nsplit(int R, int O, int K) {
+    const int kblk = (K + 255) / 256;
+    int ns = 2048 / (R * kblk > 0 ? R * kblk : 1);
+    if (ns < 1) ns = 1;
+    if (ns > (O + 15) / 16) ns = (O + 15) / 16;
+    return ns < 1 ? 1 : ns;
+}
+
+}  // namespace
+
+extern "C" int64_t e4s_grouped_linear_t_ws_floats(int B, int R, int O, int K) {
+    return (int64_t)linear_t_nsplit(R, O, K) * B * R * K;
+}
+
+extern "C" int e4s_grouped_linear_t_f32(const float* g, const float* w, float* out, float* ws, int B, int R, int O, int K,
+                                        float scale, const float* base, const float* mul, const float* ref, float alpha,
+                                        void* stream) {
+    if (B < 1 || B > TB || K % 4 || R < 1 || O < 1) return (int)hipErrorInvalidValue;
+    hipStream_t st = as_stream(stream);
+    const int ns = linear_t_nsplit(R, O, K);
+    const dim3 grid(R * ns, (K + 255) / 256);
+    if (B <= 1) hipLaunchKernelGGL(grouped_linear_t_kernel<1>, grid, dim3(256), 0, st, g, w, ws, B, R, O, K, ns);
+    else if (B <= 4) hipLaunchKernelGGL(grouped_linear_t_kernel<4>, grid, dim3(256), 0, st, g, w, ws, B, R, O, K, ns);
+    else hipLaunchKernelGGL(grouped_linear_t_kernel<TB>, grid, dim3(256), 0, st, g, w, ws, B, R, O, K, ns);
+    E4S_CHECK_LAUNCH();
+    const int64_t n = (int64_t)B * R * K;
+    hipLaunchKernelGGL(reduce_parts_kernel, grid1(n), dim3(256), 0, st, ws, out, ns, n, scale, base, mul, ref, alpha);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_reduce_parts_f32(const float* parts, float* out, int nparts, int64_t n, float scale, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(reduce_parts_kernel, grid1(n), dim3(256), 0, as_stream(stream), parts, out, nparts, n, scale,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_grouped_outer_f32(const float* g, const float* h, float* dw, int B, int R, int O, int K, float scale,
+                                     void* stream) {
+    if (K % 4) return (int)hipErrorInvalidValue;
+    const int64_t n = (int64_t)R * O * (K / 4);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(grouped_outer_kernel, grid1(n), dim3(256), 0, as_stream(stream), g, h, dw, B, R, O, K, scale);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_batch_sum_f32(const float* x, float* out, int B, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(batch_sum_kernel, grid1(n), dim3(256), 0, as_stream(stream), x, out, B, n);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
+                                 double beta2, double eps, double weight_decay, int step, void* stream) {
+    if (step < 1) return (int)hipErrorInvalidValue;
+    if (n <= 0) return 0;
+    // bias corrections in double on the host, as torch.optim.Adam computes them (python floats)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2_sqrt = sqrt(1.0 - pow(beta2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, grid1(n), dim3(256), 0, as_stream(stream), p, grad, m, v, n, (float)(lr / bc1),
+                       (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)(1.0 - beta1),
+                       (float)(1.0 - beta2), (float)bc2_sqrt);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}

@@ -7,7 +7,9 @@
 //   create_masks (dilation / erosion)     scripts/face_swap.py:30-48, src/utils/morphology.py:23-198 (flat SE, geodesic)
 //   tensor2im                             src/utils/torch_utils.py:63-69
 //   paste with a content mask             scripts/face_swap.py:291-304 (F.interpolate bilinear of the mask + lerp)
-// Everything is integer / comparison / single-rounding fp32 arithmetic, so the results are bit-exact w.r.t. the reference.
+// Everything is integer / comparison / single-rounding fp32 arithmetic, so the results are bit-exact w.r.t. the reference
+// -- except the bilinear mask resize inside the paste, whose association order (and FMA use) is implementation-defined
+// in ATen itself: there a uint8 result may differ by one step where the mask is fractional.
 #include "common.h"
 
 namespace {
@@ -141,7 +143,8 @@ __global__ void paste_kernel(const uint8_t* __restrict__ face, const uint8_t* __
     const float im = 1.f - m;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float v = (float)face[i * 3 + c] * m + (float)target[i * 3 + c] * im;
+        // two rounded products and a rounded sum, as numpy evaluates it (no fused multiply-add)
+        const float v = __fadd_rn(__fmul_rn((float)face[i * 3 + c], m), __fmul_rn((float)target[i * 3 + c], im));
         out[i * 3 + c] = (uint8_t)v;
     }
 }

