@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--steps-only", action="store_true", help="only the timed steps (clean rocprofv3 kernel traces)")
     ap.add_argument("--probe-only", action="store_true", help="run only the headline-kernel probe (for rocprofv3)")
     ap.add_argument("--probe-reps", type=int, default=20)
+    ap.add_argument("--opt-only", action="store_true", help="run only the configs[2] optimisation leg (for rocprofv3)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,6 +222,10 @@ def main():
 
     if args.probe_only:
         print(json.dumps(headline_probe(net, B, inputs[4], args.probe_reps)))
+        return
+    if args.opt_only:
+        one = [t[:1].contiguous() if torch.is_tensor(t) else [n[:1].contiguous() for n in t] for t in inputs]
+        print(json.dumps({"config3_opt_step_ms": optimisation_leg(net, one, args.opt_steps), "steps": args.opt_steps}))
         return
 
     from e4s_amd import shard

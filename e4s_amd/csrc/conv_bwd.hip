@@ -36,7 +36,8 @@ struct BwdSmem {
 };
 
 template <int BN>
-__global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_params p, const int ntn) {
+__global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_params p, const int ntn, const int gsplit,
+                                                           float* __restrict__ dx_ws) {
     constexpr int WN = BN / 32, WM = 4 / WN, TM = BM / (WM * 32);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     BwdSmem<BN>& sm = *reinterpret_cast<BwdSmem<BN>*>(smem_raw);
@@ -44,7 +45,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
     const int li = lane & 31, kh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    // gsplit > 1 (low resolutions: a handful of tiles, a serial loop of up to 36 tap groups x Cy/32 stages): the tap groups
+    // are split over gsplit blocks per tile; each writes its partial dx / ds, added in group order afterwards
+    const int logical0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int gs = logical0 % gsplit;
+    const int logical = logical0 / gsplit;
     const int mt = logical / ntn, nt = logical - mt * ntn;
     const int n0 = nt * BN;
     const int tx_n = (p.Wx + TW - 1) / TW, per_img = ((p.Hx + TH - 1) / TH) * tx_n;
@@ -149,12 +154,14 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
 
-    fetch(0, 0);
+    const int gper = (ngroups + gsplit - 1) / gsplit;
+    const int g_lo = gs * gper, g_hi = min(g_lo + gper, ngroups);
+    if (g_lo < g_hi) fetch(g_lo, 0);
     store(0);
     __syncthreads();
 
     int s = 0;
-    for (int grp = 0; grp < ngroups; ++grp) {
+    for (int grp = g_lo; grp < g_hi; ++grp) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
         for (int ch = 0; ch < nchunk; ++ch, ++s) {
             int ngrp = grp, nch = ch + 1;
             if (nch == nchunk) { nch = 0; ++ngrp; }
-            const bool more = ngrp < ngroups;
+            const bool more = ngrp < g_hi;
             if (more) fetch(ngrp, nch * KC);
             {
                 const int buf = s & 1;
@@ -230,7 +237,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
         for (int r = 0; r < 16; ++r) {
             const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             const int off = sm.out_off[row];
-            if (off >= 0) p.dx[(size_t)off * p.Cx + n0 + wn * 32 + li] = acc[tm][r];
+            float* dxo = gsplit > 1 ? dx_ws + (size_t)gs * ((size_t)p.B * p.Hx * p.Wx * p.Cx) : p.dx;
+            if (off >= 0) dxo[(size_t)off * p.Cx + n0 + wn * 32 + li] = acc[tm][r];
         }
     }
     if (p.ds) {
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
 #pragma unroll
             for (int j = 0; j < 128 / BN; ++j) v += sm.dS[j][t];
             // one slot per (tile of the sample, region, channel); e4s_conv_bwd_mfma_f32 adds the tiles in order afterwards
-            p.ds_ws[(size_t)rem0 * ((size_t)p.B * R * p.Cx) + ((size_t)tb * R + t / BN) * p.Cx + n0 + (t % BN)] = v;
+            p.ds_ws[((size_t)rem0 * gsplit + gs) * ((size_t)p.B * R * p.Cx) + ((size_t)tb * R + t / BN) * p.Cx + n0 + (t % BN)] = v;
         }
     }
 }
@@ -259,15 +267,29 @@ __global__ void pack_bwd_kernel(const float* __restrict__ w, float* __restrict__
 }
 
 template <int BN>
-int launch_bwd(const e4s_conv_bwd_params& p, int mtiles, hipStream_t st) {
+int launch_bwd(const e4s_conv_bwd_params& p, int mtiles, int gsplit, float* dx_ws, hipStream_t st) {
     static std::atomic<uint64_t> smem_set{0};
     if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(conv_bwd_kernel<BN>), (int)sizeof(BwdSmem<BN>), smem_set)) return e;
     const int ntn = p.Cx / BN;
-    hipLaunchKernelGGL(conv_bwd_kernel<BN>, dim3(mtiles * ntn), dim3(NTHR), sizeof(BwdSmem<BN>), st, p, ntn);
+    hipLaunchKernelGGL(conv_bwd_kernel<BN>, dim3(mtiles * ntn * gsplit), dim3(NTHR), sizeof(BwdSmem<BN>), st, p, ntn, gsplit,
+                       dx_ws);
     E4S_CHECK_LAUNCH();
     return 0;
 }
 
+}  // namespace
+
+namespace {
+// tap-group split of the low-resolution layers: enough blocks to cover the chip, each with >= 1 group
+int bwd_gsplit(const e4s_conv_bwd_params& p) {
+    const int per_img = ((p.Hx + TH - 1) / TH) * ((p.Wx + TW - 1) / TW);
+    const int blocks = p.B * per_img * (p.Cx / (p.Cx % 64 == 0 ? 64 : 32));
+    const int ngroups = p.ncls * 9;
+    if (blocks >= 256) return 1;
+    int gs = 512 / blocks;
+    if (gs > ngroups) gs = ngroups;
+    return gs < 1 ? 1 : gs;
+}
 }  // namespace
 
 extern "C" int e4s_conv_bwd_mfma_f32(const e4s_conv_bwd_params* pp, void* stream) {
@@ -275,20 +297,33 @@ extern "C" int e4s_conv_bwd_mfma_f32(const e4s_conv_bwd_params* pp, void* stream
     if (p.Cx % 32 || p.Cy % KC || (p.ncls != 1 && p.ncls != 4)) return (int)hipErrorInvalidValue;
     if (p.labels && (p.R < 1 || p.R > MAXR)) return (int)hipErrorInvalidValue;
     if (p.Hy != p.Hx * (p.ncls == 4 ? 2 : 1) || p.Wy != p.Wx * (p.ncls == 4 ? 2 : 1)) return (int)hipErrorInvalidValue;
-    if (p.ds && (!p.x || !p.ds_ws)) return (int)hipErrorInvalidValue;
+    if (p.ds && !p.x) return (int)hipErrorInvalidValue;
     const int per_img = ((p.Hx + TH - 1) / TH) * ((p.Wx + TW - 1) / TW);
     const int mtiles = p.B * per_img;
     if (mtiles <= 0) return 0;
-    const int rc = (p.Cx % 64 == 0) ? launch_bwd<64>(p, mtiles, as_stream(stream)) : launch_bwd<32>(p, mtiles, as_stream(stream));
-    if (rc || !p.ds) return rc;
+    const int gsplit = bwd_gsplit(p);
+    if ((p.ds || gsplit > 1) && !p.ds_ws) return (int)hipErrorInvalidValue;
     const int R = p.labels ? p.R : 1;
-    return e4s_reduce_parts_f32(p.ds_ws, p.ds, per_img, (int64_t)p.B * R * p.Cx, 1.f, stream);
+    const int64_t nds = (int64_t)p.B * R * p.Cx, ndx = (int64_t)p.B * p.Hx * p.Wx * p.Cx;
+    // workspace: [ds parts + their chunk sums][dx parts (gsplit > 1)]
+    float* dx_ws = p.ds_ws + (p.ds ? e4s_reduce_parts_ws_floats(per_img * gsplit, nds) : 0);
+    const int rc = (p.Cx % 64 == 0) ? launch_bwd<64>(p, mtiles, gsplit, dx_ws, as_stream(stream))
+                                    : launch_bwd<32>(p, mtiles, gsplit, dx_ws, as_stream(stream));
+    if (rc) return rc;
+    if (gsplit > 1)
+        if (int e = e4s_reduce_parts_f32(dx_ws, p.dx, gsplit, ndx, 1.f, stream)) return e;
+    if (!p.ds) return 0;
+    return e4s_reduce_parts_f32(p.ds_ws, p.ds, per_img * gsplit, nds, 1.f, stream);
 }
 
 extern "C" int64_t e4s_conv_bwd_ws_floats(const e4s_conv_bwd_params* pp) {
     const e4s_conv_bwd_params& p = *pp;
     const int per_img = ((p.Hx + TH - 1) / TH) * ((p.Wx + TW - 1) / TW);
-    return (int64_t)per_img * p.B * (p.labels ? p.R : 1) * p.Cx;
+    const int gsplit = bwd_gsplit(p);
+    int64_t n = 0;
+    if (p.ds) n += e4s_reduce_parts_ws_floats(per_img * gsplit, (int64_t)p.B * (p.labels ? p.R : 1) * p.Cx);
+    if (gsplit > 1) n += e4s_reduce_parts_ws_floats(gsplit, (int64_t)p.B * p.Hx * p.Wx * p.Cx);
+    return n;
 }
 
 extern "C" int e4s_pack_taps_bwd_f32(const float* w, float* wt, int ncls, int cout, int cin, void* stream) {

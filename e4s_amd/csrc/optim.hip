@@ -47,6 +47,17 @@ __global__ void grouped_linear_t_kernel(const float* __restrict__ g, const float
     }
 }
 
+// out[c][i] = sum of the parts of chunk c (RCHUNK consecutive parts, added in order): first level of a long reduction
+constexpr int RCHUNK = 64;
+__global__ void reduce_chunks_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p0 = blockIdx.y * RCHUNK, p1 = min(p0 + RCHUNK, nparts);
+    float s = 0.f;
+    for (int p = p0; p < p1; ++p) s += part[(int64_t)p * n + i];
+    out[(int64_t)blockIdx.y * n + i] = s;
+}
+
 // out[i] = base[i] + mul[i] * scale * gate(i) * sum_{s < nparts} part[s * n + i]      (parts added in order)
 // gate: ref ? (ref[i] > 0 ? 1 : alpha) : 1  (leaky-ReLU derivative keyed on the saved activation)
 __global__ void reduce_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int64_t n,
@@ -139,9 +150,26 @@ extern "C" int e4s_grouped_linear_t_f32(const float* g, const float* w, float* o
     return 0;
 }
 
-extern "C" int e4s_reduce_parts_f32(const float* parts, float* out, int nparts, int64_t n, float scale, void* stream) {
+extern "C" int64_t e4s_reduce_parts_ws_floats(int nparts, int64_t n) {
+    // the parts themselves + one level of chunk sums behind them (nparts > RCHUNK^2 would need a third level: refused)
+    return (int64_t)nparts * n + (int64_t)((nparts + RCHUNK - 1) / RCHUNK) * n;
+}
+
+extern "C" int e4s_reduce_parts_f32(float* parts, float* out, int nparts, int64_t n, float scale, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(reduce_parts_kernel, grid1(n), dim3(256), 0, as_stream(stream), parts, out, nparts, n, scale,
+    if (nparts > RCHUNK * RCHUNK * 4) return (int)hipErrorInvalidValue;
+    hipStream_t st = as_stream(stream);
+    const float* src = parts;
+    if (nparts > RCHUNK) {      // two levels, both in part order: chunk sums first (parallel over chunks), then the chunks
+        const int nch = (nparts + RCHUNK - 1) / RCHUNK;
+        float* lvl = parts + (int64_t)nparts * n;
+        hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, st, parts, lvl,
+                           nparts, n);
+        E4S_CHECK_LAUNCH();
+        src = lvl;
+        nparts = nch;
+    }
+    hipLaunchKernelGGL(reduce_parts_kernel, grid1(n), dim3(256), 0, st, src, out, nparts, n, scale,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
     E4S_CHECK_LAUNCH();
     return 0;

@@ -502,9 +502,9 @@ def conv_bwd(gz, wt, x, s, d, labels, num_regions, ncls, want_ds=True):
     else:
         p.labels, p.Hm, p.Wm, p.R = None, 0, 0, 1
     p.B, p.Hx, p.Wx, p.Cx, p.Hy, p.Wy, p.Cy, p.ncls = b, hx, wx, cx, hy, wy, cy, ncls
-    ws = None
-    if want_ds:         # per-tile partial sums of ds, added in tile order by the entry point (no atomics)
-        ws = torch.empty(lib.load().e4s_conv_bwd_ws_floats(ctypes.byref(p)), device=x.device, dtype=torch.float32)
+    # partial sums of ds (and of dx where the tap groups are split over blocks), added in order by the entry point
+    nws = lib.load().e4s_conv_bwd_ws_floats(ctypes.byref(p))
+    ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
     p.ds_ws = fptr(ws)
     call("e4s_conv_bwd_mfma_f32", ctypes.byref(p), stream())
     return dx, ds
@@ -521,7 +521,9 @@ def demod_grad(gz, y, noise, noise_w, bias, alpha, gain, labels, num_regions):
     nb = 0
     if noise is not None:
         nb = h * w if noise.shape[0] > 1 else 0
-    ws = torch.empty(lib.load().e4s_seg_reduce_nsplit(b, h, w, c) * dd.numel(), device=gz.device, dtype=torch.float32)
+    L = lib.load()
+    ws = torch.empty(L.e4s_reduce_parts_ws_floats(L.e4s_seg_reduce_nsplit(b, h, w, c), dd.numel()), device=gz.device,
+                     dtype=torch.float32)
     call("e4s_demod_grad_f32", fptr(gz), fptr(y), fptr(noise), fptr(noise_w) if noise is not None else None, nb,
          fptr(bias), float(alpha), float(gain), ptr(labels), hm, wm, r, fptr(dd), fptr(ws), b, h, w, c, stream())
     return dd
@@ -536,8 +538,10 @@ def torgb_bwd(drgb, x, ws, labels, num_regions, dx_acc=None):
         hm, wm = labels.shape[1:]
     dws = torch.empty(b * r, 3, c, device=x.device, dtype=torch.float32)
     drgb = _f32(drgb)
-    ws = torch.empty(lib.load().e4s_seg_reduce_nsplit(b, h, w, c) * dws.numel(), device=x.device, dtype=torch.float32)
-    call("e4s_torgb_bwd_w_f32", fptr(drgb), fptr(x), ptr(labels), hm, wm, r, fptr(dws), fptr(ws), b, h, w, c, stream())
+    L = lib.load()
+    scratch = torch.empty(L.e4s_reduce_parts_ws_floats(L.e4s_seg_reduce_nsplit(b, h, w, c), dws.numel()), device=x.device,
+                          dtype=torch.float32)
+    call("e4s_torgb_bwd_w_f32", fptr(drgb), fptr(x), ptr(labels), hm, wm, r, fptr(dws), fptr(scratch), b, h, w, c, stream())
     acc = 1 if dx_acc is not None else 0
     dx = dx_acc if dx_acc is not None else torch.empty_like(x)
     call("e4s_torgb_bwd_x_f32", fptr(drgb), fptr(ws), ptr(labels), hm, wm, r, fptr(dx), b, h, w, c, acc, stream())

@@ -74,6 +74,7 @@ SIGNATURES = {
     "e4s_grouped_linear_t_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "e4s_grouped_linear_t_ws_floats": [c_i, c_i, c_i, c_i],
     "e4s_reduce_parts_f32": [c_p, c_p, c_i, c_l, c_f, c_p],
+    "e4s_reduce_parts_ws_floats": [c_i, c_l],
     "e4s_grouped_outer_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "e4s_batch_sum_f32": [c_p, c_p, c_i, c_l, c_p],
     "e4s_adam_step_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_p],
@@ -101,7 +102,7 @@ SIGNATURES = {
     "e4s_grouped_linear_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p],
 }
 
-INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats"}       # size queries: return a count, not an error code
+INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats"}       # size queries: return a count, not an error code
 
 _lib = None
 

@@ -172,8 +172,10 @@ typedef struct {
     int Hm, Wm, R;
     int B, Hx, Wx, Cx, Hy, Wy, Cy;
     int ncls;                /* 1: 3x3 stride-1 conv; 4: polyphase up-conv (Hy = 2*Hx) */
-    float* ds_ws;            /* scratch of e4s_conv_bwd_ws_floats(p) floats when ds != NULL: one slot per (tile of the sample,
-                                group, channel), added in tile order after the MFMA pass -- ds is bit-reproducible */
+    float* ds_ws;            /* scratch of e4s_conv_bwd_ws_floats(p) floats (may be 0 -> NULL): ds partial sums, one slot per
+                                (tile of the sample, tap-group split, group, channel), and -- at low resolutions, where the
+                                tap groups are split over several blocks per tile -- the partial dx; both are added in a
+                                fixed order after the MFMA pass: dx and ds are bit-reproducible */
 } e4s_conv_bwd_params;
 
 /* dx[q,ci] = sum_{tap} s[r(p),ci] * sum_co wt[tap,ci,co] * d[r(p),co] * gz[p,co]   (p = pixel fed by q through tap)
@@ -188,8 +190,8 @@ int e4s_demod_grad_f32(const float* gz, const float* y, const float* noise, cons
                        int64_t noise_bstride, const float* bias, float alpha, float gain,
                        const uint8_t* labels, int Hm, int Wm, int R, float* dd, float* ws, int B, int H, int W, int C,
                        void* stream);
-/* pixel splits of the two segmented reductions here: their `ws` scratch holds nsplit x (output elements) floats, one
- * slot per split, added in order (bit-reproducible; no floating-point atomics) */
+/* pixel splits of the two segmented reductions here: their `ws` scratch holds e4s_reduce_parts_ws_floats(nsplit, output
+ * elements) floats, one slot per split, added in order (bit-reproducible; no floating-point atomics) */
 int e4s_seg_reduce_nsplit(int B, int H, int W, int C);
 /* ToRGB backward: dws[g,c,ci] = sum_{p in g} drgb[b,c,p]*x[p,ci] (overwritten); dx[p,ci] (+)= sum_c drgb*ws[g(p),c,ci] */
 int e4s_torgb_bwd_w_f32(const float* drgb, const float* x, const uint8_t* labels, int Hm, int Wm, int R,
@@ -231,8 +233,11 @@ int e4s_grouped_linear_t_f32(const float* g, const float* w, float* out, float* 
                              float scale, const float* base, const float* mul, const float* ref, float alpha,
                              void* stream);
 int64_t e4s_grouped_linear_t_ws_floats(int B, int R, int O, int K);
-/* out[i] = scale * sum_{p < nparts} parts[p*n + i], p in order (second stage of every split reduction) */
-int e4s_reduce_parts_f32(const float* parts, float* out, int nparts, int64_t n, float scale, void* stream);
+/* out[i] = scale * sum_{p < nparts} parts[p*n + i] in a fixed order (second stage of every split reduction): 64-part
+ * chunks first, then the chunk sums.  `parts` must have room for e4s_reduce_parts_ws_floats(nparts, n) floats (the parts
+ * plus the chunk sums behind them). */
+int e4s_reduce_parts_f32(float* parts, float* out, int nparts, int64_t n, float scale, void* stream);
+int64_t e4s_reduce_parts_ws_floats(int nparts, int64_t n);
 /* dw[r,o,k] = scale * sum_b g[b,r,o] * h[b,r,k] (LocalMLP weight gradients);  out[i] = sum_b x[b*n + i] (bias gradients) */
 int e4s_grouped_outer_f32(const float* g, const float* h, float* dw, int B, int R, int O, int K, float scale, void* stream);
 int e4s_batch_sum_f32(const float* x, float* out, int B, int64_t n, void* stream);
