@@ -382,6 +382,7 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
             const float* sn = s_nz + mbuf * BM * NZ;
             float osc[TN], bsv[TN], slp[TN];
             int coff[TN], nzi[TN];
+            const int ycs = p.y_cstride ? p.y_cstride : p.Cout;
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int n = cur.n0 + (wn * TN + tn) * 32 + li;
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                 osc[tn] = p.out_scale ? p.out_scale[(size_t)cur.tb * p.Cout + co] : 1.f;
                 bsv[tn] = p.bias ? p.bias[co] : 0.f;
                 slp[tn] = (p.act == 2) ? p.slope[co] : p.alpha;
-                coff[tn] = ((ph >> 1) * p.Wo + (ph & 1)) * p.Cout + co;
+                coff[tn] = ((ph >> 1) * p.Wo + (ph & 1)) * ycs + co;
                 nzi[tn] = ph;
             }
             const float gain = (p.act == 1) ? p.gain : 1.f;
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                     for (int tn = 0; tn < TN; ++tn) {
                         float v = acc[tm][tn][r] * osc[tn] + sn[row * NZ + (SHUF ? nzi[tn] : 0)] + bsv[tn];
                         if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
-                        p.y[(size_t)off * p.Cout + coff[tn]] = v;
+                        p.y[(size_t)off * ycs + coff[tn]] = v;
                     }
                 }
             }
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
         const unsigned char* wp = wbytes + ((size_t)tap * p.Cout + n0) * wrow + (size_t)chunk * 128 + bq;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) P.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
-        const int oy = (ntaps == 9) ? tap / 3 - 1 : 0, ox = (ntaps == 9) ? tap % 3 - 1 : 0;
+        const int oy = ((ntaps == 9) ? tap / 3 - 1 : 0) + p.tap_shift, ox = ((ntaps == 9) ? tap % 3 - 1 : 0) + p.tap_shift;
         unsigned okm = 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
             for (int tn = 0; tn < TN; ++tn) {
                 float v = acc[tm][tn][r] + bsv[tn];
                 if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
-                p.y[(size_t)off * p.Cout + n0 + (wn * TN + tn) * 32 + li] = v;
+                p.y[(size_t)off * (p.y_cstride ? p.y_cstride : p.Cout) + n0 + (wn * TN + tn) * 32 + li] = v;
             }
         }
     }
@@ -970,7 +971,8 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     if (p.istride == 2 || p.ntaps == 1) {      // encoder stride-2 3x3 / 1x1 shortcut convs: per-tap gather kernel
         if (p.Cin % KC || p.Cout % BN || (p.ntaps != 9 && p.ntaps != 1) || p.ncls != 1 || p.ostride != 1 || p.tiles ||
             p.labels || p.in_scale || p.out_scale || p.in_stats || p.noise || p.Ho != p.Ha || p.Wo != p.Wa ||
-            p.Hi >= 32767 || p.Wi >= 32767 || (p.Ha - 1) * p.istride >= p.Hi || (p.Wa - 1) * p.istride >= p.Wi)
+            p.Hi >= 32767 || p.Wi >= 32767 || (p.Ha - 1) * p.istride >= p.Hi || (p.Wa - 1) * p.istride >= p.Wi ||
+            p.tap_shift < 0 || p.tap_shift > 1)
             return (int)hipErrorInvalidValue;
         return launch_gather(p, as_stream(stream));
     }
@@ -980,7 +982,7 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
         return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
     if (p.labels) {                       // per-pixel regions: the region-select kernel (128-wide column tiles only)
-        if (!p.in_scale || p.in_stats || p.act == 2 || p.Cout % BN || p.groups_per_batch < 1 || p.groups_per_batch > MAXR)
+        if (p.y_cstride || !p.in_scale || p.in_stats || p.act == 2 || p.Cout % BN || p.groups_per_batch < 1 || p.groups_per_batch > MAXR)
             return (int)hipErrorInvalidValue;
         return launch_region(p, st);
     }

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
                 }
             }
         } else {
-            const int oy = (ntaps == 9) ? tap / 3 - 1 : 0, ox = (ntaps == 9) ? tap % 3 - 1 : 0;
+            const int oy = ((ntaps == 9) ? tap / 3 - 1 : 0) + p.tap_shift, ox = ((ntaps == 9) ? tap % 3 - 1 : 0) + p.tap_shift;
             const int doff = oy * p.Wi + ox;
             unsigned okm = 0;
 #pragma unroll
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     const bool nz_pc = p.noise && p.noise_per_channel;
     const float nzw = nz_pc ? p.noise_w[0] : 0.f;
     const bool row_scale = SPATIAL && p.out_scale;
+    const int ycs = p.y_cstride ? p.y_cstride : p.Cout;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
                 const float sc = row_scale ? drow[ncol] : osc[tn];
                 float v = acc[tm][tn][r] * sc + nzv + bsv[tn];
                 if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
-                p.y[(size_t)off * p.Cout + n0 + ncol] = v;
+                p.y[(size_t)off * ycs + n0 + ncol] = v;
             }
         }
     }
@@ -428,6 +429,7 @@ extern "C" int e4s_conv_mfma_f32(const e4s_conv_params* pp, int spatial, void* s
     if (p.Cin % KC || p.Cout % 32 || (p.ntaps != 9 && p.ntaps != 1) || (p.ncls != 1 && p.ncls != 4))
         return (int)hipErrorInvalidValue;
     if (p.Hi >= 32767 || p.Wi >= 32767) return (int)hipErrorInvalidValue;
+    if (p.tap_shift && (spatial || p.tiles || p.tap_shift != 1)) return (int)hipErrorInvalidValue;
     if (spatial) {
         if (p.tiles || p.istride != 1 || p.ntaps != 9) return (int)hipErrorInvalidValue;
         if (p.labels && (p.groups_per_batch < 1 || p.groups_per_batch > 16)) return (int)hipErrorInvalidValue;

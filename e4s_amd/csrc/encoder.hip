@@ -265,6 +265,33 @@ __global__ void grouped_linear_kernel(const float* __restrict__ x, const float* 
     }
 }
 
+// K > 64*4*MAXKV: the weight row no longer fits in registers; it is re-read per sample (rows of <= 64 KB: L2 hits)
+__global__ void grouped_linear_longk_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                            const float* __restrict__ bias, const float* __restrict__ add,
+                                            float* __restrict__ y, int B, int R, int K, int O, float scale, int act,
+                                            float alpha) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= (int64_t)R * O) return;
+    const int r = (int)(wid / O), o = (int)(wid % O);
+    const float* wrow = Wt + ((int64_t)r * O + o) * K;
+    for (int b = 0; b < B; ++b) {
+        const float* xr = x + ((int64_t)b * R + r) * K;
+        float acc = 0.f;
+        for (int i = lane * 4; i < K; i += 256) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + i);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
+            acc += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+        }
+        float a = wave_sum(acc);
+        if (lane == 0) {
+            a = a * scale + (bias ? bias[(int64_t)r * O + o] : 0.f);
+            if (act == 1) a = a > 0.f ? a : a * alpha;
+            y[((int64_t)b * R + r) * O + o] = a + (add ? add[o] : 0.f);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int e4s_resize_bilinear_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream) {
@@ -339,9 +366,14 @@ extern "C" int e4s_region_mean_f32(const float* feats, const uint8_t* labels, in
 
 extern "C" int e4s_grouped_linear_f32(const float* x, const float* W, const float* bias, const float* add, float* y,
                                       int B, int R, int K, int O, float scale, int act, float alpha, void* stream) {
-    if (K % 4 || K > 64 * 4 * MAXKV) return (int)hipErrorInvalidValue;
+    if (K % 4) return (int)hipErrorInvalidValue;
     const int64_t nw = (int64_t)R * O;
     if (nw <= 0 || B <= 0) return 0;
+    if (K > 64 * 4 * MAXKV) {
+        hipLaunchKernelGGL(grouped_linear_longk_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, as_stream(stream), x, W, bias, add, y, B, R, K, O, scale, act, alpha);
+        E4S_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(grouped_linear_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, as_stream(stream), x, W, bias, add, y, B, R, K, O, scale, act, alpha);
     E4S_CHECK_LAUNCH();
     return 0;

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_kernel(const e4s_conv_params p
                     v = v * dsc + bsv + sm.nz[t];
                     if (nz_pc) v += nw * p.noise[((int64_t)tb * p.noise_bstride + (int64_t)oy * p.Wo + ox) * p.Cout + col];
                     if (p.act) v = (v > 0.f ? v : v * slp) * gain;
-                    p.y[opix * p.Cout + col] = v;
+                    p.y[opix * (p.y_cstride ? p.y_cstride : p.Cout) + col] = v;
                 }
             }
         }

@@ -212,14 +212,17 @@ def region_plan(labels, num_regions, ha, wa, nphase):
 # ---- the conv --------------------------------------------------------------------------------
 def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, in_scale=None, out_scale=None,
               noise=None, noise_w=None, noise_per_channel=False, bias=None, slope=None, act=0, alpha=0.2,
-              gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1, w_split=None, in_stats=None):
+              gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1, w_split=None, in_stats=None,
+              out=None, tap_shift=0):
     """x NHWC [B,Hi,Wi,Cin]; w [ncls, ntaps, Cout, Cin] -> y NHWC [B,Ho,Wo,Cout].
     anchors = (Ha, Wa); defaults: up-conv (ncls=4) anchors = input grid, output 2x;
     strided conv anchors = output grid.
     w_split: the split-bf16 image of w (split_bf16x2); when given the contraction runs on e4s_conv_bf16x3_f32
     (callers check bf16x3_eligible first -- an ineligible shape is an error, not a silent fp32 run).
     in_stats: [B,Cin,2] InstanceNorm statistics of x; the normalisation is applied while the input is staged (split-bf16
-    kernel only)."""
+    kernel only).
+    out: write the Cout channels into the FIRST channels of this wider NHWC tensor [B,Ho,Wo,Cy >= Cout] (returned).
+    tap_shift: gather kernels only: 1 = padding-0 strided conv (input coord = anchor*istride + tap)."""
     b, hi, wi, cin = x.shape
     if anchors is None:
         anchors = (hi // istride, wi // istride)
@@ -232,9 +235,16 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     if plan is None and not spatial and (ha * wa) % BM != 0 and w_split is None:
         # natural-order tiles must not straddle samples: tiny grids go through a trivial one-region plan
         plan = region_plan(torch.zeros(b, 1, 1, device=x.device, dtype=torch.uint8), 1, ha, wa, ncls)
-    y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32)
+    if out is None:
+        y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32)
+    else:
+        y = out
+        if tuple(y.shape[:3]) != (b, ho, wo) or y.shape[3] < cout or labels is not None or plan is not None:
+            raise RuntimeError("conv_mfma(out=...): need an unlabelled conv and an NHWC buffer [B,Ho,Wo,>=Cout]")
     p = ConvParams()
     p.x, p.w, p.y = fptr(x), fptr(w), fptr(y)
+    p.y_cstride = y.shape[3] if out is not None else 0
+    p.tap_shift = int(tap_shift)
     if plan is not None:
         p.rows, p.tiles, p.meta, p.tiles_cap = ptr(plan.rows), ptr(plan.tiles), ptr(plan.meta), plan.tiles_cap
         p.groups_per_batch = plan.R
@@ -310,14 +320,15 @@ def split_bf16x2(w):
 
 
 def upconv_mfma(x, w3, cout, k4, *, in_scale=None, out_scale=None, labels=None, num_regions=1, noise=None,
-                noise_w=None, noise_per_channel=False, bias=None, act=0, alpha=0.2, gain=LRELU_GAIN):
+                noise_w=None, noise_per_channel=False, bias=None, act=0, alpha=0.2, gain=LRELU_GAIN, out=None):
     """Exact transposed-conv + blur up-sampling conv.  x NHWC [B,H,W,Cin]; w3 [1,9,Cout,Cin] (plain taps);
     k4 the 4x4 blur kernel -> y NHWC [B,2H,2W,Cout]."""
     b, hi, wi, cin = x.shape
     ho, wo = 2 * hi, 2 * wi
-    y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32)
+    y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32) if out is None else out
     p = ConvParams()
     p.x, p.w, p.y = fptr(x), fptr(w3), fptr(y)
+    p.y_cstride = y.shape[3] if out is not None else 0
     p.rows = p.tiles = p.meta = None
     p.tiles_cap = 0
     p.B, p.Ha, p.Wa = b, hi, wi
@@ -476,6 +487,52 @@ def adam_step(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step):
     """torch.optim.Adam's update of one fp32 tensor, in place, as ONE kernel."""
     call("e4s_adam_step_f32", fptr(p), fptr(_f32(grad)), fptr(m), fptr(v), p.numel(), float(lr), float(beta1), float(beta2),
          float(eps), float(weight_decay), int(step), stream())
+
+
+# ---- GPEN FullGenerator / Discriminator support ------------------------------------------------
+def conv1x1_small(x_nchw, w, bias, scale, act=0, alpha=0.2, gain=LRELU_GAIN, out=None):
+    """x NCHW [B,Cin<=4,H,W]; w [Cout,Cin] -> NHWC [B,H,W,Cout] = act(x.w*scale + bias)."""
+    x = _f32(x_nchw)
+    b, cin, h, wd = x.shape
+    cout = w.shape[0]
+    y = torch.empty(b, h, wd, cout, device=x.device, dtype=torch.float32) if out is None else out
+    call("e4s_conv1x1_small_f32", fptr(x), fptr(_f32(w)), fptr(bias), fptr(y), b, h * wd, cin, cout, y.shape[3],
+         float(scale), int(act), float(alpha), float(gain), stream())
+    return y
+
+
+def noise_half(feat, noise_w, bias, out, coff, alpha=0.2, gain=LRELU_GAIN):
+    """out[..., coff:coff+C] = lrelu(noise_w*feat + bias)*gain; feat NHWC [B,H,W,C], out NHWC [B,H,W,Cy]."""
+    b, h, w, c = feat.shape
+    call("e4s_noise_half_f32", fptr(feat), fptr(noise_w), fptr(bias), fptr(out), b * h * w, c, out.shape[3], int(coff),
+         float(alpha), float(gain), stream())
+    return out
+
+
+def pixelnorm(x):
+    x = _f32(x)
+    y = torch.empty_like(x)
+    call("e4s_pixelnorm_f32", fptr(x), fptr(y), x.shape[0], x.shape[1], stream())
+    return y
+
+
+def add_scale(a, b, scale):
+    out = torch.empty_like(a)
+    call("e4s_add_scale_f32", fptr(a), fptr(b), fptr(out), float(scale), a.numel(), stream())
+    return out
+
+
+def minibatch_stddev(x, cy, group):
+    """x NHWC [B,H,W,C] -> NHWC [B,H,W,cy] = [x | group stddev statistic | zeros]."""
+    b, h, w, c = x.shape
+    y = torch.empty(b, h, w, cy, device=x.device, dtype=torch.float32)
+    call("e4s_minibatch_stddev_f32", fptr(x), fptr(y), b, h * w, c, cy, int(group), stream())
+    return y
+
+
+def upfirdn2d_nhwc(x, kernel, up=1, down=1, pad=(0, 0)):
+    """upfirdn2d on an NHWC activation: the op's native [major, H, W, minor] view with major = B, minor = C."""
+    return upfirdn2d_raw(x, kernel, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
 
 
 # ---- backward (generator) --------------------------------------------------------------------

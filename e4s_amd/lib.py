@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe4s_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -33,7 +33,7 @@ class ConvParams(ctypes.Structure):
         ("labels", c_p), ("Hm", c_i), ("Wm", c_i),
         ("noise", c_p), ("noise_w", c_p), ("noise_bstride", c_l), ("noise_per_channel", c_i),
         ("bias", c_p), ("slope", c_p), ("act", c_i), ("alpha", c_f), ("gain", c_f),
-        ("in_stats", c_p),
+        ("in_stats", c_p), ("y_cstride", c_i), ("tap_shift", c_i),
     ]
 
 
@@ -92,6 +92,11 @@ SIGNATURES = {
     "e4s_instnorm_apply_f32": [c_p] * 7 + [c_i] * 5 + [c_p],
     "e4s_se_gate_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_region_mean_f32": [c_p, c_p, c_i, c_i, c_p] + [c_i] * 7 + [c_p],
+    "e4s_conv1x1_small_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_p],
+    "e4s_noise_half_f32": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
+    "e4s_pixelnorm_f32": [c_p, c_p, c_i, c_i, c_p],
+    "e4s_add_scale_f32": [c_p, c_p, c_p, c_f, c_l, c_p],
+    "e4s_minibatch_stddev_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_onehot_u8_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_swap_head_mask_u8": [c_p, c_p, c_p, c_p, c_l, c_p],
     "e4s_foreground_mask_f32": [c_p, c_p, c_p, c_l, c_p],

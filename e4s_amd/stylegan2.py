@@ -561,7 +561,87 @@ class Generator(nn.Module):
         return skip, feats
 
 
-# ---- Discriminator (config 5 only; plain torch convs through conv2d_gradfix, HIP blur + bias-act) ----
+# ---- ConvLayer on the HIP kernels (Discriminator, GPEN encoder) ----------------------------------------------------------
+def _packed_equal_conv(conv, cin_pad):
+    """EqualConv2d weight * scale (model.py:117-123) tap-packed [1,k*k,Cout,cin_pad] (input channels zero-padded to the
+    kernels' 32-channel K step), + its split-bf16 image; cached on the module."""
+    key = _param_key(conv.weight) + (cin_pad,)
+    pk = getattr(conv, "_e4s_pack", None)
+    if pk is None or pk["key"] != key:
+        with torch.no_grad():
+            w = conv.weight.detach().float() * conv.scale
+            cout, cin, k, _ = w.shape
+            if cin_pad != cin:
+                w = torch.cat([w, w.new_zeros(cout, cin_pad - cin, k, k)], 1)
+            pk = {"key": key, "w": K.pack_taps(w.contiguous())}
+        conv._e4s_pack = pk
+    return pk
+
+
+def conv_layer_nhwc(layer, x, x_is_nchw=False):
+    """ConvLayer (model.py:670-716; GPEN's copy gpen_model.py:558-606) on NHWC activations: [Blur] -> EqualConv2d ->
+    [FusedLeakyReLU | ScaledLeakyReLU] as [e4s_upfirdn2d_f32] + ONE conv launch with bias and activation in its epilogue.
+    x NHWC [B,H,W,Cin] (or the NCHW image for the 3 -> C stem, x_is_nchw); returns NHWC."""
+    mods = list(layer)
+    i = 0
+    blur = None
+    if isinstance(mods[0], Blur):
+        blur, i = mods[0], 1
+    conv = mods[i]
+    tail = mods[i + 1] if len(mods) > i + 1 else None
+    cout, cin, k, _ = conv.weight.shape
+    if isinstance(tail, FusedLeakyReLU):
+        bias, act, alpha, gain = tail.bias, 1, tail.negative_slope, tail.scale
+    elif isinstance(tail, ScaledLeakyReLU):
+        bias, act, alpha, gain = None, 1, tail.negative_slope, math.sqrt(2)
+    else:
+        bias, act, alpha, gain = conv.bias, 0, 0.2, 1.0
+    if x_is_nchw:
+        if k != 1 or conv.stride != 1 or cin > 4:
+            raise NotImplementedError("NCHW input is only accepted by the 1x1 stem ConvLayer")
+        return K.conv1x1_small(x, conv.weight.detach().reshape(cout, cin), bias, conv.scale, act, alpha, gain)
+    cx = x.shape[3]
+    pk = _packed_equal_conv(conv, cx)                   # cx > cin: the caller padded the activation (513 -> 544)
+    if cx < cin or cx % 32:
+        raise RuntimeError(f"ConvLayer on {cx} channels: need a multiple of 32 >= {cin}")
+    kw = dict(bias=bias, act=act, alpha=alpha, gain=gain)
+    b, h, w, _ = x.shape
+
+    def split():
+        if "w_split" not in pk:
+            pk["w_split"] = K.split_bf16x2(pk["w"])
+        return pk["w_split"]
+    if conv.stride == 1:
+        if k != 3 or conv.padding != 1:
+            raise NotImplementedError("stride-1 ConvLayers are 3x3 / padding 1 (model.py:701-703)")
+        if K.want_bf16x3(b, h, w, cx, cout):
+            return K.conv_mfma(x, pk["w"], cout, w_split=split(), **kw)
+        return K.conv_mfma(x, pk["w"], cout, **kw)
+    if blur is None or conv.stride != 2 or conv.padding != 0 or k not in (1, 3):
+        raise NotImplementedError("down-sampling ConvLayers are Blur + stride-2 padding-0 convs (model.py:683-700)")
+    xb = K.upfirdn2d_nhwc(x, blur.kernel, pad=blur.pad)
+    hb, wb = xb.shape[1:3]
+    anchors = ((hb - k) // 2 + 1, (wb - k) // 2 + 1)
+    gk = dict(istride=2, ntaps=k * k, anchors=anchors, tap_shift=1 if k == 3 else 0, **kw)
+    tiles = (b * anchors[0] * anchors[1] + 255) // 256 * (cout // 128 if cout % 128 == 0 else 0)
+    if K.PRECISION != "f32" and cout % 128 == 0 and (K.PRECISION == "bf16x3" or tiles >= K.BF16X3_MIN_BLOCKS):
+        return K.conv_mfma(xb, pk["w"], cout, w_split=split(), **gk)
+    return K.conv_mfma(xb, pk["w"], cout, **gk)
+
+
+def equal_linear_lrelu(lin, x):
+    """EqualLinear(activation='fused_lrelu') (model.py:159-164): lrelu(x W^T scale + bias lr_mul, 0.2) * sqrt(2) on
+    e4s_grouped_linear_f32; the positive gain is folded into scale and bias.  Plain EqualLinear when no activation."""
+    w = lin.weight.detach()
+    g = math.sqrt(2) if lin.activation else 1.0
+    bias = (lin.bias.detach() * (lin.lr_mul * g)).unsqueeze(0) if lin.bias is not None else None
+    y = K.grouped_linear(x.unsqueeze(1).contiguous(), w.unsqueeze(0), bias, None, lin.scale * g,
+                         act=1 if lin.activation else 0, alpha=0.2)
+    return y.squeeze(1)
+
+
+# ---- Discriminator (config 5): native forward on the MFMA conv kernels when no gradient is asked for; with autograd the
+# convs go through conv2d_gradfix -> ATen exactly as the reference does (its R1 penalty needs double backward) ----
 class ConvLayer(nn.Sequential):
     """model.py:670-716"""
 
@@ -617,7 +697,30 @@ class Discriminator(nn.Module):
         self.final_linear = nn.Sequential(EqualLinear(channels[4] * 4 * 4, channels[4], activation="fused_lrelu"),
                                           EqualLinear(channels[4], 1))
 
+    def _needs_autograd(self, input):
+        return torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))
+
+    @torch.no_grad()
+    def forward_native(self, input):
+        """model.py:740-799 as a schedule of HIP kernels on NHWC tensors (no autograd): ConvLayers on the MFMA convs,
+        ResBlock combine, minibatch stddev (the 513-channel map is zero-padded to 544 for the 32-channel K step)."""
+        convs = list(self.convs)
+        x = conv_layer_nhwc(convs[0], input, x_is_nchw=True)
+        for rb in convs[1:]:
+            r = conv_layer_nhwc(rb.conv2, conv_layer_nhwc(rb.conv1, x))
+            x = K.add_scale(r, conv_layer_nhwc(rb.skip, x), 1.0 / math.sqrt(2))
+        b, h, w, c = x.shape
+        group = min(b, self.stddev_group)
+        if b % group:
+            raise RuntimeError("minibatch stddev needs the batch to be a multiple of the group (as the reference's view)")
+        x = K.minibatch_stddev(x, (c + 1 + 31) // 32 * 32, group)
+        x = conv_layer_nhwc(self.final_conv, x)
+        flat = K.nhwc_to_nchw(x).reshape(b, -1)
+        return equal_linear_lrelu(self.final_linear[1], equal_linear_lrelu(self.final_linear[0], flat))
+
     def forward(self, input):
+        if input.is_cuda and not self._needs_autograd(input):
+            return self.forward_native(input)
         out = self.convs(input)
         batch, channel, height, width = out.shape
         group = min(batch, self.stddev_group)

@@ -126,6 +126,11 @@ typedef struct {
     const float* in_stats;   /* e4s_conv_bf16x3_f32 only: [B][Cin][2] {mean, rstd} (e4s_instnorm_stats_f32): the input is
                                 InstanceNorm-ed, (x - mean) * rstd, while it is staged (helpers.py:128-131 folded into the
                                 unit's first conv); excludes in_scale.  NULL elsewhere */
+    int y_cstride;           /* channels per pixel of the buffer y points into (0 = Cout): the conv may write the first Cout
+                                channels of a wider NHWC tensor -- GPEN's StyledConv concatenates its noise (the encoder
+                                feature map) behind the conv output (gpen_model.py:343-353).  Plain (unlabelled) kernels */
+    int tap_shift;           /* gather mode (istride 2 / ntaps 1 kernels): input coord = anchor*istride + tap - 1 + tap_shift;
+                                1 = the padding-0 stride-2 conv behind a Blur (ConvLayer, model.py:683-700) */
 } e4s_conv_params;
 
 /* y = epilogue( sum_{tap,ci} x[anchor*istride + tap - 1, ci] * in_scale[g,ci] * w[cls,tap,co,ci] )
@@ -223,6 +228,23 @@ int e4s_mask_mul_add_f32(const float* y, const float* mask, float* out, int r, i
 int e4s_noise_bias_act_nhwc_f32(const float* x, const float* noise, const float* noise_w, int64_t noise_bstride,
                                 const float* bias, float* y, int B, int HW, int C, float alpha, float gain,
                                 void* stream);
+
+/* ---- GPEN FullGenerator / Discriminator support ---------------------------------- */
+/* 1x1 conv with tiny Cin (<= 4; the 3 -> C stem ConvLayer, gpen_model.py:658, model.py:756): x NCHW [B,Cin,HW],
+ * w [Cout,Cin], y NHWC (channel stride y_cstride or Cout): act(x.w*scale + bias), act 1 = leaky-relu(alpha)*gain */
+int e4s_conv1x1_small_f32(const float* x, const float* w, const float* bias, float* y, int B, int HW, int Cin, int Cout,
+                          int y_cstride, float scale, int act, float alpha, float gain, void* stream);
+/* y[pix, coff + c] = lrelu(noise_w[0]*feat[pix, c] + bias[c], alpha)*gain: the noise half of GPEN's concatenating
+ * StyledConv (gpen_model.py:343-353); feat NHWC [npix, C], y NHWC with y_cstride channels per pixel */
+int e4s_noise_half_f32(const float* feat, const float* noise_w, const float* bias, float* y, int64_t npix, int C,
+                       int y_cstride, int coff, float alpha, float gain, void* stream);
+/* PixelNorm over dim 1 of x [B,D] */
+int e4s_pixelnorm_f32(const float* x, float* y, int B, int D, void* stream);
+/* out = (a + b) * scale over n floats (ResBlock combine, model.py:733-737) */
+int e4s_add_scale_f32(const float* a, const float* b, float* out, float scale, int64_t n, void* stream);
+/* minibatch-stddev feature (model.py:783-790, stddev_feat = 1): x NHWC [B,HW,C] -> y NHWC [B,HW,Cy]: x, then the group
+ * statistic in channel C, zeros up to Cy (Cy > C; pads 513 -> 544 channels for the 32-channel K step) */
+int e4s_minibatch_stddev_f32(const float* x, float* y, int B, int HW, int C, int Cy, int group, void* stream);
 
 /* ---- optimisation / training step around the generator backward ------------------------- */
 /* out[b,r,k] = base + mul * scale * gate * sum_o g[b,r,o] * w[r,o,k]   -- "x @ W": the transposed contraction of the
