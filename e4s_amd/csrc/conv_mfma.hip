@@ -429,7 +429,7 @@ extern "C" int e4s_conv_mfma_f32(const e4s_conv_params* pp, int spatial, void* s
     if (p.Cin % KC || p.Cout % 32 || (p.ntaps != 9 && p.ntaps != 1) || (p.ncls != 1 && p.ncls != 4))
         return (int)hipErrorInvalidValue;
     if (p.Hi >= 32767 || p.Wi >= 32767) return (int)hipErrorInvalidValue;
-    if (p.tap_shift && (spatial || p.tiles || p.tap_shift != 1)) return (int)hipErrorInvalidValue;
+    if (p.tap_shift && (spatial || p.tap_shift != 1)) return (int)hipErrorInvalidValue;
     if (spatial) {
         if (p.tiles || p.istride != 1 || p.ntaps != 9) return (int)hipErrorInvalidValue;
         if (p.labels && (p.groups_per_batch < 1 || p.groups_per_batch > 16)) return (int)hipErrorInvalidValue;
