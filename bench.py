@@ -144,6 +144,28 @@ def optimisation_leg(net, one, steps):
     return round((time.perf_counter() - t0) / steps * 1e3, 3)
 
 
+def gpen_leg(dev, reps=10):
+    """GPEN-BFR-512's FullGenerator (the restoration pass that runs once per swap before the parser,
+    scripts/face_swap.py:206-210) on the same kernels: single-image latency and 8-image throughput, synthetic weights."""
+    from e4s_amd.gpen import FullGenerator
+    net = FullGenerator(512, 512, 8, channel_multiplier=2, narrow=1)
+    net.load_state_dict(synth.synth_gpen_state_dict(512, n_mlp=8), strict=True)
+    net = net.to(dev).eval()
+    out = {}
+    for b in (1, 8):
+        x = synth.synth_image(b, 512, tag="gpen_bench").to(dev)
+        for _ in range(3):
+            net(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            net(x)
+        torch.cuda.synchronize()
+        out[f"b{b}_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+    out["images_per_s_b8"] = round(8e3 / out["b8_ms"], 1)
+    return out
+
+
 def cpu_baseline(sd, lat, inputs, hip_img0, hip_img0_b1):
     """One swap (sample 0 of the bench batch) on the host cores with the CPU oracle; returns the baseline record and the
     max-abs differences of (sample 0 of the timed batch, the batch-1 run) against it."""
@@ -321,6 +343,7 @@ def main():
             out["ms_per_step_f32"] = round(dt32 * 1e3, 3)
             out["max_abs_default_vs_f32"] = float((img32 - img).abs().max())
             del g32
+        out["gpen512"] = gpen_leg(dev)
         if args.opt_steps > 0:
             ms = optimisation_leg(net, one, args.opt_steps)
             out["config3_opt_step_ms"] = ms
