@@ -1,0 +1,169 @@
+"""Autograd of the regional style encoder (config 5, src/training/coach.py:340-356: the encoder and the LocalMLPs are what
+E4S trains; SURVEY.md 8(a) a1-a4 backward).  One torch.autograd.Function around FSEncoder_PSP.encode_nhwc: the forward is the
+same kernel schedule with a tape, the backward walks the 24 IR-SE units in reverse:
+
+    regional pooling            e4s_region_mean_bwd_f32
+    gate * IN(r2) + shortcut     e4s_instnorm_bwd_f32 (its second sum IS dL/dgate), SE chain rule on [B,C] vectors
+    conv 3x3 (stride 1 / 2)      dgrad: e4s_conv_bwd_mfma_f32 (stride 2: on the zero-inserted gradient);
+    conv 1x1 stride 2            dgrad: e4s_conv_mfma_f32 with the transposed weights + e4s_strided_scatter_f32
+    PReLU                        e4s_prelu_bwd_f32
+    IN(x)                        e4s_instnorm_bwd_f32
+    weight gradients             operand builder e4s_shift_scale_f32 + one [Cout x P] x [P x Cin] BLAS contraction per tap
+                                 (as the generator's, autograd.py:styled_conv_weight_grad); the 3 -> 64 stem via im2col
+
+The exact-zero SE input (the spatial mean of an instance-normalised map, helpers.py:64-66) makes dL/d(pooled) flow back
+only through rounding residue; that path (O(1e-8) of the gradient) is dropped."""
+import torch
+import torch.nn.functional as F
+
+from . import kernels as K
+from .encoders import _pack3x3, _conv3x3, _conv_strided
+
+
+def _wgrad(gz, xin, stride, ntaps):
+    """dW [Cout,Cin,k,k] of y = conv(xin, W, stride, padding=k//2): gz NHWC [B,Ho,Wo,Cout], xin NHWC [B,Hi,Wi,Cin]."""
+    b, ho, wo, cout = gz.shape
+    cin = xin.shape[3]
+    g2 = gz.reshape(-1, cout)
+    if ntaps == 1:
+        xs = K.shift_scale(xin, None, None, 1, (ho, wo), istride=stride)
+        return (g2.t() @ xs.view(-1, cin)).view(cout, cin, 1, 1)
+    taps = []
+    for ty in range(3):
+        for tx in range(3):
+            xs = K.shift_scale(xin, None, None, 1, (ho, wo), istride=stride, dy=ty - 1, dx=tx - 1)
+            taps.append(g2.t() @ xs.view(-1, cin))
+    return torch.stack(taps, -1).view(cout, cin, 3, 3)
+
+
+def _wt(conv):
+    """backward-packed (flipped, transposed) taps of a 3x3 conv, cached with the forward pack."""
+    w = _pack3x3(conv)
+    key = conv._e4s_pack[0]
+    if getattr(conv, "_e4s_wt", None) is None or conv._e4s_wt[0] != key:
+        conv._e4s_wt = (key, K.pack_taps_bwd(w))
+    return conv._e4s_wt[1]
+
+
+def unit_forward(unit, x, tape):
+    """bottleneck_IR_SE_Ours.run_nhwc with a tape (the PReLU runs as its own pass so that its input is saved)."""
+    conv1, prelu, conv2, se = unit.res_layer[1], unit.res_layer[2], unit.res_layer[3], unit.res_layer[5]
+    st_x, _ = K.instnorm_stats(x)
+    u1 = _conv3x3(x, conv1, unit.depth, in_stats=st_x)
+    r1 = K.prelu(u1, prelu.weight)
+    r2 = _conv3x3(r1, conv2, unit.depth) if unit.stride == 1 else _conv_strided(r1, conv2, unit.depth, unit.stride, 9)
+    st_r, pooled = K.instnorm_stats(r2, want_pooled=True)
+    fc1, fc2 = se.fc1.weight.view(se.fc1.weight.shape[0], -1), se.fc2.weight.view(se.fc2.weight.shape[0], -1)
+    gate = K.se_gate(pooled, fc1, fc2)
+    rec = dict(unit=unit, x=x, st_x=st_x, u1=u1, r1=r1, r2=r2, st_r=st_r, pooled=pooled, gate=gate)
+    if unit.in_channel == unit.depth:
+        out = K.instnorm_apply(r2, st_r, gate=gate, res=x, rs=unit.stride)
+    else:
+        sc = _conv_strided(x, unit.shortcut_layer[0], unit.depth, unit.stride, 1)
+        st_sc, _ = K.instnorm_stats(sc)
+        out = K.instnorm_apply(r2, st_r, gate=gate, res=sc, res_stats=st_sc)
+        rec.update(sc=sc, st_sc=st_sc)
+    tape.append(rec)
+    return out
+
+
+def unit_backward(rec, dout, give):
+    unit = rec["unit"]
+    conv1, prelu, conv2, se = unit.res_layer[1], unit.res_layer[2], unit.res_layer[3], unit.res_layer[5]
+    x, r1, r2, gate = rec["x"], rec["r1"], rec["r2"], rec["gate"]
+    s = unit.stride
+    # ---- gate * IN(r2): dr2 and dL/dgate ----
+    dr2, sums = K.instnorm_bwd(dout, r2, rec["st_r"], gate)
+    dgate = sums[:, :, 1]
+    fc1, fc2 = se.fc1.weight.detach().view(se.fc1.weight.shape[0], -1), se.fc2.weight.detach().view(se.fc2.weight.shape[0], -1)
+    hidden = torch.relu(rec["pooled"] @ fc1.t())                              # [B,Cr]  (tiny [B,C]-sized chain rule)
+    dz = dgate * gate * (1.0 - gate)
+    give(se.fc2.weight, (dz.t() @ hidden).view_as(se.fc2.weight))
+    dh = (dz @ fc2) * (hidden > 0)
+    give(se.fc1.weight, (dh.t() @ rec["pooled"]).view_as(se.fc1.weight))
+    # ---- conv2 (3x3, stride s) ----
+    give(conv2.weight, _wgrad(dr2, r1, s, 9))
+    gz2 = dr2 if s == 1 else K.strided_scatter(dr2, s)
+    dr1, _ = K.conv_bwd(gz2, _wt(conv2), r1, None, None, None, 1, 1, want_ds=False)
+    # ---- PReLU ----
+    du1, dslope = K.prelu_bwd(dr1, rec["u1"], prelu.weight)
+    give(prelu.weight, dslope)
+    # ---- conv1 on IN(x) ----
+    xn = K.instnorm_apply(x, rec["st_x"])
+    give(conv1.weight, _wgrad(du1, xn, 1, 9))
+    del xn
+    dxn, _ = K.conv_bwd(du1, _wt(conv1), x, None, None, None, 1, 1, want_ds=False)
+    dx, _ = K.instnorm_bwd(dxn, x, rec["st_x"])
+    # ---- shortcut ----
+    if unit.in_channel == unit.depth:
+        K.strided_scatter(dout, s, out=dx)                                   # MaxPool2d(1, s) backward (s = 1: plain add)
+    else:
+        sconv = unit.shortcut_layer[0]
+        dsc, _ = K.instnorm_bwd(dout, rec["sc"], rec["st_sc"])
+        give(sconv.weight, _wgrad(dsc, x, s, 1))
+        wT = sconv.weight.detach().view(unit.depth, unit.in_channel).t().contiguous().view(1, 1, unit.in_channel, unit.depth)
+        t = K.conv_mfma(dsc, wT, unit.in_channel, ntaps=1, spatial=False)
+        K.strided_scatter(t, s, out=dx)
+    return dx
+
+
+class EncoderFn(torch.autograd.Function):
+    """codes [B,R,1280] = FSEncoder_PSP(x256, labels) with gradients w.r.t. every encoder parameter (passed as extra inputs
+    so that autograd routes them)."""
+
+    @staticmethod
+    def forward(ctx, enc, x256, labels, num_regions, *params):
+        tape = []
+        conv0, prelu0 = enc.input_layer[0], enc.input_layer[2]
+        c0 = K.conv3x3_small(x256, conv0.weight.detach())
+        st0, _ = K.instnorm_stats(c0)
+        x = K.instnorm_apply(c0, st0, slope=prelu0.weight.detach())
+        b = x.shape[0]
+        codes = torch.empty(b, num_regions, 256 + 512 + 512, device=x.device, dtype=torch.float32)
+        off = {6: 0, 20: 256, 23: 768}
+        shapes = {}
+        for i, unit in enumerate(enc.body):
+            x = unit_forward(unit, x, tape)
+            if i in off:
+                K.region_mean_into(x, labels, codes, num_regions, off[i])
+                shapes[i] = tuple(x.shape)
+        ctx.enc, ctx.tape, ctx.labels, ctx.R = enc, tape, labels, num_regions
+        ctx.stem = dict(x256=x256, c0=c0, st0=st0)
+        ctx.off, ctx.shapes = off, shapes
+        ctx.pidx = {id(p): i for i, p in enumerate(params)}
+        ctx.nparams = len(params)
+        return codes
+
+    @staticmethod
+    def backward(ctx, dcodes):
+        enc, tape = ctx.enc, ctx.tape
+        grads = [None] * ctx.nparams
+
+        def give(p, g):
+            i = ctx.pidx.get(id(p))
+            if i is not None:
+                grads[i] = g if grads[i] is None else grads[i] + g
+        dcodes = dcodes.contiguous().to(torch.float32)
+        dout = None
+        for i in reversed(range(len(tape))):
+            if i in ctx.off:
+                dout = K.region_mean_bwd(dcodes, ctx.labels, ctx.R, ctx.shapes[i], ctx.off[i], dfeat_acc=dout)
+            if dout is None:
+                continue
+            dout = unit_backward(tape[i], dout, give)
+            tape[i] = None                                                  # free the unit's activations
+        # ---- stem: PReLU(IN(conv3x3(img))) ----
+        conv0, prelu0 = enc.input_layer[0], enc.input_layer[2]
+        st = ctx.stem
+        n0 = K.instnorm_apply(st["c0"], st["st0"])
+        dn0, dslope0 = K.prelu_bwd(dout, n0, prelu0.weight)
+        give(prelu0.weight, dslope0)
+        dc0, _ = K.instnorm_bwd(dn0, st["c0"], st["st0"])
+        if id(conv0.weight) in ctx.pidx:
+            # 3-channel input: the [64 x P] x [P x 27] contraction over an im2col of the image (BLAS)
+            img = K.nhwc_to_nchw(st["x256"])
+            b = img.shape[0]
+            cols = F.unfold(img, 3, padding=1)                               # [B, 27, P]
+            dw0 = torch.einsum("bpc,bkp->ck", dc0.view(b, -1, dc0.shape[3]), cols)
+            give(conv0.weight, dw0.view_as(conv0.weight))
+        return (None, None, None, None) + tuple(grads)

@@ -489,6 +489,57 @@ def adam_step(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step):
          float(eps), float(weight_decay), int(step), stream())
 
 
+# ---- encoder backward (config 5) -------------------------------------------------------------------
+def instnorm_bwd(dy, x, stats, gate=None, dx_acc=None):
+    """InstanceNorm2d backward (x NHWC [B,H,W,C], stats from instnorm_stats; gate [B,C] = the SE gate that multiplied the
+    normalised tensor, or None).  Returns (dx (accumulated into dx_acc if given), sums [B,C,2] = {sum dy, sum dy*xhat})."""
+    b, h, w, c = x.shape
+    sums = torch.empty(b, c, 2, device=x.device, dtype=torch.float32)
+    dx = dx_acc if dx_acc is not None else torch.empty_like(x)
+    ws = torch.empty(lib.load().e4s_instnorm_bwd_ws_doubles(b, h * w, c), device=x.device, dtype=torch.float64)
+    call("e4s_instnorm_bwd_f32", fptr(_f32(dy)), fptr(x), fptr(stats), fptr(gate), fptr(sums), fptr(dx), ptr(ws), b, h * w, c,
+         1 if dx_acc is not None else 0, stream())
+    return dx, sums
+
+
+def prelu(u, slope):
+    y = torch.empty_like(u)
+    call("e4s_prelu_f32", fptr(u), fptr(slope), fptr(y), u.numel() // u.shape[-1], u.shape[-1], stream())
+    return y
+
+
+def prelu_bwd(dy, u, slope):
+    """(du, dslope [C]) of y = PReLU(u), u NHWC [..., C]."""
+    c = u.shape[-1]
+    npix = u.numel() // c
+    du = torch.empty_like(u)
+    dslope = torch.empty(c, device=u.device, dtype=torch.float32)
+    ws = torch.empty(lib.load().e4s_prelu_bwd_ws_floats(npix, c), device=u.device, dtype=torch.float32)
+    call("e4s_prelu_bwd_f32", fptr(_f32(dy)), fptr(u), fptr(slope), fptr(du), fptr(dslope), fptr(ws), npix, c, stream())
+    return du, dslope
+
+
+def strided_scatter(src, s, out=None):
+    """out[b, y*s, x*s] (+)= src[b, y, x]; src NHWC [B,H,W,C].  out=None: a zero-inserted [B,H*s,W*s,C] tensor."""
+    b, h, w, c = src.shape
+    acc = 1 if out is not None else 0
+    if out is None:
+        out = torch.empty(b, h * s, w * s, c, device=src.device, dtype=torch.float32)
+    call("e4s_strided_scatter_f32", fptr(_f32(src)), fptr(out), b, h, w, c, int(s), acc, stream())
+    return out
+
+
+def region_mean_bwd(dcodes, labels, num_regions, shape, off, dfeat_acc=None):
+    """dfeat[b,p,c] (+)= dcodes[b, label(p), off + c] / count[b, label(p)];  shape = (B,H,W,C) of the feature map."""
+    b, h, w, c = shape
+    dfeat = dfeat_acc if dfeat_acc is not None else torch.empty(b, h, w, c, device=dcodes.device, dtype=torch.float32)
+    counts = torch.empty(b * num_regions, device=dcodes.device, dtype=torch.int32)
+    dcodes = _f32(dcodes)
+    call("e4s_region_mean_bwd_f32", fptr(dcodes), ptr(labels), labels.shape[1], labels.shape[2], ptr(counts), fptr(dfeat),
+         b, h, w, c, num_regions, dcodes.shape[2], int(off), 1 if dfeat_acc is not None else 0, stream())
+    return dfeat
+
+
 # ---- GPEN FullGenerator / Discriminator support ------------------------------------------------
 def conv1x1_small(x_nchw, w, bias, scale, act=0, alpha=0.2, gain=LRELU_GAIN, out=None):
     """x NCHW [B,Cin<=4,H,W]; w [Cout,Cin] -> NHWC [B,H,W,Cout] = act(x.w*scale + bias)."""
@@ -550,8 +601,8 @@ def conv_bwd(gz, wt, x, s, d, labels, num_regions, ncls, want_ds=True):
     b, hy, wy, cy = gz.shape
     _, hx, wx, cx = x.shape
     dx = torch.empty_like(x)
-    g = s.shape[0]
-    ds = torch.empty(g, cx, device=x.device, dtype=torch.float32) if want_ds else None
+    want_ds = want_ds and s is not None
+    ds = torch.empty(s.shape[0], cx, device=x.device, dtype=torch.float32) if want_ds else None
     p = ConvBwdParams()
     p.gz, p.wt, p.dx, p.x, p.ds, p.s, p.d = fptr(gz), fptr(wt), fptr(dx), fptr(x), fptr(ds), fptr(s), fptr(d)
     if labels is not None:

@@ -92,6 +92,13 @@ SIGNATURES = {
     "e4s_instnorm_apply_f32": [c_p] * 7 + [c_i] * 5 + [c_p],
     "e4s_se_gate_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_region_mean_f32": [c_p, c_p, c_i, c_i, c_p] + [c_i] * 7 + [c_p],
+    "e4s_instnorm_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_instnorm_bwd_ws_doubles": [c_i, c_i, c_i],
+    "e4s_prelu_f32": [c_p, c_p, c_p, c_l, c_i, c_p],
+    "e4s_prelu_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p],
+    "e4s_prelu_bwd_ws_floats": [c_l, c_i],
+    "e4s_strided_scatter_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "e4s_region_mean_bwd_f32": [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_conv1x1_small_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_p],
     "e4s_noise_half_f32": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
     "e4s_pixelnorm_f32": [c_p, c_p, c_i, c_i, c_p],
@@ -107,7 +114,7 @@ SIGNATURES = {
     "e4s_grouped_linear_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p],
 }
 
-INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats"}       # size queries: return a count, not an error code
+INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats"}       # size queries: return a count, not an error code
 
 _lib = None
 

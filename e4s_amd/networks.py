@@ -77,33 +77,36 @@ class Net3(nn.Module):
             self._mlp_pack = (key, w0, b0, w2, b2)
         return self._mlp_pack[1:]
 
-    def _require_no_encoder_grad(self, img):
-        """The encoder has no backward yet (config 5's remaining piece): refuse loudly instead of detaching silently
-        when a gradient through get_style_vectors would be needed -- w.r.t. the image, or w.r.t. encoder parameters
-        that still require grad (Net3 leaves them trainable, networks.py:48).  Inference scripts call this under
-        torch.no_grad() (face_swap.py:150, optimization.py:186-188)."""
+    def _encoder_needs_grad(self, img):
+        """True when get_style_vectors must build an autograd graph: grad mode on and some encoder parameter trainable
+        (Net3 leaves them trainable, networks.py:48; coach.py:340-356 trains them).  Gradients w.r.t. the IMAGE are not
+        provided -- nothing in the reference asks for them -- and are refused loudly instead of detaching silently."""
         if not torch.is_grad_enabled():
-            return
-        if img.requires_grad or any(p.requires_grad for p in self.encoder.parameters()):
-            raise NotImplementedError(
-                "get_style_vectors under autograd: the regional encoder's backward is not built (generator and "
-                "LocalMLP gradients are: e4s_amd/autograd.py).  Call it under torch.no_grad(), or freeze the encoder "
-                "(for p in net.encoder.parameters(): p.requires_grad = False) to train G / the MLPs on fixed codes.")
+            return False
+        if img.requires_grad:
+            raise NotImplementedError("gradients w.r.t. the input image of the regional encoder are not implemented "
+                                      "(parameter gradients are: e4s_amd/encoder_autograd.py)")
+        return any(p.requires_grad for p in self.encoder.parameters())
 
     # ---- API ------------------------------------------------------------------------------------
     def get_style_vectors(self, img, mask):
         """networks.py:121-133: img [B,3,H,W] in [-1,1], one-hot mask [B,R,Hm,Wm] ->
         ([B,R,1280], zeros [B,512,16,16])."""
-        self._require_no_encoder_grad(img)
+        train = self._encoder_needs_grad(img)
         with torch.no_grad():
             labels, flags = K.mask_labels(mask)
             if self.G.strict_mask and not torch.cuda.is_current_stream_capturing() and bool(flags.item()):
                 raise NotImplementedError("get_style_vectors needs a one-hot parsing mask (labelMap2OneHot); the "
                                           "regional pooling of soft masks is not implemented")
             x256 = K.resize_bilinear_to_nhwc(img, 256, 256)                  # F.interpolate(...,'bilinear') :131
-            codes, last = self.encoder.encode_nhwc(x256, labels, mask.shape[1])
-            b, h, w, c = last.shape
-            return codes, torch.zeros(b, c, h, w, device=img.device, dtype=torch.float32)
+            if not train:
+                codes, last = self.encoder.encode_nhwc(x256, labels, mask.shape[1])
+                b, h, w, c = last.shape
+                return codes, torch.zeros(b, c, h, w, device=img.device, dtype=torch.float32)
+        from .encoder_autograd import EncoderFn
+        params = [p for p in self.encoder.parameters() if p.requires_grad]
+        codes = EncoderFn.apply(self.encoder, x256, labels, mask.shape[1], *params)
+        return codes, torch.zeros(img.shape[0], 512, 16, 16, device=img.device, dtype=torch.float32)
 
     def cal_style_codes(self, style_vectors):
         """networks.py:135-158 -> [B,R,n_latent,512]."""

@@ -229,6 +229,27 @@ int e4s_noise_bias_act_nhwc_f32(const float* x, const float* noise, const float*
                                 const float* bias, float* y, int B, int HW, int C, float alpha, float gain,
                                 void* stream);
 
+/* ---- backward of the regional style encoder (config 5: joint train step, src/training/coach.py:340-356) ------------- */
+/* InstanceNorm2d backward (+ the SE gate that multiplied its output): sums[b,c] = {A = sum_p dy, Bq = sum_p dy*xhat}
+ * (Bq is also dL/d(gate)), dx (+)= rstd * gate * (dy - A/N - xhat*Bq/N); x NHWC [B,HW,C], stats from
+ * e4s_instnorm_stats_f32, gate [B,C] or NULL; ws: e4s_instnorm_bwd_ws_doubles(B,HW,C) doubles.  Ordered reductions. */
+int e4s_instnorm_bwd_f32(const float* dy, const float* x, const float* stats, const float* gate, float* sums, float* dx,
+                         double* ws, int B, int HW, int C, int accumulate, void* stream);
+int64_t e4s_instnorm_bwd_ws_doubles(int B, int HW, int C);
+/* PReLU(C) on NHWC [npix, C]: y = u > 0 ? u : slope[c]*u;  backward: du = dy * (u > 0 ? 1 : slope[c]),
+ * dslope[c] = sum_p dy*u*[u <= 0] (ordered; ws: e4s_prelu_bwd_ws_floats(npix, C) floats) */
+int e4s_prelu_f32(const float* u, const float* slope, float* y, int64_t npix, int C, void* stream);
+int e4s_prelu_bwd_f32(const float* dy, const float* u, const float* slope, float* du, float* dslope, float* ws,
+                      int64_t npix, int C, void* stream);
+int64_t e4s_prelu_bwd_ws_floats(int64_t npix, int C);
+/* out[b, y*s, x*s, :] (+)= in[b, y, x, :], in NHWC [B,H,W,C], out NHWC [B,H*s,W*s,C]; without accumulate the other
+ * positions are zero-filled (zero insertion: the stride-2 conv's dgrad; with accumulate: MaxPool2d(1, s)'s backward) */
+int e4s_strided_scatter_f32(const float* in, float* out, int B, int H, int W, int C, int s, int accumulate, void* stream);
+/* backward of e4s_region_mean_f32: dfeat[b,p,c] (+)= dcodes[b, label(p), off + c] / count[b, label(p)];
+ * counts: int scratch [B*R] */
+int e4s_region_mean_bwd_f32(const float* dcodes, const uint8_t* labels, int Hm, int Wm, int* counts, float* dfeat, int B,
+                            int H, int W, int C, int R, int stride, int off, int accumulate, void* stream);
+
 /* ---- GPEN FullGenerator / Discriminator support ---------------------------------- */
 /* 1x1 conv with tiny Cin (<= 4; the 3 -> C stem ConvLayer, gpen_model.py:658, model.py:756): x NCHW [B,Cin,HW],
  * w [Cout,Cin], y NHWC (channel stride y_cstride or Cout): act(x.w*scale + bias), act 1 = leaky-relu(alpha)*gain */

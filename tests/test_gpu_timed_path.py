@@ -226,9 +226,11 @@ def test_graphed_swap_flags_soft_masks_and_guards_encoder_autograd():
     graphed(driven, hard, target, hard, hard, noise)
     graphed.validate()                                     # the flag was reset
     with torch.enable_grad():                              # nothing detaches silently
-        with pytest.raises(NotImplementedError):
-            net.get_style_vectors(driven, hard)
+        sv, _ = net.get_style_vectors(driven, hard)        # trainable encoder under autograd: a graph is built
+        assert sv.requires_grad
+        with pytest.raises(NotImplementedError):           # image gradients are not provided: refused, not dropped
+            net.get_style_vectors(driven.clone().requires_grad_(True), hard)
         for p in net.encoder.parameters():
             p.requires_grad = False
-        sv, _ = net.get_style_vectors(driven, hard)        # frozen encoder: allowed
+        sv, _ = net.get_style_vectors(driven, hard)        # frozen encoder: plain inference
         assert not sv.requires_grad

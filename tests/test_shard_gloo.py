@@ -158,3 +158,59 @@ def test_gloo_world2_overlapped_gather_of_uint8_images():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _worker_ddp(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from e4s_amd.ddp import GradAverager
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 7), torch.nn.Linear(7, 3))
+    model[3].weight.requires_grad = False                       # a frozen parameter is skipped
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 40, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    lo, hi = shard.shard_range(8, world, rank)
+    loss = torch.nn.functional.mse_loss(model(x[lo:hi]), y[lo:hi])
+    loss.backward()
+    if rank == 1:
+        model[2].bias.grad = None                               # a rank without a gradient contributes zeros
+    avg = GradAverager(model.parameters(), bucket_mb=0.02)      # tiny buckets: several collectives
+    nb = len(avg.buckets)
+    avg.average()
+    # single-process reference: mean of the two shard losses' gradients
+    ref = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 7), torch.nn.Linear(7, 3))
+    ref.load_state_dict(model.state_dict())
+    want = [torch.zeros_like(p) for p in ref.parameters()]
+    for r in range(world):
+        ref.zero_grad()
+        a, b = shard.shard_range(8, world, r)
+        torch.nn.functional.mse_loss(ref(x[a:b]), y[a:b]).backward()
+        for i, p in enumerate(ref.parameters()):
+            if p.grad is not None and not (r == 1 and i == 3):  # parameter index 3 = model[2].bias, dropped on rank 1
+                want[i] += p.grad / world
+    ok = nb > 1
+    for i, (p, w) in enumerate(zip(model.parameters(), want)):
+        if not p.requires_grad:
+            continue
+        ok = ok and p.grad is not None and bool(torch.allclose(p.grad, w, atol=1e-6, rtol=1e-5))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_averaging_equals_single_process():
+    """config 5's collective: bucketed all-reduce averaging of the gradients == the gradient of the mean of the shard
+    losses computed in one process."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ddp, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
