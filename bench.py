@@ -166,6 +166,38 @@ def gpen_leg(dev, reps=10):
     return out
 
 
+def train_leg(dev, lat, steps=3, batch=2):
+    """BASELINE.json configs[4] on ONE GPU: Net3.forward (encoder + LocalMLPs trainable, G frozen -- the reference's
+    default, networks.py:63-66) on a batch of 2 (train_options.py:24) at 1024^2 -> MSE loss -> backward through the HIP
+    generator / MLP / encoder backward kernels -> fused Adam.  The adversarial / LPIPS / ID terms of coach.py:340-356 need
+    the loss networks and are not part of this leg."""
+    from e4s_amd.optim import FusedAdam
+    net = Net3(make_opts(out_size=SIZE))
+    net.load_state_dict(synth.synth_state_dict(SIZE, KREM), strict=True)
+    net.latent_avg = lat.to(dev)
+    net = net.to(dev).train()
+    img = synth.synth_image(batch, SIZE, seed=7, tag="train_img").to(dev)
+    target = synth.synth_image(batch, SIZE, seed=7, tag="train_tgt").to(dev)
+    mask = synth.onehot(synth.synth_labels_face(batch, 512, seed=21)).to(dev)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = FusedAdam(params, lr=1e-4)
+
+    def one_step():
+        opt.zero_grad()
+        out, _ = net(img, mask)
+        torch.nn.functional.mse_loss(out, target).backward()
+        opt.step()
+    one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": round(ms, 2), "batch": batch, "images_per_s": round(batch * 1e3 / ms, 2),
+            "trainable_parameters": int(sum(p.numel() for p in params))}
+
+
 def cpu_baseline(sd, lat, inputs, hip_img0, hip_img0_b1):
     """One swap (sample 0 of the bench batch) on the host cores with the CPU oracle; returns the baseline record and the
     max-abs differences of (sample 0 of the timed batch, the batch-1 run) against it."""
@@ -200,6 +232,8 @@ def main():
                          "cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam each) and report the measured total")
     ap.add_argument("--f32-steps", type=int, default=5, help="also time this many steps with E4S_PRECISION=f32 (exact "
                                                              "fp32 MFMA everywhere) and report value_f32 / ms_per_step_f32")
+    ap.add_argument("--train-steps", type=int, default=3, help="configs[4] leg on one GPU: time this many joint train steps "
+                                                               "(batch 2 at 1024^2, encoder + LocalMLPs trainable)")
     ap.add_argument("--gather-fp32", action="store_true",
                     help="N>1: all-gather the fp32 [B,3,H,W] images (100 MB per 8 swaps) instead of the default uint8 HWC "
                          "images the pipeline ends with (torch_utils.tensor2im, packed on the device: 25 MB)")
@@ -344,6 +378,8 @@ def main():
             out["max_abs_default_vs_f32"] = float((img32 - img).abs().max())
             del g32
         out["gpen512"] = gpen_leg(dev)
+        if args.train_steps > 0:
+            out["config5_train_step_1gpu"] = train_leg(dev, lat, args.train_steps)
         if args.opt_steps > 0:
             ms = optimisation_leg(net, one, args.opt_steps)
             out["config3_opt_step_ms"] = ms

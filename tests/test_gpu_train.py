@@ -20,7 +20,7 @@ def _f32(monkeypatch):
     monkeypatch.setattr(K, "PRECISION", "f32")
 
 
-@pytest.mark.parametrize("cin,depth,stride,res", [(64, 128, 2, 32), (128, 128, 1, 16), (256, 256, 2, 16), (128, 128, 2, 32)])
+@pytest.mark.parametrize("cin,depth,stride,res", [(64, 128, 2, 32), (128, 128, 1, 16), (512, 512, 2, 16), (128, 256, 2, 32), (512, 512, 1, 8)])
 def test_encoder_unit_backward_vs_oracle_f64(cin, depth, stride, res):
     """One bottleneck_IR_SE_Ours unit: dx and every parameter gradient vs fp64 autograd of the oracle."""
     from e4s_amd import kernels as K
@@ -93,30 +93,38 @@ def test_net3_train_step_gradients_vs_oracle_autograd():
     out, _ = net(img.to(DEV), mask.to(DEV), randomize_noise=False)
     loss = torch.nn.functional.mse_loss(out, target.to(DEV))
     loss.backward()
-    # oracle
-    sd_r = {k: (v.clone().requires_grad_(True) if (k.startswith("encoder.") or k.startswith("MLPs.")) else v) for k, v in sd.items()}
-    sv, _ = orc.get_style_vectors(sd_r, img, mask)
-    codes = orc.cal_style_codes(sd_r, sv, lat, 13)
-    out_r, _ = orc.gen_img(sd_r, codes, mask, noise, 256, 13)
-    loss_r = torch.nn.functional.mse_loss(out_r, target)
+    # oracle in fp64 (an fp32 reference's own summation noise through ~80 layers is ~1e-2 of some gradients)
+    sd_r = {k: (v.double().requires_grad_(True) if (k.startswith("encoder.") or k.startswith("MLPs.")) else v.double())
+            for k, v in sd.items()}
+    sv, _ = orc.get_style_vectors(sd_r, img.double(), mask.double())
+    codes = orc.cal_style_codes(sd_r, sv, lat.double(), 13)
+    out_r, _ = orc.gen_img(sd_r, codes, mask.double(), [n.double() for n in noise], 256, 13)
+    loss_r = torch.nn.functional.mse_loss(out_r, target.double())
     loss_r.backward()
     assert maxabs(out, out_r) < 1e-3 and abs(float(loss) - float(loss_r)) < 1e-4 * float(loss_r)
-    worst = 0.0
-    checked = 0
+    # Metric: relative L2 error per tensor, plus the share of elements off by more than 1e-3 of the tensor's scale.  A pure
+    # max-abs bound is the wrong tool here: PReLU / leaky-ReLU derivatives are discontinuous at 0, and a pre-activation of
+    # magnitude ~1e-7 (there is one in body.6 at this input) lands on the other side of the kink in ANY two fp32
+    # implementations -- that single pixel changes 0.3 % of one conv's weight gradient by up to 2 % of its scale.
+    worst_l2, worst_name, worst_frac, checked = 0.0, "", 0.0, 0
     for name, p in net.named_parameters():
         if not p.requires_grad:
             assert not (name.startswith("encoder.") or name.startswith("MLPs."))
             continue
         assert p.grad is not None, name
-        ref = sd_r[name].grad
         if ".fc1." in name or ".fc2." in name:
             continue                                   # rounding-residue gradients of the SE layers (see the unit test)
-        s = float(ref.abs().max())
-        err = maxabs(p.grad, ref) / max(s, 1e-12)
-        worst = max(worst, err)
+        ref = sd_r[name].grad
+        d = p.grad.detach().cpu().double() - ref
+        l2 = float(d.norm() / ref.norm().clamp_min(1e-30))
+        frac = float((d.abs() > 1e-3 * ref.abs().max()).double().mean())
+        if l2 > worst_l2:
+            worst_l2, worst_name = l2, name
+        worst_frac = max(worst_frac, frac)
         checked += 1
-        assert err < 5e-3, (name, err, s)
-    print(f"Net3 train step: {checked} parameter tensors, worst relative max-abs gradient error {worst:.3e}")
+        assert l2 < 2e-3 and frac < 0.01, (name, l2, frac)
+    print(f"Net3 train step: {checked} parameter tensors vs fp64 autograd: worst relative L2 gradient error {worst_l2:.3e} "
+          f"({worst_name}); worst share of elements off by > 1e-3 of scale {worst_frac:.2e}")
     assert checked > 100
 
 
