@@ -7,8 +7,8 @@ for config 5 (`train_G=True`), the gradients of every generator / LocalMLP param
 e4s_demod_grad_f32, e4s_torgb_bwd_*_f32, e4s_upfirdn2d_f32, e4s_fused_bias_act_f32), including the transposed
 contractions of the style prologue's chain rule and of the LocalMLP backward (e4s_grouped_linear_t_f32,
 e4s_grouped_outer_f32); every split reduction adds its partial sums in a fixed order, so gradients are bit-reproducible.
-Only the generator's conv weight gradients (config 5) still build their operands natively and contract them with the
-BLAS (`styled_conv_weight_grad`), as do the tiny modulation-weight outer products.
+Conv weight gradients (config 5) run on the fp32-MFMA weight-gradient kernel (e4s_conv_wgrad_f32); only the tiny
+modulation-weight / polyphase-fold outer products are plain matmuls on [G,C]-sized operands.
 """
 import math
 
@@ -60,33 +60,23 @@ def _polyphase_map(blur_kernel):
 
 def styled_conv_weight_grad(rec, extras, num_regions):
     """dL/d(conv.weight) [1,Cout,Cin,3,3] of one fused StyledConv (config 5, train_G=True).
-    out_pre = d * sum W s x:  dW = (gz*d)^T (s*x shifted)  [a plain GEMM over all pixels, operands built by
-    e4s_shift_scale_f32]  -  W * ((dd*d^3)^T s^2)  [through the demodulation]."""
+    out_pre = d * sum W s x:  dW = (gz*d)^T (s*x shifted)  [the contraction over all pixels: e4s_conv_wgrad_f32, region
+    scales applied to the operands on the fly]  -  W * ((dd*d^3)^T s^2)  [through the demodulation]."""
     layer = rec["layer"]
     conv = layer.conv
     x, s, d, labels = rec["x"], rec["s"], rec["d"], rec["labels"]
     gz, dd3 = extras["gz"], extras["dd3"]
     b, ho, wo, cout = gz.shape
     _, h, w, cin = x.shape
-    gds = K.shift_scale(gz, d, labels, num_regions, (ho, wo))
     wraw = conv.weight.detach()[0]                                   # [Cout,Cin,3,3]
+    kw = dict(s=s, d=d, labels=labels, num_regions=num_regions)
     if not conv.upsample:
-        g2 = gds.view(-1, cout)
-        taps = []
-        for ty in range(3):
-            for tx in range(3):
-                xs = K.shift_scale(x, s, labels, num_regions, (h, w), dy=ty - 1, dx=tx - 1)
-                taps.append(g2.t() @ xs.view(-1, cin))
-        dw = torch.stack(taps, -1).view(cout, cin, 3, 3)
+        dw = K.conv_wgrad(gz, x, **kw).permute(1, 2, 0).reshape(cout, cin, 3, 3)
     else:
-        deff = []
-        for ph in range(4):
-            py, px = ph >> 1, ph & 1
-            g2 = gds[:, py::2, px::2].reshape(-1, cout)
-            for e in range(9):
-                xs = K.shift_scale(x, s, labels, num_regions, (h, w), dy=e // 3 - 1, dx=e % 3 - 1, os=2, py=py, px=px)
-                deff.append(g2.t() @ xs.view(-1, cin))
-        deff = torch.stack(deff, 0).view(36, cout * cin)
+        # gradient w.r.t. the 4 x 9 polyphase kernels (one e4s_conv_wgrad_f32 call per output phase), folded back onto
+        # the 3 x 3 weight with the transpose of the polyphase map
+        deff = torch.stack([K.conv_wgrad(gz, x, ostride=2, phase=(ph >> 1, ph & 1), anchors=(h, w), **kw)
+                            for ph in range(4)]).view(36, cout * cin)
         cmap = _polyphase_map(conv.blur.kernel).to(deff.device).view(36, 9)
         dw = (cmap.t() @ deff).view(9, cout, cin).permute(1, 2, 0).reshape(cout, cin, 3, 3)
     dw = dw - wraw * (dd3.t() @ (s * s)).view(cout, cin, 1, 1)

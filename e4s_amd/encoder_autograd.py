@@ -8,8 +8,8 @@ same kernel schedule with a tape, the backward walks the 24 IR-SE units in rever
     conv 1x1 stride 2            dgrad: e4s_conv_mfma_f32 with the transposed weights + e4s_strided_scatter_f32
     PReLU                        e4s_prelu_bwd_f32
     IN(x)                        e4s_instnorm_bwd_f32
-    weight gradients             operand builder e4s_shift_scale_f32 + one [Cout x P] x [P x Cin] BLAS contraction per tap
-                                 (as the generator's, autograd.py:styled_conv_weight_grad); the 3 -> 64 stem via im2col
+    weight gradients             e4s_conv_wgrad_f32 (fp32 MFMA over the pixels, all 9 taps per block); the 3 -> 64 stem via
+                                 an im2col + one BLAS contraction
 
 The exact-zero SE input (the spatial mean of an instance-normalised map, helpers.py:64-66) makes dL/d(pooled) flow back
 only through rounding residue; that path (O(1e-8) of the gradient) is dropped."""
@@ -21,19 +21,12 @@ from .encoders import _pack3x3, _conv3x3, _conv_strided
 
 
 def _wgrad(gz, xin, stride, ntaps):
-    """dW [Cout,Cin,k,k] of y = conv(xin, W, stride, padding=k//2): gz NHWC [B,Ho,Wo,Cout], xin NHWC [B,Hi,Wi,Cin]."""
-    b, ho, wo, cout = gz.shape
-    cin = xin.shape[3]
-    g2 = gz.reshape(-1, cout)
-    if ntaps == 1:
-        xs = K.shift_scale(xin, None, None, 1, (ho, wo), istride=stride)
-        return (g2.t() @ xs.view(-1, cin)).view(cout, cin, 1, 1)
-    taps = []
-    for ty in range(3):
-        for tx in range(3):
-            xs = K.shift_scale(xin, None, None, 1, (ho, wo), istride=stride, dy=ty - 1, dx=tx - 1)
-            taps.append(g2.t() @ xs.view(-1, cin))
-    return torch.stack(taps, -1).view(cout, cin, 3, 3)
+    """dW [Cout,Cin,k,k] of y = conv(xin, W, stride, padding=k//2): gz NHWC [B,Ho,Wo,Cout], xin NHWC [B,Hi,Wi,Cin], on the
+    fp32-MFMA weight-gradient kernel (e4s_conv_wgrad_f32: the contraction over the pixels, split-K, ordered reduction)."""
+    cout, cin = gz.shape[3], xin.shape[3]
+    dw = K.conv_wgrad(gz, xin, ntaps=ntaps, istride=stride)                # [ntaps, Cout, Cin]
+    k = 3 if ntaps == 9 else 1
+    return dw.permute(1, 2, 0).reshape(cout, cin, k, k)
 
 
 def _wt(conv):

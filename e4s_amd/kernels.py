@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import lib
-from .lib import ConvBwdParams, ConvParams, c_p, call, fptr, ptr, stream
+from .lib import ConvBwdParams, ConvParams, ConvWgradParams, c_p, call, fptr, ptr, stream
 
 BM = 128          # GEMM row tile of e4s_conv_mfma_f32
 # Arithmetic of the contractions that have a split-bf16 kernel (the encoder's stride-1 3x3 convs):
@@ -487,6 +487,30 @@ def adam_step(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step):
     """torch.optim.Adam's update of one fp32 tensor, in place, as ONE kernel."""
     call("e4s_adam_step_f32", fptr(p), fptr(_f32(grad)), fptr(m), fptr(v), p.numel(), float(lr), float(beta1), float(beta2),
          float(eps), float(weight_decay), int(step), stream())
+
+
+def conv_wgrad(gz, x, *, ntaps=9, istride=1, anchors=None, ostride=1, phase=(0, 0), s=None, d=None, labels=None,
+               num_regions=1):
+    """dw [ntaps, Cout, Cin] of a 3x3 / 1x1 conv (see e4s_conv_wgrad_f32): gz NHWC [B,Ho,Wo,Cout], x NHWC [B,Hi,Wi,Cin].
+    anchors default to the output grid (ostride 1) / the input grid (polyphase phase, ostride 2)."""
+    b, ho, wo, cout = gz.shape
+    _, hi, wi, cin = x.shape
+    if anchors is None:
+        anchors = (ho // ostride, wo // ostride)
+    dw = torch.empty(ntaps, cout, cin, device=x.device, dtype=torch.float32)
+    p = ConvWgradParams()
+    p.gz, p.x, p.dw, p.s, p.d = fptr(_f32(gz)), fptr(x), fptr(dw), fptr(s), fptr(d)
+    if labels is not None:
+        p.labels, p.Hm, p.Wm, p.R = ptr(labels), labels.shape[1], labels.shape[2], num_regions
+    else:
+        p.labels, p.Hm, p.Wm, p.R = None, 0, 0, 1
+    p.B, p.Hi, p.Wi, p.Cin, p.Ha, p.Wa, p.Ho, p.Wo, p.Cout = b, hi, wi, cin, anchors[0], anchors[1], ho, wo, cout
+    p.istride, p.ostride, p.py, p.px, p.ntaps = istride, ostride, phase[0], phase[1], ntaps
+    p.ws = None
+    ws = torch.empty(lib.load().e4s_conv_wgrad_ws_floats(ctypes.byref(p)), device=x.device, dtype=torch.float32)
+    p.ws = fptr(ws)
+    call("e4s_conv_wgrad_f32", ctypes.byref(p), stream())
+    return dw
 
 
 # ---- encoder backward (config 5) -------------------------------------------------------------------

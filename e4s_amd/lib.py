@@ -47,6 +47,16 @@ class ConvBwdParams(ctypes.Structure):
     ]
 
 
+class ConvWgradParams(ctypes.Structure):
+    """Mirror of ``e4s_conv_wgrad_params`` (include/e4s_hip.h)."""
+    _fields_ = [
+        ("gz", c_p), ("x", c_p), ("dw", c_p), ("ws", c_p), ("s", c_p), ("d", c_p), ("labels", c_p),
+        ("Hm", c_i), ("Wm", c_i), ("R", c_i),
+        ("B", c_i), ("Hi", c_i), ("Wi", c_i), ("Cin", c_i), ("Ha", c_i), ("Wa", c_i), ("Ho", c_i), ("Wo", c_i), ("Cout", c_i),
+        ("istride", c_i), ("ostride", c_i), ("py", c_i), ("px", c_i), ("ntaps", c_i),
+    ]
+
+
 # name -> argtypes (all return int except the two info calls); keep in sync with include/e4s_hip.h
 SIGNATURES = {
     "e4s_fused_bias_act_f32": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_p],
@@ -92,6 +102,8 @@ SIGNATURES = {
     "e4s_instnorm_apply_f32": [c_p] * 7 + [c_i] * 5 + [c_p],
     "e4s_se_gate_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_region_mean_f32": [c_p, c_p, c_i, c_i, c_p] + [c_i] * 7 + [c_p],
+    "e4s_conv_wgrad_f32": [ctypes.POINTER(ConvWgradParams), c_p],
+    "e4s_conv_wgrad_ws_floats": [ctypes.POINTER(ConvWgradParams)],
     "e4s_instnorm_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_instnorm_bwd_ws_doubles": [c_i, c_i, c_i],
     "e4s_prelu_f32": [c_p, c_p, c_p, c_l, c_i, c_p],
@@ -114,7 +126,7 @@ SIGNATURES = {
     "e4s_grouped_linear_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p],
 }
 
-INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats"}       # size queries: return a count, not an error code
+INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats"}       # size queries: return a count, not an error code
 
 _lib = None
 

@@ -187,6 +187,25 @@ typedef struct {
  * ds[g,ci] += sum_{q,tap: r(p)=g} x[q,ci] * (sum_co wt*d*gz)      -- one fp32-MFMA pass, Cx % 64 == 0, Cy % 32 == 0 */
 int e4s_conv_bwd_mfma_f32(const e4s_conv_bwd_params* p, void* stream);
 int64_t e4s_conv_bwd_ws_floats(const e4s_conv_bwd_params* p);
+/* Weight gradient of the 3x3 / 1x1 convs on fp32 MFMA (config 5): the contraction over the PIXELS of the operands the
+ * forward contracts over (Cin, taps):  dw[tap][co][ci] = sum_a (gz[o(a)][co] * d[g(a)][co]) * (x[a*istride + tap - 1][ci]
+ * * s[g(a)][ci]),  o(a) = a*ostride + (py, px), g(a) = b*R + label(o(a)) (b when labels == NULL); 1x1: x[a*istride]. */
+typedef struct {
+    const float* gz;         /* dL/d(out_pre), NHWC [B, Ho, Wo, Cout] */
+    const float* x;          /* forward input, NHWC [B, Hi, Wi, Cin] */
+    float* dw;               /* out (overwritten): [ntaps][Cout][Cin] -- the tap-packed layout of e4s_pack_taps_f32 */
+    float* ws;               /* scratch: e4s_conv_wgrad_ws_floats(p) floats (split-K slabs, added in a fixed order) */
+    const float* s;          /* [G][Cin] forward modulation or NULL */
+    const float* d;          /* [G][Cout] forward demodulation coefficient or NULL */
+    const uint8_t* labels;   /* [B,Hm,Wm] or NULL */
+    int Hm, Wm, R;
+    int B, Hi, Wi, Cin, Ha, Wa, Ho, Wo, Cout;
+    int istride;             /* 1 or 2 */
+    int ostride, py, px;     /* 1,0,0; or 2 and the phase of a polyphase up-conv (one call per phase) */
+    int ntaps;               /* 9 or 1 */
+} e4s_conv_wgrad_params;
+int e4s_conv_wgrad_f32(const e4s_conv_wgrad_params* p, void* stream);
+int64_t e4s_conv_wgrad_ws_floats(const e4s_conv_wgrad_params* p);
 /* forward-packed weights [ncls][9][Cout][Cin] -> backward layout [ncls][9][Cin][Cout], taps flipped */
 int e4s_pack_taps_bwd_f32(const float* w, float* wt, int ncls, int cout, int cin, void* stream);
 /* dd[b,r,co] = sum_{p in r} gz[p,co] * (lrelu^-1(y[p,co])/gain - noise_w*noise[p] - bias[co])   (= d * dL/dd; the

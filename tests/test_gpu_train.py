@@ -148,3 +148,24 @@ def test_fused_adam_train_loop_descends():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,stride,ntaps", [(2, 16, 32, 64, 128, 1, 9), (1, 20, 12, 96, 32, 1, 9), (2, 16, 16, 128, 64, 2, 9),
+                                                         (3, 8, 24, 64, 160, 2, 1), (1, 64, 64, 32, 32, 1, 9)])
+def test_conv_wgrad_kernel_vs_fp64(b, h, w, cin, cout, stride, ntaps):
+    """e4s_conv_wgrad_f32 (fp32 MFMA over the pixels, split-K with ordered reduction) vs torch's fp64 conv weight gradient;
+    ragged tiles, 32- and 160-channel (partial 64-wide tiles) operands, stride 2, 1x1."""
+    from e4s_amd import kernels as K
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(13)
+    k = 3 if ntaps == 9 else 1
+    x = torch.randn(b, cin, h, w, generator=g, dtype=torch.float64)
+    wt = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64).requires_grad_(True)
+    y = F.conv2d(x, wt, stride=stride, padding=k // 2)
+    gz = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    (y * gz).sum().backward()
+    dw = K.conv_wgrad(K.nchw_to_nhwc(gz.float().to(DEV)), K.nchw_to_nhwc(x.float().to(DEV)), ntaps=ntaps, istride=stride)
+    got = dw.permute(1, 2, 0).reshape(cout, cin, k, k)
+    assert maxabs(got, wt.grad) < 2e-5 * float(wt.grad.abs().max())
+    dw2 = K.conv_wgrad(K.nchw_to_nhwc(gz.float().to(DEV)), K.nchw_to_nhwc(x.float().to(DEV)), ntaps=ntaps, istride=stride)
+    assert torch.equal(dw, dw2)                                        # ordered split-K: bit-reproducible
