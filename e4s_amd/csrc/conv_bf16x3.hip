@@ -81,8 +81,8 @@ __device__ __forceinline__ f32x8 load8(const float* src) {
     return f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
 }
 
-struct TileId {          // one 16x16-pixel x BN-column output tile
-    int tb, tyb, txb, n0;
+struct TileId {          // one 16x16-pixel x BN-column output tile (x one K split: input-channel chunks [c_lo, c_hi))
+    int tb, tyb, txb, n0, ks, c_lo, c_hi;
 };
 
 // Plain kernel, PERSISTENT: the grid is one block per CU (or fewer tiles); block b walks tiles b, b + grid, ... and the
@@ -97,7 +97,8 @@ struct TileId {          // one 16x16-pixel x BN-column output tile
 //   (column n = phase * Cout + co) over the input grid, pixel-shuffled by the epilogue: output pixel (2ay+py, 2ax+px).
 template <typename C, int XF, bool SHUF>
 __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_params p, const int ntn, const int tx_n,
-                                                            const int per_img, const int ntiles) {
+                                                            const int per_img, const int ntiles, const int ksplit,
+                                                            const int cper) {
     constexpr int BM = PBM, BN = C::BN, NTHR = PNTHR, WN = C::WN, TM = C::TM, TN = C::TN, TH = PTH, TPS = C::TPS;
     constexpr int NSTG = C::NSTG, PIECE = C::PIECE, BITEMS = C::BITEMS, BJ = C::BJ;
     constexpr int A_BYTES = PA_BYTES, B_BYTES = C::B_BYTES, NZ = SHUF ? 4 : 1;
@@ -114,8 +115,16 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
     const int G = gridDim.x;
     const int first = xcd_remap(blockIdx.x, G);
 
-    auto decode = [&](int t) -> TileId {
+    const int nchunk = p.Cin / KC;
+    // split-K (ksplit > 1; launches with too few tiles to fill the chip, e.g. batch-1 latency runs): the input-channel
+    // chunks of a tile are divided over ksplit consecutive tile ids; each writes its raw partial accumulators to
+    // p.splitk_ws[ks] and a second kernel adds the slabs in order and applies the epilogue
+    auto decode = [&](int t0) -> TileId {
         TileId id;
+        const int t = t0 / ksplit;
+        id.ks = t0 - t * ksplit;
+        id.c_lo = id.ks * cper;
+        id.c_hi = min(id.c_lo + cper, nchunk);
         const int mt = t / ntn, nt = t - mt * ntn;
         id.n0 = nt * BN;
         id.tb = mt / per_img;
@@ -141,7 +150,6 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
         }
     };
 
-    const int nchunk = p.Cin / KC;
     const int ngemm = SHUF ? 4 * p.Cout : p.Cout;
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(p.w);
     const size_t wrow = (size_t)p.Cin * 4;             // bytes per (tap, cout) row of the split weights
@@ -210,18 +218,18 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
 
     // ---- prologue: whole halo of tile 0 / chunk 0, weights of its stage 0, its metadata ----
     {
-        const float* xb = p.x + (size_t)cur.tb * img_stride;
+        const float* xb = p.x + (size_t)cur.tb * img_stride + cur.c_lo * KC;
         for (int item = tid; item < PITEMS; item += NTHR) {
             bool ok;
             const size_t off = item_src(cur, item, ok);
             f32x8 v = load8(xb + off);
-            if (XF) v = apply_xop(v, load_xop(cur.tb, (item & 3) * 8));
+            if (XF) v = apply_xop(v, load_xop(cur.tb, cur.c_lo * KC + (item & 3) * 8));
             if (!ok) v = zero8;                                 // zero padding applies AFTER the transform (conv pad)
             split_store(sA + item_dst(item), v);
         }
         f32x4 pb[BJ];
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wbytes + b_src(j, cur.n0, 0, 0));
+        for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wbytes + b_src(j, cur.n0, 0, cur.c_lo));
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
             if (b_ok[j]) *reinterpret_cast<f32x4*>(sB + b_dst[j]) = pb[j];
@@ -265,13 +273,13 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-        for (int chunk = 0; chunk < nchunk; ++chunk) {
-            const bool last_chunk = (chunk + 1 == nchunk);
+        for (int chunk = cur.c_lo; chunk < cur.c_hi; ++chunk) {
+            const bool last_chunk = (chunk + 1 == cur.c_hi);
             // owner of chunk cg+1 (whose halo is fetched during this chunk) and of the stage after this chunk's last
             const TileId& own = last_chunk ? nxt : cur;
             const bool have_nc = !last_chunk || has_next;
-            const float* xb_n = p.x + (size_t)own.tb * img_stride + (last_chunk ? 0 : (chunk + 1) * KC);
-            const int c_n = last_chunk ? 0 : chunk + 1;
+            const int c_n = last_chunk ? nxt.c_lo : chunk + 1;
+            const float* xb_n = p.x + (size_t)own.tb * img_stride + c_n * KC;
 #pragma clang loop unroll_count(NSTG <= 3 ? NSTG : 1)
             for (int ts = 0; ts < NSTG; ++ts) {
                 const unsigned char* Ab = sA + (cg & 1) * A_BYTES;
@@ -396,6 +404,8 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
             }
             const float gain = (p.act == 1) ? p.gain : 1.f;
             const bool do_act = p.act != 0;
+            const bool raw = ksplit > 1;
+            float* yo = raw ? p.splitk_ws + (size_t)cur.ks * ((size_t)p.B * p.Ho * p.Wo * ycs) : p.y;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -405,9 +415,12 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                     if (off < 0) continue;
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
-                        float v = acc[tm][tn][r] * osc[tn] + sn[row * NZ + (SHUF ? nzi[tn] : 0)] + bsv[tn];
-                        if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
-                        p.y[(size_t)off * ycs + coff[tn]] = v;
+                        float v = acc[tm][tn][r];
+                        if (!raw) {
+                            v = v * osc[tn] + sn[row * NZ + (SHUF ? nzi[tn] : 0)] + bsv[tn];
+                            if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
+                        }
+                        yo[(size_t)off * ycs + coff[tn]] = v;
                     }
                 }
             }
@@ -926,6 +939,45 @@ __global__ void split_bf16x2_kernel(const float* __restrict__ w, unsigned short*
     *reinterpret_cast<bf16x8*>(d + 32) = l;
 }
 
+// second stage of a split-K launch: y = act(sum_ks ws[ks] * out_scale[b] + noise_w * noise + bias), slabs added in order
+__global__ void splitk_epilogue_kernel(const e4s_conv_params p, const int ksplit, const int ycs, const int64_t hw,
+                                       const int64_t n4) {
+    const int C4 = p.Cout / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)(i % C4) * 4;
+    const int64_t pix = i / C4;
+    const int64_t b = pix / hw;
+    const size_t slab = (size_t)p.B * hw * ycs;
+    const float* src = p.splitk_ws + (size_t)pix * ycs + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab);
+    float nz = 0.f;
+    if (p.noise) nz = p.noise_w[0] * p.noise[b * p.noise_bstride + (pix - b * hw)];
+    const float gain = (p.act == 1) ? p.gain : 1.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = v[e] * (p.out_scale ? p.out_scale[b * p.Cout + c + e] : 1.f) + nz + (p.bias ? p.bias[c + e] : 0.f);
+        if (p.act) t = (t > 0.f ? t : t * (p.act == 2 ? p.slope[c + e] : p.alpha)) * gain;
+        v[e] = t;
+    }
+    *reinterpret_cast<f32x4*>(p.y + (size_t)pix * ycs + c) = v;
+}
+
+// split-K policy of the plain kernel: only when the tiles alone leave most CUs idle; every split keeps >= 2 chunks
+void plain_split(const e4s_conv_params& p, int ntn, int& ksplit, int& cper) {
+    const int nchunk = p.Cin / KC;
+    const int64_t tiles = (int64_t)p.B * ((p.Ha + PTH - 1) / PTH) * ((p.Wa + TW - 1) / TW) * ntn;
+    ksplit = 1;
+    cper = nchunk;
+    if (tiles >= 128 || nchunk < 4) return;
+    int want = (int)((256 + tiles - 1) / tiles);
+    if (want > nchunk / 2) want = nchunk / 2;
+    if (want < 2) return;
+    cper = (nchunk + want - 1) / want;
+    ksplit = (nchunk + cper - 1) / cper;
+}
+
 int num_cus() {
     static int cus[64] = {0};
     int dev = 0;
@@ -948,12 +1000,23 @@ int launch(const e4s_conv_params& p, hipStream_t st) {
     const int ngemm = SHUF ? 4 * p.Cout : p.Cout;
     const int ntn = ngemm / C::BN;
     const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + PTH - 1) / PTH) * tx_n;
-    const int64_t ntiles = (int64_t)p.B * per_img * ntn;
+    int ksplit, cper;
+    plain_split(p, ngemm / C::BN, ksplit, cper);
+    if (ksplit > 1 && !p.splitk_ws) return (int)hipErrorInvalidValue;
+    const int64_t ntiles = (int64_t)p.B * per_img * ntn * ksplit;
     if (ntiles <= 0) return 0;
     if (ntiles >= (1ll << 31)) return (int)hipErrorInvalidValue;
     const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());        // persistent: one block per CU
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PNTHR), SMEM, st, p, ntn, tx_n, per_img, (int)ntiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PNTHR), SMEM, st, p, ntn, tx_n, per_img, (int)ntiles, ksplit, cper);
     E4S_CHECK_LAUNCH();
+    if (ksplit > 1) {
+        const int ycs = p.y_cstride ? p.y_cstride : p.Cout;
+        const int64_t npix = (int64_t)p.B * p.Ho * p.Wo;
+        const int64_t n4 = npix * (p.Cout / 4);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p, ksplit, ycs,
+                           (int64_t)p.Ho * p.Wo, n4);
+        E4S_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -995,6 +1058,18 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     if (p.Cout % 128 == 0) return launch_xf<CfgL, false>(p, st);
     if (p.Cout % 64 == 0) return launch_xf<CfgM, false>(p, st);
     return launch_xf<CfgS, false>(p, st);
+}
+
+extern "C" int64_t e4s_conv_bf16x3_ws_floats(const e4s_conv_params* pp) {
+    const e4s_conv_params& p = *pp;
+    if (p.labels || p.istride != 1 || p.ntaps != 9 || p.Cin % KC) return 0;      // region / gather kernels: no split-K
+    const bool up = (p.ncls == 4);
+    const int ngemm = up ? 4 * p.Cout : p.Cout;
+    const int bn = (up || p.Cout % 128 == 0) ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
+    int ksplit, cper;
+    plain_split(p, ngemm / bn, ksplit, cper);
+    if (ksplit <= 1) return 0;
+    return (int64_t)ksplit * p.B * p.Ho * p.Wo * (p.y_cstride ? p.y_cstride : p.Cout);
 }
 
 extern "C" int e4s_split_bf16x2_f32(const float* w, void* out, int64_t rows, int cin, void* stream) {

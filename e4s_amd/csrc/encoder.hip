@@ -317,6 +317,7 @@ static int instnorm_nsplit(int B, int HW, int C) {
     int nsplit = 2048 / (B * (C / 64) > 0 ? B * (C / 64) : 1);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > HW / 64) nsplit = HW / 64 > 0 ? HW / 64 : 1;
+    if (nsplit > 64) nsplit = 64;            // the finalize pass adds the slots serially per (b, c)
     return nsplit;
 }
 

@@ -282,6 +282,9 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
                 or (in_stats is not None and (in_scale is not None or labels is not None))):
             raise RuntimeError("e4s_conv_bf16x3_f32 does not cover this contraction")
         p.w = fptr(w_split)
+        nws = lib.load().e4s_conv_bf16x3_ws_floats(ctypes.byref(p))        # split-K partial sums (few-tile launches)
+        skws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
+        p.splitk_ws = fptr(skws)
         call("e4s_conv_bf16x3_f32", ctypes.byref(p), stream())
     elif in_stats is not None:
         raise RuntimeError("fused InstanceNorm staging exists only in e4s_conv_bf16x3_f32")
@@ -306,7 +309,15 @@ def want_bf16x3(b, h, w, cin, cout, ncls=1, masked=False):
     # 256-pixel x 128/64/32-column tiles (unmasked polyphase up-conv: ONE GEMM with 4*Cout columns)
     n = 4 * cout if (ncls == 4 and not masked) else cout
     bn = 128 if n % 128 == 0 else 64 if n % 64 == 0 else 32
-    return b * ((h + 15) // 16) * ((w + 15) // 16) * (n // bn) * (ncls if masked else 1) >= BF16X3_MIN_BLOCKS
+    tiles = b * ((h + 15) // 16) * ((w + 15) // 16) * (n // bn) * (ncls if masked else 1)
+    if tiles >= BF16X3_MIN_BLOCKS:
+        return True
+    if masked:
+        return False
+    # few tiles (batch-1 latency runs): the plain kernel splits the input channels over blocks (csrc: plain_split)
+    nchunk = cin // 32
+    split = min(nchunk // 2, -(-256 // tiles)) if nchunk >= 4 else 1
+    return tiles * max(split, 1) >= 64
 
 
 def split_bf16x2(w):

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe4s_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -33,7 +33,7 @@ class ConvParams(ctypes.Structure):
         ("labels", c_p), ("Hm", c_i), ("Wm", c_i),
         ("noise", c_p), ("noise_w", c_p), ("noise_bstride", c_l), ("noise_per_channel", c_i),
         ("bias", c_p), ("slope", c_p), ("act", c_i), ("alpha", c_f), ("gain", c_f),
-        ("in_stats", c_p), ("y_cstride", c_i), ("tap_shift", c_i),
+        ("in_stats", c_p), ("y_cstride", c_i), ("splitk_ws", c_p), ("tap_shift", c_i),
     ]
 
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "e4s_conv_mfma_f32": [ctypes.POINTER(ConvParams), c_i, c_p],
     "e4s_upconv_mfma_f32": [ctypes.POINTER(ConvParams), c_p, c_p],
     "e4s_conv_bf16x3_f32": [ctypes.POINTER(ConvParams), c_p],
+    "e4s_conv_bf16x3_ws_floats": [ctypes.POINTER(ConvParams)],
     "e4s_split_bf16x2_f32": [c_p, c_p, c_l, c_i, c_p],
     "e4s_upconv_blocks_per_cu": [],
     "e4s_instnorm_ws_doubles": [c_i, c_i, c_i],
@@ -126,7 +127,7 @@ SIGNATURES = {
     "e4s_grouped_linear_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p],
 }
 
-INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats"}       # size queries: return a count, not an error code
+INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats"}       # size queries: return a count, not an error code
 
 _lib = None
 

@@ -129,6 +129,10 @@ typedef struct {
     int y_cstride;           /* channels per pixel of the buffer y points into (0 = Cout): the conv may write the first Cout
                                 channels of a wider NHWC tensor -- GPEN's StyledConv concatenates its noise (the encoder
                                 feature map) behind the conv output (gpen_model.py:343-353).  Plain (unlabelled) kernels */
+    float* splitk_ws;        /* e4s_conv_bf16x3_f32, unlabelled 3x3: scratch of e4s_conv_bf16x3_ws_floats(p) floats (0 -> may be
+                                NULL): launches with too few tiles to fill the chip (batch-1 latency runs) split the input
+                                channels over several blocks per tile; the raw partial sums land here and are added in a
+                                fixed order by a second kernel that also applies the epilogue */
     int tap_shift;           /* gather mode (istride 2 / ntaps 1 kernels): input coord = anchor*istride + tap - 1 + tap_shift;
                                 1 = the padding-0 stride-2 conv behind a Blur (ConvLayer, model.py:683-700) */
 } e4s_conv_params;
@@ -161,6 +165,7 @@ int e4s_upconv_blocks_per_cu(void);    /* diagnostic: occupancy of that kernel a
  *   labels != NULL  region-select (per-pixel style on the A fragment): masked StyledConvs (model.py:386-400), plain or
  *                   polyphase; Cout % 128 == 0, in_scale required, act != 2 */
 int e4s_conv_bf16x3_f32(const e4s_conv_params* p, void* stream);
+int64_t e4s_conv_bf16x3_ws_floats(const e4s_conv_params* p);
 /* w fp32 [rows][cin] -> out [rows][cin/32][32 hi bf16 | 32 lo bf16] (same byte size), cin % 32 == 0 */
 int e4s_split_bf16x2_f32(const float* w, void* out, int64_t rows, int cin, void* stream);
 

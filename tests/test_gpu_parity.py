@@ -207,6 +207,39 @@ def test_conv_bf16x3_gather_stride2_vs_conv2d_f64(b, h, w, cin, cout, ntaps):
     assert err < 1e-4 * float(want.abs().max()), (err, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,kind", [(2, 32, 32, 512, 512, "in"), (1, 16, 16, 256, 128, "style"), (1, 16, 32, 128, 64, "plain"),
+                                                 (1, 8, 8, 256, 64, "up")])
+def test_conv_bf16x3_split_k_vs_unsplit_path(b, h, w, cin, cout, kind):
+    """Few-tile launches (batch-1 latency runs) split the input channels over blocks and add the slabs in a second kernel:
+    against the fp64 convolution, with every epilogue flavour (fused InstanceNorm + PReLU, style/demod/noise/bias/lrelu,
+    none, pixel-shuffled up-conv), and bit-reproducible."""
+    from e4s_amd import kernels as K, lib
+    g = torch.Generator().manual_seed(37)
+    x = (torch.randn(b, h, w, cin, generator=g) * 1.2 + 0.1).to(DEV)
+    ncls = 4 if kind == "up" else 1
+    wt = torch.randn(ncls, 9, cout, cin, generator=g).to(DEV) / math.sqrt(cin * 9)
+    ws = K.split_bf16x2(wt)
+    ho = h * 2 if kind == "up" else h
+    kw = {}
+    if kind == "in":
+        st, _ = K.instnorm_stats(x)
+        kw = dict(in_stats=st, act=2, slope=(torch.rand(cout, generator=g) * 0.5).to(DEV))
+    elif kind in ("style", "up"):
+        kw = dict(in_scale=(torch.rand(b, cin, generator=g) + 0.5).to(DEV), out_scale=(torch.rand(b, cout, generator=g) + 0.5).to(DEV),
+                  noise=torch.randn(b, 1, ho, ho * w // h, generator=g).to(DEV), noise_w=torch.tensor([0.3], device=DEV),
+                  bias=(torch.randn(cout, generator=g) * 0.1).to(DEV), act=1)
+    if kind == "up":
+        kw.update(ncls=4, ostride=2)
+    y = K.conv_mfma(x, wt, cout, w_split=ws, **kw)
+    y2 = K.conv_mfma(x, wt, cout, w_split=ws, **kw)
+    assert torch.equal(y, y2)
+    if kind == "in":
+        ref = K.conv_mfma(K.instnorm_apply(x, kw["in_stats"]), wt, cout, act=2, slope=kw["slope"])
+    else:
+        ref = K.conv_mfma(x, wt, cout, **kw)                             # exact fp32 kernel, same epilogue
+    assert 0 < maxabs(y, ref) < 1e-4 * float(ref.abs().max())
+
+
 def test_bf16x3_rejects_shapes_it_does_not_cover():
     from e4s_amd import kernels as K
     x = torch.zeros(1, 16, 16, 64, device=DEV)

@@ -126,10 +126,11 @@ def test_auto_precision_policy(monkeypatch):
     from e4s_amd import kernels as K
     monkeypatch.setattr(K, "PRECISION", "auto")
     assert K.want_bf16x3(16, 32, 32, 512, 512)            # bench batch: 2 x 8 images -> 256 tiles
-    assert not K.want_bf16x3(2, 32, 32, 512, 512)         # batch-1 latency run: 32 tiles -> exact fp32 kernel
+    assert K.want_bf16x3(2, 32, 32, 512, 512)             # batch-1 latency run: 32 tiles x 8 K-splits
+    assert not K.want_bf16x3(2, 32, 32, 512, 512, masked=True)   # region-select kernel: no split-K, 32 tiles -> exact fp32
     assert K.want_bf16x3(8, 512, 512, 64, 64)             # Cout 64 / 32: 128-pixel tiles, 64- / 32-wide column tiles
     assert K.want_bf16x3(8, 512, 512, 64, 32, ncls=4)
-    assert not K.want_bf16x3(1, 64, 64, 64, 64)           # ... only where >= 512 of them exist
+    assert not K.want_bf16x3(1, 64, 64, 64, 64)           # 16 tiles, 2 chunks: nothing to split -> exact fp32
     assert not K.want_bf16x3(8, 64, 64, 64, 64, masked=True)   # region-select kernel: 128-wide column tiles only
     assert K.want_bf16x3(8, 32, 32, 512, 512, ncls=4)     # polyphase up-conv: 4 phases count as tiles
     monkeypatch.setattr(K, "PRECISION", "f32")
