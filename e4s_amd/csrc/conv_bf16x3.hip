@@ -81,6 +81,27 @@ __device__ __forceinline__ f32x8 load8(const float* src) {
     return f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
 }
 
+__global__ void splitk_epilogue_kernel(const e4s_conv_params p, const int ksplit, const int ycs, const int64_t hw,
+                                       const int64_t n4);
+
+// split-K policy shared by the plain and the region-select kernels: only when the tiles alone leave most CUs idle; every
+// split keeps >= 2 input-channel chunks
+inline void few_tiles_split(int64_t tiles, int nchunk, int& ksplit, int& cper) {
+    ksplit = 1;
+    cper = nchunk;
+    if (tiles >= 128 || nchunk < 4) return;
+    int want = (int)((256 + tiles - 1) / tiles);
+    if (want > nchunk / 2) want = nchunk / 2;
+    if (want < 2) return;
+    cper = (nchunk + want - 1) / want;
+    ksplit = (nchunk + cper - 1) / cper;
+}
+
+inline void region_split(const e4s_conv_params& p, int& ksplit, int& cper) {
+    const int64_t tiles = (int64_t)p.B * ((p.Ha + 15) / 16) * ((p.Wa + 15) / 16) * p.ncls * (p.Cout / 128);
+    few_tiles_split(tiles, p.Cin / 32, ksplit, cper);
+}
+
 struct TileId {          // one 16x16-pixel x BN-column output tile (x one K split: input-channel chunks [c_lo, c_hi))
     int tb, tyb, txb, n0, ks, c_lo, c_hi;
 };
@@ -459,7 +480,8 @@ static_assert(XPIECE * 9 >= XITEMS && XPIECE <= NTHR, "extended halo split");
 
 __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv_params p, const int ntn,
                                                                   const int tx_n, const int per_img,
-                                                                  const int tiles_per_cls) {
+                                                                  const int tiles_per_cls, const int ksplit,
+                                                                  const int cper) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                          // [2][HALO][ROWB]  fp32 x, 32 channels per row
     unsigned char* sB = smem + 2 * A_BYTES;            // [2][BN][ROWB]    split weights
@@ -472,7 +494,11 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
     const int li = lane & 31, kh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    // ksplit > 1 (few tiles: batch-1 latency runs): the input-channel chunks are split over ksplit blocks per tile; each
+    // stores d[region] * (its partial sum) and a second kernel adds the slabs in order and applies noise / bias / activation
+    const int logical0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = logical0 % ksplit;
+    const int logical = logical0 / ksplit;
     const int mt = logical / ntn, nt = logical - mt * ntn;
     const int n0 = nt * BN;
     const int cls = mt / tiles_per_cls;
@@ -502,7 +528,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
         s_grp[tid] = r;
     }
 
-    const int nchunk = p.Cin / KC, nstage = nchunk * 9;
+    const int c_lo = ks * cper, nchunk = min(p.Cin / KC - c_lo, cper), nstage = nchunk * 9;      // this block's chunks
     const float* xb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin;
     const float* stab = p.in_scale + (size_t)tb * R * p.Cin;
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(p.w) + (size_t)cls * 9 * p.Cout * p.Cin * 4;
@@ -543,16 +569,16 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
         *reinterpret_cast<f32x4*>(dst + 16) = f32x4{v[4], v[5], v[6], v[7]};
     };
 
-    // ---- prologue: halo + style slice of chunk 0, weights of stage 0 ----
+    // ---- prologue: halo + style slice of the first chunk, weights of stage 0 ----
     for (int item = tid; item < XPIECE * 9; item += NTHR) {
         const Item it = item_of(item);
-        f32x8 v = load8(it.src);
+        f32x8 v = load8(it.src + c_lo * KC);
         if (!it.ok) v = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (item < XITEMS) store8(smem + it.dst, v);
     }
     const int bq = (tid & 7) * 16, br0 = tid >> 3;
     {
-        const unsigned char* wp = wbytes + (size_t)n0 * wrow + bq;
+        const unsigned char* wp = wbytes + (size_t)n0 * wrow + (size_t)c_lo * 128 + bq;
         f32x4 pb[BJ];
 #pragma unroll
         for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
@@ -581,7 +607,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
 
     f32x8 sv[TM][2];                 // style fragments of the current chunk: s[region(row)][kk*16 + kh*8 .. +7]
     const bool piece_thr = tid < XPIECE;
-    int tap = 0, chunk = 0, t1 = 1, c1 = 0;
+    int tap = 0, chunk = 0, t1 = 1, c1 = c_lo;       // chunk: relative to c_lo (LDS buffer parity); c1: absolute
 
     for (int s = 0; s < nstage; ++s) {
         const unsigned char* Ab = sA + (chunk & 1) * A_BYTES + ((tap / 3) * HALO_W + (tap % 3)) * ROWB;
@@ -627,7 +653,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
                 wbytes + ((size_t)(more ? t1 : 0) * p.Cout + n0) * wrow + (size_t)(more ? c1 : 0) * 128 + bq;
 #pragma unroll
             for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
-            pa = load8(it.src + (have_next ? (chunk + 1) * KC : 0));
+            pa = load8(it.src + (have_next ? (c_lo + chunk + 1) * KC : 0));
         };
 
         // -- 4 groups of 6 MFMAs; the next group's fp32 fragment is requested before the current one is converted --
@@ -694,7 +720,8 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) bsv[tn] = p.bias ? p.bias[n0 + (wn * TN + tn) * 32 + li] : 0.f;
     const float gain = (p.act == 1) ? p.gain : 1.f;
-    const bool do_act = p.act != 0, scaled = p.out_scale != nullptr;
+    const bool do_act = p.act != 0, scaled = p.out_scale != nullptr, raw = ksplit > 1;
+    float* yo = raw ? p.splitk_ws + (size_t)ks * ((size_t)p.B * p.Ho * p.Wo * p.Cout) : p.y;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -707,9 +734,12 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int ncol = (wn * TN + tn) * 32 + li;
-                float v = acc[tm][tn][r] * (scaled ? drow[ncol] : 1.f) + nz + bsv[tn];
-                if (do_act) v = (v > 0.f ? v : v * p.alpha) * gain;
-                p.y[(size_t)off * p.Cout + n0 + ncol] = v;
+                float v = acc[tm][tn][r] * (scaled ? drow[ncol] : 1.f);
+                if (!raw) {
+                    v += nz + bsv[tn];
+                    if (do_act) v = (v > 0.f ? v : v * p.alpha) * gain;
+                }
+                yo[(size_t)off * p.Cout + n0 + ncol] = v;
             }
         }
     }
@@ -722,10 +752,22 @@ int launch_region(const e4s_conv_params& p, hipStream_t st) {
     const int ntn = p.Cout / BN;
     const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + TH - 1) / TH) * tx_n;
     const int tiles_per_cls = p.B * per_img;
-    const int64_t blocks = (int64_t)tiles_per_cls * p.ncls * ntn;
+    int ksplit, cper;
+    region_split(p, ksplit, cper);
+    if (ksplit > 1 && !p.splitk_ws) return (int)hipErrorInvalidValue;
+    const int64_t blocks = (int64_t)tiles_per_cls * p.ncls * ntn * ksplit;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM_REGION, st, p, ntn, tx_n, per_img, tiles_per_cls);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM_REGION, st, p, ntn, tx_n, per_img, tiles_per_cls,
+                       ksplit, cper);
     E4S_CHECK_LAUNCH();
+    if (ksplit > 1) {           // slabs already carry d[region]: the second stage adds them and applies noise / bias / act
+        e4s_conv_params q = p;
+        q.out_scale = nullptr;
+        const int64_t n4 = (int64_t)p.B * p.Ho * p.Wo * (p.Cout / 4);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, q, ksplit, p.Cout,
+                           (int64_t)p.Ho * p.Wo, n4);
+        E4S_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -964,18 +1006,9 @@ __global__ void splitk_epilogue_kernel(const e4s_conv_params p, const int ksplit
     *reinterpret_cast<f32x4*>(p.y + (size_t)pix * ycs + c) = v;
 }
 
-// split-K policy of the plain kernel: only when the tiles alone leave most CUs idle; every split keeps >= 2 chunks
 void plain_split(const e4s_conv_params& p, int ntn, int& ksplit, int& cper) {
-    const int nchunk = p.Cin / KC;
     const int64_t tiles = (int64_t)p.B * ((p.Ha + PTH - 1) / PTH) * ((p.Wa + TW - 1) / TW) * ntn;
-    ksplit = 1;
-    cper = nchunk;
-    if (tiles >= 128 || nchunk < 4) return;
-    int want = (int)((256 + tiles - 1) / tiles);
-    if (want > nchunk / 2) want = nchunk / 2;
-    if (want < 2) return;
-    cper = (nchunk + want - 1) / want;
-    ksplit = (nchunk + cper - 1) / cper;
+    few_tiles_split(tiles, p.Cin / KC, ksplit, cper);
 }
 
 int num_cus() {
@@ -1062,7 +1095,12 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
 
 extern "C" int64_t e4s_conv_bf16x3_ws_floats(const e4s_conv_params* pp) {
     const e4s_conv_params& p = *pp;
-    if (p.labels || p.istride != 1 || p.ntaps != 9 || p.Cin % KC) return 0;      // region / gather kernels: no split-K
+    if (p.istride != 1 || p.ntaps != 9 || p.Cin % KC) return 0;                  // gather kernels: no split-K
+    if (p.labels) {
+        int ksplit, cper;
+        region_split(p, ksplit, cper);
+        return ksplit > 1 ? (int64_t)ksplit * p.B * p.Ho * p.Wo * p.Cout : 0;
+    }
     const bool up = (p.ncls == 4);
     const int ngemm = up ? 4 * p.Cout : p.Cout;
     const int bn = (up || p.Cout % 128 == 0) ? 128 : (p.Cout % 64 == 0 ? 64 : 32);

@@ -312,9 +312,7 @@ def want_bf16x3(b, h, w, cin, cout, ncls=1, masked=False):
     tiles = b * ((h + 15) // 16) * ((w + 15) // 16) * (n // bn) * (ncls if masked else 1)
     if tiles >= BF16X3_MIN_BLOCKS:
         return True
-    if masked:
-        return False
-    # few tiles (batch-1 latency runs): the plain kernel splits the input channels over blocks (csrc: plain_split)
+    # few tiles (batch-1 latency runs): the kernels split the input channels over blocks (csrc: few_tiles_split)
     nchunk = cin // 32
     split = min(nchunk // 2, -(-256 // tiles)) if nchunk >= 4 else 1
     return tiles * max(split, 1) >= 64

@@ -240,6 +240,30 @@ def test_conv_bf16x3_split_k_vs_unsplit_path(b, h, w, cin, cout, kind):
     assert 0 < maxabs(y, ref) < 1e-4 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("res,cin,cout,up", [(32, 512, 512, False), (16, 512, 256, True), (64, 256, 128, False)])
+def test_region_kernel_split_k_vs_fp32(res, cin, cout, up):
+    """Masked StyledConv contractions at batch 1 (few tiles): the region-select split-bf16 kernel with the input channels
+    split over blocks (slabs carry d[region]; the second stage adds them in order + noise / bias / lrelu) vs the exact fp32
+    region-select kernel, and bit-reproducible."""
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(39)
+    b, R = 1, 12
+    ncls = 4 if up else 1
+    x = torch.randn(b, res, res, cin, generator=g).to(DEV)
+    wt = torch.randn(ncls, 9, cout, cin, generator=g).to(DEV) / math.sqrt(cin * 9)
+    labels = synth.synth_labels_blocks(b, 512, 32, seed=5).to(torch.uint8).view(b, 512, 512).to(DEV)
+    ro = res * 2 if up else res
+    kw = dict(labels=labels, num_regions=R, ncls=ncls, ostride=2 if up else 1, in_scale=(torch.rand(b * R, cin, generator=g) + 0.5).to(DEV),
+              out_scale=(torch.rand(b * R, cout, generator=g) + 0.5).to(DEV), noise=torch.randn(b, 1, ro, ro, generator=g).to(DEV),
+              noise_w=torch.tensor([0.2], device=DEV), bias=(torch.randn(cout, generator=g) * 0.1).to(DEV), act=1)
+    assert K.want_bf16x3(b, res, res, cin, cout, ncls, masked=True)
+    ws = K.split_bf16x2(wt)
+    y = K.conv_mfma(x, wt, cout, w_split=ws, **kw)
+    assert torch.equal(y, K.conv_mfma(x, wt, cout, w_split=ws, **kw))
+    ref = K.conv_mfma(x, wt, cout, **kw)
+    assert 0 < maxabs(y, ref) < 1e-4 * float(ref.abs().max())
+
+
 def test_bf16x3_rejects_shapes_it_does_not_cover():
     from e4s_amd import kernels as K
     x = torch.zeros(1, 16, 16, 64, device=DEV)

@@ -127,7 +127,8 @@ def test_auto_precision_policy(monkeypatch):
     monkeypatch.setattr(K, "PRECISION", "auto")
     assert K.want_bf16x3(16, 32, 32, 512, 512)            # bench batch: 2 x 8 images -> 256 tiles
     assert K.want_bf16x3(2, 32, 32, 512, 512)             # batch-1 latency run: 32 tiles x 8 K-splits
-    assert not K.want_bf16x3(2, 32, 32, 512, 512, masked=True)   # region-select kernel: no split-K, 32 tiles -> exact fp32
+    assert K.want_bf16x3(1, 32, 32, 512, 512, masked=True)       # region-select kernel: 16 tiles x 8 K-splits
+    assert not K.want_bf16x3(1, 4, 4, 512, 512, masked=True)     # 4 tiles x 8 splits: too few blocks -> exact fp32
     assert K.want_bf16x3(8, 512, 512, 64, 64)             # Cout 64 / 32: 128-pixel tiles, 64- / 32-wide column tiles
     assert K.want_bf16x3(8, 512, 512, 64, 32, ncls=4)
     assert not K.want_bf16x3(1, 64, 64, 64, 64)           # 16 tiles, 2 chunks: nothing to split -> exact fp32
