@@ -241,11 +241,12 @@ def test_conv_bf16x3_split_k_vs_unsplit_path(b, h, w, cin, cout, kind):
 
 
 @pytest.mark.parametrize("res,cin,cout,up", [(32, 512, 512, False), (16, 512, 256, True), (64, 256, 128, False)])
-def test_region_kernel_split_k_vs_fp32(res, cin, cout, up):
+def test_region_kernel_split_k_vs_fp32(res, cin, cout, up, monkeypatch):
     """Masked StyledConv contractions at batch 1 (few tiles): the region-select split-bf16 kernel with the input channels
     split over blocks (slabs carry d[region]; the second stage adds them in order + noise / bias / lrelu) vs the exact fp32
     region-select kernel, and bit-reproducible."""
     from e4s_amd import kernels as K
+    monkeypatch.setattr(K, "PRECISION", "auto")
     g = torch.Generator().manual_seed(39)
     b, R = 1, 12
     ncls = 4 if up else 1
