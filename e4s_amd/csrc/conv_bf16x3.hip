@@ -63,8 +63,9 @@ using CfgM = PCfg<64, 4, 2, 3>;
 using CfgS = PCfg<32, 8, 1, 3>;
 
 template <typename C, bool SHUF>
-constexpr int plain_smem() {      // A x2, B x2, 3 x per-tile metadata {out offset int, noise float x (4 if SHUF)}
-    return 2 * PA_BYTES + 2 * C::B_BYTES + 3 * PBM * 4 * (1 + (SHUF ? 4 : 1));
+constexpr int plain_smem() {      // A x2, B x2, 3 x per-tile metadata {out offset int, noise float x (4 if SHUF)},
+    return 2 * PA_BYTES + 2 * C::B_BYTES + 3 * PBM * 4 * (1 + (SHUF ? 4 : 1))        // + fused-statistics scratch
+           + (SHUF ? 0 : C::WM * C::BN * 2 * 8);
 }
 
 __device__ __forceinline__ void split_store(unsigned char* dst, const f32x8 v) {
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
     unsigned char* sB = smem + 2 * A_BYTES;            // [2][TPS*BN][ROWB]
     int* s_out = reinterpret_cast<int*>(sB + 2 * B_BYTES);            // [3][BM]
     float* s_nz = reinterpret_cast<float*>(s_out + 3 * BM);           // [3][BM][NZ]
+    double* s_st = reinterpret_cast<double*>(s_nz + 3 * BM * NZ);     // [WM][BN][2] (fused output statistics; !SHUF)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -426,6 +428,10 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
             const float gain = (p.act == 1) ? p.gain : 1.f;
             const bool do_act = p.act != 0;
             const bool raw = ksplit > 1;
+            const bool stats = !SHUF && !raw && p.stats_ws != nullptr;
+            double st_s[TN], st_q[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) st_s[tn] = st_q[tn] = 0.0;
             float* yo = raw ? p.splitk_ws + (size_t)cur.ks * ((size_t)p.B * p.Ho * p.Wo * ycs) : p.y;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -442,8 +448,33 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                             if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
                         }
                         yo[(size_t)off * ycs + coff[tn]] = v;
+                        if (stats) { st_s[tn] += (double)v; st_q[tn] += (double)v * (double)v; }
                     }
                 }
+            }
+            if (!SHUF && stats) {
+                // per-channel {sum, sum of squares} of the tile: lanes li / li+32 hold the two row halves of a column
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    st_s[tn] += __shfl_xor(st_s[tn], 32, 64);
+                    st_q[tn] += __shfl_xor(st_q[tn], 32, 64);
+                    if (kh == 0) {
+                        const int col = (wn * TN + tn) * 32 + li;
+                        s_st[(wm * BN + col) * 2] = st_s[tn];
+                        s_st[(wm * BN + col) * 2 + 1] = st_q[tn];
+                    }
+                }
+                __syncthreads();
+                if (tid < BN) {
+                    double a = 0.0, q = 0.0;
+#pragma unroll
+                    for (int j = 0; j < C::WM; ++j) { a += s_st[(j * BN + tid) * 2]; q += s_st[(j * BN + tid) * 2 + 1]; }
+                    const int tile_in_img = cur.tyb * tx_n + cur.txb;
+                    double* slot = p.stats_ws + (((size_t)cur.tb * p.Cout + cur.n0 + tid) * p.stats_slots + tile_in_img) * 2;
+                    slot[0] = a;
+                    slot[1] = q;
+                }
+                __syncthreads();
             }
         }
         if (!has_next) break;
@@ -931,6 +962,10 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
     }
     const float gain = (p.act == 1) ? p.gain : 1.f;
     const bool do_act = p.act != 0;
+    const bool stats = p.stats_ws != nullptr;         // the launcher guarantees tiles that do not straddle samples
+    double st_s[TN], st_q[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) st_s[tn] = st_q[tn] = 0.0;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -943,7 +978,32 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
                 float v = acc[tm][tn][r] + bsv[tn];
                 if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
                 p.y[(size_t)off * (p.y_cstride ? p.y_cstride : p.Cout) + n0 + (wn * TN + tn) * 32 + li] = v;
+                if (stats) { st_s[tn] += (double)v; st_q[tn] += (double)v * (double)v; }
             }
+        }
+    }
+    if (stats) {
+        double* s_st = reinterpret_cast<double*>(sA);        // the stage loop's last barrier has passed: A is free
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            st_s[tn] += __shfl_xor(st_s[tn], 32, 64);
+            st_q[tn] += __shfl_xor(st_q[tn], 32, 64);
+            if (kh == 0) {
+                const int col = (wn * TN + tn) * 32 + li;
+                s_st[(wm * BN + col) * 2] = st_s[tn];
+                s_st[(wm * BN + col) * 2 + 1] = st_q[tn];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            double a = 0.0, q = 0.0;
+#pragma unroll
+            for (int j = 0; j < NTHR / 64 / WN; ++j) { a += s_st[(j * BN + tid) * 2]; q += s_st[(j * BN + tid) * 2 + 1]; }
+            const int tiles_per_img = hw / BM;
+            const int b = mt / tiles_per_img, tile_in_img = mt - b * tiles_per_img;
+            double* slot = p.stats_ws + (((size_t)b * p.Cout + n0 + tid) * p.stats_slots + tile_in_img) * 2;
+            slot[0] = a;
+            slot[1] = q;
         }
     }
 }
@@ -1068,13 +1128,17 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
         if (p.Cin % KC || p.Cout % BN || (p.ntaps != 9 && p.ntaps != 1) || p.ncls != 1 || p.ostride != 1 || p.tiles ||
             p.labels || p.in_scale || p.out_scale || p.in_stats || p.noise || p.Ho != p.Ha || p.Wo != p.Wa ||
             p.Hi >= 32767 || p.Wi >= 32767 || (p.Ha - 1) * p.istride >= p.Hi || (p.Wa - 1) * p.istride >= p.Wi ||
-            p.tap_shift < 0 || p.tap_shift > 1)
+            p.tap_shift < 0 || p.tap_shift > 1 ||
+            (p.stats_ws && (p.act != 0 || (p.Ha * p.Wa) % BM || p.stats_slots != (p.Ha * p.Wa) / BM)))
             return (int)hipErrorInvalidValue;
         return launch_gather(p, as_stream(stream));
     }
     if (p.Cin % KC || p.Cout % 32 || p.ntaps != 9 || (p.ncls != 1 && !up) || p.istride != 1 ||
         p.ostride != (up ? 2 : 1) || p.tiles || p.noise_per_channel || p.Ha != p.Hi || p.Wa != p.Wi ||
         p.Ho != p.Hi * p.ostride || p.Wo != p.Wi * p.ostride || (p.in_stats && p.in_scale))
+        return (int)hipErrorInvalidValue;
+    if (p.stats_ws && (p.labels || up || p.act != 0 || p.noise || p.out_scale ||
+                       p.stats_slots != ((p.Ha + PTH - 1) / PTH) * ((p.Wa + TW - 1) / TW)))
         return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
     if (p.labels) {                       // per-pixel regions: the region-select kernel (128-wide column tiles only)

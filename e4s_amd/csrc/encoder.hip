@@ -160,6 +160,57 @@ __global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* 
     *reinterpret_cast<f32x4*>(y + i * 4) = o;
 }
 
+// The same apply, organised like the statistics pass (block = sample x 64-channel slab x pixel range; lanes walk the
+// channels, 4 pixel groups): it ALSO accumulates the fp64 partial sums of its output, i.e. the next unit's InstanceNorm
+// statistics, so that pass never re-reads the tensor.
+__global__ void instnorm_apply_stats_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                            const float* __restrict__ gate, const float* __restrict__ res,
+                                            const float* __restrict__ res_stats, const float* __restrict__ slope,
+                                            float* __restrict__ y, double* __restrict__ ws, int H, int W, int C, int rs,
+                                            int nsplit) {
+    const int slabs = C / 64, HW = H * W;
+    const int split = blockIdx.x % nsplit;
+    const int slab = (blockIdx.x / nsplit) % slabs;
+    const int b = blockIdx.x / (nsplit * slabs);
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int c = slab * 64 + cl;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p0 = split * per, p1 = (p0 + per < HW) ? p0 + per : HW;
+    const int64_t bc = (int64_t)b * C + c;
+    const float mean = stats[bc * 2], rstd = stats[bc * 2 + 1];
+    const float g = gate ? gate[bc] : 1.f;
+    const float rmean = res_stats ? res_stats[bc * 2] : 0.f, rrstd = res_stats ? res_stats[bc * 2 + 1] : 1.f;
+    const float sl = slope ? slope[c] : 0.f;
+    const int Wr = W * rs;
+    double s = 0.0, q = 0.0;
+    for (int p = p0 + pg; p < p1; p += 4) {
+        const int64_t idx = ((int64_t)b * HW + p) * C + c;
+        float o = (x[idx] - mean) * rstd;
+        if (gate) o *= g;
+        if (res) {
+            const int yy = p / W, xx = p - yy * W;
+            float t = res[(((int64_t)b * H * rs + (int64_t)yy * rs) * Wr + (int64_t)xx * rs) * C + c];
+            if (res_stats) t = (t - rmean) * rrstd;
+            o += t;
+        }
+        if (slope) o = o > 0.f ? o : o * sl;
+        y[idx] = o;
+        s += (double)o;
+        q += (double)o * (double)o;
+    }
+    __shared__ double red[2][4][64];
+    red[0][pg][cl] = s;
+    red[1][pg][cl] = q;
+    __syncthreads();
+    if (pg == 0) {
+        s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        q = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        double* slot = ws + (bc * nsplit + split) * 2;
+        slot[0] = s;
+        slot[1] = q;
+    }
+}
+
 // ---- SE gate (helpers.py:56-72): fc1 -> relu -> fc2 -> sigmoid on the pooled vector; one block per sample
 __global__ void se_gate_kernel(const float* __restrict__ pooled_in, const float* __restrict__ fc1,
                                const float* __restrict__ fc2, float* __restrict__ gate, int C, int Cr) {
@@ -330,6 +381,28 @@ extern "C" int e4s_instnorm_stats_f32(const float* x, float* stats, float* poole
     E4S_CHECK_LAUNCH();
     const int n = B * C;
     hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, stats, pooled, n, HW, eps, nsplit);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_instnorm_finalize_f32(const double* ws, float* stats, float* pooled, int B, int HW, int C, int nslots,
+                                         float eps, void* stream) {
+    const int n = B * C;
+    if (n <= 0 || nslots < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), ws, stats, pooled, n,
+                       HW, eps, nslots);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_instnorm_apply_stats_f32(const float* x, const float* stats, const float* gate, const float* res,
+                                            const float* res_stats, const float* slope, float* y, double* ws, int* nslots,
+                                            int B, int H, int W, int C, int rs, void* stream) {
+    if (C % 64 || rs < 1 || !nslots) return (int)hipErrorInvalidValue;
+    const int ns = instnorm_nsplit(B, H * W, C);
+    *nslots = ns;
+    hipLaunchKernelGGL(instnorm_apply_stats_kernel, dim3(B * (C / 64) * ns), dim3(256), 0, as_stream(stream), x, stats, gate,
+                       res, res_stats, slope, y, ws, H, W, C, rs, ns);
     E4S_CHECK_LAUNCH();
     return 0;
 }

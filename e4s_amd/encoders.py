@@ -37,7 +37,7 @@ def _pack3x3(conv):
     return conv._e4s_pack[1]
 
 
-def _conv3x3(x, conv, cout, in_stats=None, **kw):
+def _conv3x3(x, conv, cout, in_stats=None, want_stats=False, **kw):
     """Stride-1 3x3 conv (+ fused epilogue) in the configured arithmetic: the split-bf16 kernel where it applies and
     K.PRECISION asks for it, the exact fp32-MFMA kernel otherwise.  in_stats: InstanceNorm statistics of x -- the
     normalisation (helpers.py:128-131) is folded into the split-bf16 kernel's halo staging, or runs as its own pass
@@ -46,13 +46,13 @@ def _conv3x3(x, conv, cout, in_stats=None, **kw):
     if K.want_bf16x3(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout):
         if getattr(conv, "_e4s_split", None) is None or conv._e4s_split[0] != conv._e4s_pack[0]:
             conv._e4s_split = (conv._e4s_pack[0], K.split_bf16x2(w))
-        return K.conv_mfma(x, w, cout, w_split=conv._e4s_split[1], in_stats=in_stats, **kw)
+        return K.conv_mfma(x, w, cout, w_split=conv._e4s_split[1], in_stats=in_stats, want_stats=want_stats, **kw)
     if in_stats is not None:
         x = K.instnorm_apply(x, in_stats)
-    return K.conv_mfma(x, w, cout, **kw)
+    return K.conv_mfma(x, w, cout, want_stats=want_stats, **kw)
 
 
-def _conv_strided(x, conv, cout, stride, ntaps):
+def _conv_strided(x, conv, cout, stride, ntaps, want_stats=False):
     """The unit's stride-2 3x3 conv / 1x1 shortcut conv (helpers.py:125-137): per-tap gather kernels -- split-bf16 where
     K.PRECISION asks for it and the launch has enough 256-pixel tiles, exact fp32 otherwise."""
     w = _pack3x3(conv)
@@ -61,8 +61,8 @@ def _conv_strided(x, conv, cout, stride, ntaps):
     if K.PRECISION != "f32" and cout % 128 == 0 and (K.PRECISION == "bf16x3" or tiles >= K.BF16X3_MIN_BLOCKS):
         if getattr(conv, "_e4s_split", None) is None or conv._e4s_split[0] != conv._e4s_pack[0]:
             conv._e4s_split = (conv._e4s_pack[0], K.split_bf16x2(w))
-        return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps, w_split=conv._e4s_split[1])
-    return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps)
+        return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps, w_split=conv._e4s_split[1], want_stats=want_stats)
+    return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps, want_stats=want_stats)
 
 
 class SEModule(Module):
@@ -95,23 +95,24 @@ class bottleneck_IR_SE_Ours(Module):
                                     InstanceNorm2d(depth),
                                     SEModule(depth, 16))
 
-    def run_nhwc(self, x):
-        """x NHWC [B,H,W,Cin] -> NHWC [B,H/stride,W/stride,depth]."""
+    def run_nhwc(self, x, st_x=None, want_stats=False):
+        """x NHWC [B,H,W,Cin] -> NHWC [B,H/stride,W/stride,depth].  Every InstanceNorm statistic is produced by the kernel
+        that writes the tensor it describes: st_x (of the input) by the previous unit's final pass (want_stats -> returns
+        (out, st_out) for the next unit), those of the two conv outputs by the convs' epilogues."""
         conv1, prelu, conv2, se = self.res_layer[1], self.res_layer[2], self.res_layer[3], self.res_layer[5]
-        st_x, _ = K.instnorm_stats(x)
+        if st_x is None:
+            st_x, _ = K.instnorm_stats(x)
         r = _conv3x3(x, conv1, self.depth, in_stats=st_x, act=2, slope=prelu.weight)
         if self.stride == 1:
-            r = _conv3x3(r, conv2, self.depth)
+            r, (st_r, pooled) = _conv3x3(r, conv2, self.depth, want_stats=True)
         else:
-            r = _conv_strided(r, conv2, self.depth, self.stride, 9)
-        st_r, pooled = K.instnorm_stats(r, want_pooled=True)
+            r, (st_r, pooled) = _conv_strided(r, conv2, self.depth, self.stride, 9, want_stats=True)
         gate = K.se_gate(pooled, se.fc1.weight.view(se.fc1.weight.shape[0], -1),
                          se.fc2.weight.view(se.fc2.weight.shape[0], -1))
         if self.in_channel == self.depth:
-            return K.instnorm_apply(r, st_r, gate=gate, res=x, rs=self.stride)      # MaxPool2d(1, stride)
-        sc = _conv_strided(x, self.shortcut_layer[0], self.depth, self.stride, 1)
-        st_sc, _ = K.instnorm_stats(sc)
-        return K.instnorm_apply(r, st_r, gate=gate, res=sc, res_stats=st_sc)
+            return K.instnorm_apply(r, st_r, gate=gate, res=x, rs=self.stride, want_stats=want_stats)   # MaxPool2d(1, s)
+        sc, (st_sc, _) = _conv_strided(x, self.shortcut_layer[0], self.depth, self.stride, 1, want_stats=True)
+        return K.instnorm_apply(r, st_r, gate=gate, res=sc, res_stats=st_sc, want_stats=want_stats)
 
     def forward(self, x):
         return K.nhwc_to_nchw(self.run_nhwc(K.nchw_to_nhwc(x)))
@@ -145,12 +146,16 @@ class FSEncoder_PSP(Module):
         """x256: NHWC [B,256,256,3]; labels uint8 [B,Hm,Wm].  Returns codes [B,R,1280]."""
         x = K.conv3x3_small(x256, self.input_layer[0].weight)
         st, _ = K.instnorm_stats(x)
-        x = K.instnorm_apply(x, st, slope=self.input_layer[2].weight)
+        x, st_x = K.instnorm_apply(x, st, slope=self.input_layer[2].weight, want_stats=True)
         b = x.shape[0]
         codes = torch.empty(b, num_regions, 256 + 512 + 512, device=x.device, dtype=torch.float32)
         off = {6: 0, 20: 256, 23: 768}
+        last = len(self.body) - 1
         for i, unit in enumerate(self.body):
-            x = unit.run_nhwc(x)
+            if i < last:
+                x, st_x = unit.run_nhwc(x, st_x, want_stats=True)
+            else:
+                x = unit.run_nhwc(x, st_x)
             if i in off:
                 K.region_mean_into(x, labels, codes, num_regions, off[i])
         return codes, x

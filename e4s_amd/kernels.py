@@ -213,7 +213,7 @@ def region_plan(labels, num_regions, ha, wa, nphase):
 def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, in_scale=None, out_scale=None,
               noise=None, noise_w=None, noise_per_channel=False, bias=None, slope=None, act=0, alpha=0.2,
               gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1, w_split=None, in_stats=None,
-              out=None, tap_shift=0):
+              out=None, tap_shift=0, want_stats=False):
     """x NHWC [B,Hi,Wi,Cin]; w [ncls, ntaps, Cout, Cin] -> y NHWC [B,Ho,Wo,Cout].
     anchors = (Ha, Wa); defaults: up-conv (ncls=4) anchors = input grid, output 2x;
     strided conv anchors = output grid.
@@ -222,7 +222,9 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     in_stats: [B,Cin,2] InstanceNorm statistics of x; the normalisation is applied while the input is staged (split-bf16
     kernel only).
     out: write the Cout channels into the FIRST channels of this wider NHWC tensor [B,Ho,Wo,Cy >= Cout] (returned).
-    tap_shift: gather kernels only: 1 = padding-0 strided conv (input coord = anchor*istride + tap)."""
+    tap_shift: gather kernels only: 1 = padding-0 strided conv (input coord = anchor*istride + tap).
+    want_stats: also return the InstanceNorm statistics of the OUTPUT, (y, (stats [B,Cout,2], pooled [B,Cout])): emitted by
+    the split-bf16 kernels' epilogue (no extra pass over y) where that applies, by e4s_instnorm_stats_f32 otherwise."""
     b, hi, wi, cin = x.shape
     if anchors is None:
         anchors = (hi // istride, wi // istride)
@@ -285,11 +287,29 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
         nws = lib.load().e4s_conv_bf16x3_ws_floats(ctypes.byref(p))        # split-K partial sums (few-tile launches)
         skws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
         p.splitk_ws = fptr(skws)
+        fused = None
+        if want_stats and nws == 0 and act == 0 and noise is None and out_scale is None and labels is None and ncls == 1 \
+                and cout % 64 == 0 and out is None:
+            if gather_ok:
+                slots = (ha * wa) // 256 if (ha * wa) % 256 == 0 else 0
+            else:
+                slots = ((ha + 15) // 16) * ((wa + 15) // 16)
+            if slots:
+                fused = torch.empty(b * cout * slots * 2, device=x.device, dtype=torch.float64)
+                p.stats_ws, p.stats_slots = ptr(fused), slots
         call("e4s_conv_bf16x3_f32", ctypes.byref(p), stream())
+        if fused is not None:
+            stats = torch.empty(b, cout, 2, device=x.device, dtype=torch.float32)
+            pooled = torch.empty(b, cout, device=x.device, dtype=torch.float32)
+            call("e4s_instnorm_finalize_f32", ptr(fused), fptr(stats), fptr(pooled), b, ho * wo, cout, p.stats_slots, 1e-5,
+                 stream())
+            return y, (stats, pooled)
     elif in_stats is not None:
         raise RuntimeError("fused InstanceNorm staging exists only in e4s_conv_bf16x3_f32")
     else:
         call("e4s_conv_mfma_f32", ctypes.byref(p), 1 if spatial else 0, stream())
+    if want_stats:
+        return y, instnorm_stats(y, want_pooled=True)
     return y
 
 
@@ -425,11 +445,23 @@ def instnorm_stats(x, want_pooled=False, eps=1e-5):
     return stats, pooled
 
 
-def instnorm_apply(x, stats, gate=None, res=None, res_stats=None, slope=None, rs=1):
+def instnorm_apply(x, stats, gate=None, res=None, res_stats=None, slope=None, rs=1, want_stats=False):
+    """want_stats: also return the InstanceNorm statistics of the OUTPUT ((y, stats [B,C,2])), accumulated by the same
+    pass (the next encoder unit normalises this tensor first thing, helpers.py:128)."""
     b, h, w, c = x.shape
     y = torch.empty_like(x)
+    if want_stats and c % 64 == 0:
+        ws = torch.empty(lib.load().e4s_instnorm_ws_doubles(b, h * w, c), device=x.device, dtype=torch.float64)
+        nslots = ctypes.c_int(0)
+        call("e4s_instnorm_apply_stats_f32", fptr(x), fptr(stats), fptr(gate), fptr(res), fptr(res_stats), fptr(slope),
+             fptr(y), ptr(ws), ctypes.byref(nslots), b, h, w, c, rs, stream())
+        out_stats = torch.empty(b, c, 2, device=x.device, dtype=torch.float32)
+        call("e4s_instnorm_finalize_f32", ptr(ws), fptr(out_stats), None, b, h * w, c, nslots.value, 1e-5, stream())
+        return y, out_stats
     call("e4s_instnorm_apply_f32", fptr(x), fptr(stats), fptr(gate), fptr(res), fptr(res_stats), fptr(slope), fptr(y),
          b, h, w, c, rs, stream())
+    if want_stats:
+        return y, instnorm_stats(y)[0]
     return y
 
 

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe4s_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -33,7 +33,7 @@ class ConvParams(ctypes.Structure):
         ("labels", c_p), ("Hm", c_i), ("Wm", c_i),
         ("noise", c_p), ("noise_w", c_p), ("noise_bstride", c_l), ("noise_per_channel", c_i),
         ("bias", c_p), ("slope", c_p), ("act", c_i), ("alpha", c_f), ("gain", c_f),
-        ("in_stats", c_p), ("y_cstride", c_i), ("splitk_ws", c_p), ("tap_shift", c_i),
+        ("in_stats", c_p), ("y_cstride", c_i), ("splitk_ws", c_p), ("stats_ws", c_p), ("stats_slots", c_i), ("tap_shift", c_i),
     ]
 
 
@@ -100,6 +100,8 @@ SIGNATURES = {
     "e4s_resize_bilinear_f32": [c_p, c_p] + [c_i] * 6 + [c_p],
     "e4s_conv3x3_small_f32": [c_p, c_p, c_p] + [c_i] * 5 + [c_p],
     "e4s_instnorm_stats_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "e4s_instnorm_finalize_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "e4s_instnorm_apply_stats_f32": [c_p] * 9 + [c_i] * 5 + [c_p],
     "e4s_instnorm_apply_f32": [c_p] * 7 + [c_i] * 5 + [c_p],
     "e4s_se_gate_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_region_mean_f32": [c_p, c_p, c_i, c_i, c_p] + [c_i] * 7 + [c_p],

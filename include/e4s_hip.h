@@ -133,6 +133,13 @@ typedef struct {
                                 NULL): launches with too few tiles to fill the chip (batch-1 latency runs) split the input
                                 channels over several blocks per tile; the raw partial sums land here and are added in a
                                 fixed order by a second kernel that also applies the epilogue */
+    double* stats_ws;        /* e4s_conv_bf16x3_f32, unlabelled, act == 0, no noise: when set, the epilogue also emits the
+                                InstanceNorm partial sums of the OUTPUT it just computed -- per (sample, channel, 256-pixel
+                                tile): {sum, sum of squares} in fp64 at stats_ws[((b*Cout + c)*stats_slots + tile)*2] -- so the
+                                statistics pass over the conv output (helpers.py:138-139) costs no extra read;
+                                e4s_instnorm_finalize_f32 adds the slots in order.  Ignored (must be re-done by the caller)
+                                when the launch is split over K: check e4s_conv_bf16x3_ws_floats(p) == 0 */
+    int stats_slots;         /* tiles per sample = slots per (b, c) */
     int tap_shift;           /* gather mode (istride 2 / ntaps 1 kernels): input coord = anchor*istride + tap - 1 + tap_shift;
                                 1 = the padding-0 stride-2 conv behind a Blur (ConvLayer, model.py:683-700) */
 } e4s_conv_params;
@@ -353,6 +360,15 @@ int e4s_conv3x3_small_f32(const float* x, const float* w, float* y, int B, int H
  * in a fixed order -- the statistics are bit-reproducible (no floating-point atomics). */
 int e4s_instnorm_stats_f32(const float* x, float* stats, float* pooled, double* ws, int B, int HW, int C,
                            float eps, void* stream);
+/* second stage alone: ws[((b*C + c)*nslots + k)*2 + {0,1}] = k-th partial {sum, sum of squares} (from a conv epilogue's
+ * stats_ws or from e4s_instnorm_apply_stats_f32) -> stats / pooled as above, slots added in order */
+int e4s_instnorm_finalize_f32(const double* ws, float* stats, float* pooled, int B, int HW, int C, int nslots, float eps,
+                              void* stream);
+/* e4s_instnorm_apply_f32 that also emits the partial sums of its OUTPUT (the next unit's InstanceNorm statistics) into
+ * ws (e4s_instnorm_ws_doubles(B, H*W, C) doubles; slots = that call's split count, returned through *nslots) */
+int e4s_instnorm_apply_stats_f32(const float* x, const float* stats, const float* gate, const float* res,
+                                 const float* res_stats, const float* slope, float* y, double* ws, int* nslots,
+                                 int B, int H, int W, int C, int rs, void* stream);
 int64_t e4s_instnorm_ws_doubles(int B, int HW, int C);
 /* y = ((x - mean)*rstd) [* gate[b,c]] [+ res[b, (y*rs)*Wr + x*rs, c]] ; optional PReLU(slope[c]) last.
  * res is NHWC [B, H*rs, W*rs, C] sampled at stride rs (MaxPool2d(1, stride), helpers.py:125-126). */

@@ -947,3 +947,28 @@ def test_generator_weight_grads_vs_oracle_f64(size, K, cells):
         checked += 1
     assert not bad, bad
     assert checked >= 20
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,stride,ntaps", [(2, 32, 32, 128, 128, 1, 9), (3, 16, 48, 64, 256, 1, 9), (2, 32, 32, 128, 128, 2, 9),
+                                                         (2, 64, 32, 64, 128, 2, 1)])
+def test_fused_output_statistics_equal_the_separate_pass(b, h, w, cin, cout, stride, ntaps, monkeypatch):
+    """InstanceNorm statistics emitted by the conv epilogues / by the apply pass == e4s_instnorm_stats_f32 on the tensor
+    they describe (same fp64 sums, different summation order: 1e-6 relative), and the encoder with them == without."""
+    from e4s_amd import kernels as K
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(b, h, w, cin, generator=g) * 1.3 + 0.4).to(DEV)
+    k = 3 if ntaps == 9 else 1
+    wp = _pack(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).to(DEV)
+    ws = K.split_bf16x2(wp)
+    y, (st, pooled) = K.conv_mfma(x, wp, cout, istride=stride, ntaps=ntaps, w_split=ws, want_stats=True)
+    st_ref, pooled_ref = K.instnorm_stats(y, want_pooled=True)
+    assert torch.equal(y, K.conv_mfma(x, wp, cout, istride=stride, ntaps=ntaps, w_split=ws))
+    assert maxabs(st, st_ref) < 2e-6 * float(st_ref.abs().max())
+    assert maxabs(pooled, pooled_ref) < 1e-6
+    gate = torch.rand(b, cout, generator=g).to(DEV)
+    res = torch.randn(y.shape, generator=g).to(DEV)
+    slope = (torch.rand(cout, generator=g) * 0.4).to(DEV)
+    out, st_out = K.instnorm_apply(y, st_ref, gate=gate, res=res, slope=slope, want_stats=True)
+    assert torch.equal(out, K.instnorm_apply(y, st_ref, gate=gate, res=res, slope=slope))
+    assert maxabs(st_out, K.instnorm_stats(out)[0]) < 2e-6 * float(st_out.abs().max())
