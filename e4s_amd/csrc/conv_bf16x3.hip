@@ -117,7 +117,10 @@ struct TileId {          // one 16x16-pixel x BN-column output tile (x one K spl
 //     the same two fp32 operations e4s_instnorm_apply_f32 performs, so fused == unfused bitwise)
 // SHUF: polyphase up-conv (model.py:287-300 folded into 4 phase kernels) as ONE GEMM with N = 4 Cout columns
 //   (column n = phase * Cout + co) over the input grid, pixel-shuffled by the epilogue: output pixel (2ay+py, 2ax+px).
-template <typename C, int XF, bool SHUF>
+// VAR: profiling variants (builds with -DE4S_ABLATIONS select them with env E4S_BF16X3_ABL; results are WRONG for VAR >= 3;
+// product builds only instantiate VAR = 0): 1 s_setprio(1) around the MFMA groups, 2 no scheduling pins, 3 MFMAs + barriers
+// only (no fragment reads, no staging), 4 MFMAs only, 5 everything but the MFMAs
+template <typename C, int XF, bool SHUF, int VAR = 0>
 __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_params p, const int ntn, const int tx_n,
                                                             const int per_img, const int ntiles, const int ksplit,
                                                             const int cper) {
@@ -283,7 +286,6 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
     const bool piece_thr = tid < PIECE;
     unsigned sg = 0, cg = 0;         // running stage / chunk counters: LDS buffer parities continue across tiles
     int mbuf = 0;                    // metadata buffer of the current tile (3-deep ring)
-
     for (;;) {
         // metadata of the NEXT tile -> ring slot mbuf+1 (its previous reader, the epilogue two tiles back, is behind
         // at least one full tile of barriers; the epilogue one tile back reads slot mbuf-1)
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                 AFrag A0, A1;
                 ldB(B0, 0);
                 ldA(A0, 0);
+                if (VAR == 3 || VAR == 4) { B1 = B0; A1 = A0; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < NGRP; ++g) {
@@ -373,11 +376,16 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                     AFrag& An = (g & 1) ? A0 : A1;
                     BFrag& Bc = (u & 1) ? B1 : B0;
                     BFrag& Bn = (u & 1) ? B0 : B1;
-                    if (g + 1 < NGRP) ldA(An, g + 1);
-                    if (tm == 0 && u + 1 < NU) ldB(Bn, u + 1);
-                    if (g == 0) issue_loads();
-                    mfmas(Ac, Bc, tm);
-                    if (g == 0) {
+                    if (VAR != 3 && VAR != 4) {
+                        if (g + 1 < NGRP) ldA(An, g + 1);
+                        if (tm == 0 && u + 1 < NU) ldB(Bn, u + 1);
+                        if (g == 0) issue_loads();
+                    }
+                    if (VAR == 1) __builtin_amdgcn_s_setprio(1);
+                    if (VAR != 5) mfmas(Ac, Bc, tm);
+                    else asm volatile("" :: "v"(Ac.h), "v"(Ac.l), "v"(Bc.h[0]), "v"(Bc.l[0]));
+                    if (VAR == 1) __builtin_amdgcn_s_setprio(0);
+                    if (g == 0 && VAR != 2 && VAR != 3 && VAR != 4) {
                         // the global-load block (~100 address/SALU instructions) is spread between this group's MFMAs:
                         // after a barrier all waves are in the same phase and nothing else would cover it
 #pragma unroll
@@ -386,9 +394,14 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                             __builtin_amdgcn_sched_group_barrier(0x126, 16, 0);     // then up to 16 VALU/SALU/VMEM-read/DS-read
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (VAR != 2) __builtin_amdgcn_sched_barrier(0);
                 }
                 // -- VGPR -> LDS: weights of the next stage, halo piece of the next chunk --
+                if (VAR == 3 || VAR == 4) {
+                    if (VAR == 3) __syncthreads();
+                    ++sg;
+                    continue;
+                }
                 if (more) {
                     unsigned char* db = sB + ((sg + 1) & 1) * B_BYTES;
 #pragma unroll
@@ -1083,9 +1096,9 @@ int num_cus() {
     return cus[dev & 63];
 }
 
-template <typename C, int XF, bool SHUF>
+template <typename C, int XF, bool SHUF, int VAR = 0>
 int launch(const e4s_conv_params& p, hipStream_t st) {
-    auto kern = conv_bf16x3_kernel<C, XF, SHUF>;
+    auto kern = conv_bf16x3_kernel<C, XF, SHUF, VAR>;
     constexpr int SMEM = plain_smem<C, SHUF>();
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static std::atomic<uint64_t> smem_set{0};
@@ -1146,6 +1159,19 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
             return (int)hipErrorInvalidValue;
         return launch_region(p, st);
     }
+#ifdef E4S_ABLATIONS      // profiling builds only (E4S_BUILD_ABLATIONS=1 python -m e4s_amd.build): tools/bench_abl.py
+    static const int abl = [] { const char* e = getenv("E4S_BF16X3_ABL"); return e ? atoi(e) : 0; }();
+    if (abl && !up && p.Cout % 128 == 0 && !p.in_stats && !p.in_scale) {
+        switch (abl) {
+            case 1: return launch<CfgL, 0, false, 1>(p, st);
+            case 2: return launch<CfgL, 0, false, 2>(p, st);
+            case 3: return launch<CfgL, 0, false, 3>(p, st);
+            case 4: return launch<CfgL, 0, false, 4>(p, st);
+            case 5: return launch<CfgL, 0, false, 5>(p, st);
+            default: break;
+        }
+    }
+#endif
     // one style per sample (or none): the persistent plain kernel.  The polyphase up-conv (ncls = 4) is ONE GEMM with
     // N = 4 Cout columns over the input grid + a pixel-shuffling epilogue.
     if (up) {
