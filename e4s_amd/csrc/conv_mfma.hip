@@ -198,7 +198,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
                 }
             }
         } else {
-            const int oy = ((ntaps == 9) ? tap / 3 - 1 : 0) + p.tap_shift, ox = ((ntaps == 9) ? tap % 3 - 1 : 0) + p.tap_shift;
+            const int kw = ntaps == 25 ? 5 : ntaps == 9 ? 3 : 1;      // square k x k taps, 'same' padding k/2
+            const int oy = tap / kw - kw / 2 + p.tap_shift, ox = tap % kw - kw / 2 + p.tap_shift;
             const int doff = oy * p.Wi + ox;
             unsigned okm = 0;
 #pragma unroll
@@ -426,8 +427,9 @@ int pick_bn(const e4s_conv_params& p, int64_t mtiles) {
 extern "C" int e4s_conv_mfma_f32(const e4s_conv_params* pp, int spatial, void* stream) {
     const e4s_conv_params& p = *pp;
     hipStream_t st = as_stream(stream);
-    if (p.Cin % KC || p.Cout % 32 || (p.ntaps != 9 && p.ntaps != 1) || (p.ncls != 1 && p.ncls != 4))
+    if (p.Cin % KC || p.Cout % 32 || (p.ntaps != 9 && p.ntaps != 1 && p.ntaps != 25) || (p.ncls != 1 && p.ncls != 4))
         return (int)hipErrorInvalidValue;
+    if (p.ntaps == 25 && (spatial || p.ncls != 1)) return (int)hipErrorInvalidValue;   // 5x5: per-tap gather mode only
     if (p.Hi >= 32767 || p.Wi >= 32767) return (int)hipErrorInvalidValue;
     if (p.tap_shift && (spatial || p.tap_shift != 1)) return (int)hipErrorInvalidValue;
     if (spatial) {

@@ -212,6 +212,20 @@ extern "C" int e4s_instnorm_bwd_f32(const float* dy, const float* x, const float
     return 0;
 }
 
+// the two ordered sums alone: sums[b,c] = {sum_p dy, sum_p dy * xhat} (frozen-statistics normalisation: the second one is
+// dL/dgate of gate * norm(x), criteria.hip applies the rest)
+extern "C" int e4s_instnorm_bwd_sums_f32(const float* dy, const float* x, const float* stats, float* sums, double* ws, int B,
+                                         int HW, int C, void* stream) {
+    if (C % 64) return (int)hipErrorInvalidValue;
+    hipStream_t st = as_stream(stream);
+    const int ns = in_nsplit(B, HW, C);
+    hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(B * (C / 64) * ns), dim3(256), 0, st, dy, x, stats, ws, HW, C, ns);
+    E4S_CHECK_LAUNCH();
+    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, ws, sums, B * C, ns);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int e4s_prelu_f32(const float* u, const float* slope, float* y, int64_t npix, int C, void* stream) {
     if (C % 4) return (int)hipErrorInvalidValue;
     const int64_t n4 = npix * (C / 4);

@@ -76,6 +76,10 @@ class SEModule(Module):
         self.fc2 = Conv2d(channels // reduction, channels, kernel_size=1, padding=0, bias=False)
         self.sigmoid = Sigmoid()
 
+    def forward(self, x):
+        """torch semantics, for third-party modules that embed an SEModule (the native units call e4s_se_gate_f32)."""
+        return x * torch.sigmoid(self.fc2(torch.relu(self.fc1(x.mean((2, 3), keepdim=True)))))
+
 
 class bottleneck_IR_SE_Ours(Module):
     """helpers.py:122-144"""

@@ -732,3 +732,126 @@ def shift_scale(x, tab, labels, num_regions, anchors, istride=1, dy=0, dx=0, os=
     call("e4s_shift_scale_f32", fptr(x), fptr(tab), ptr(labels), hm, wm, num_regions if labels is not None else 1,
          fptr(out), b, ha, wa, hi, wi, c, istride, dy, dx, os, py, px, stream())
     return out
+
+
+# ---- loss networks (csrc/criteria.hip) -------------------------------------------------------------------------
+def adaptive_pool(x, out_hw, crop=None, in_nchw=True, scale=None, shift=None):
+    """F.adaptive_avg_pool2d of x[:, :, y0:y0+hc, x0:x0+wc] (+ per-channel affine) -> NHWC [B,Ho,Wo,C]."""
+    x = _f32(x)
+    if in_nchw:
+        b, c, hi, wi = x.shape
+    else:
+        b, hi, wi, c = x.shape
+    y0, x0, hc, wc = crop if crop is not None else (0, 0, hi, wi)
+    ho, wo = out_hw
+    y = torch.empty(b, ho, wo, c, device=x.device, dtype=torch.float32)
+    call("e4s_adaptive_pool_f32", fptr(x), fptr(y), b, c, hi, wi, y0, x0, hc, wc, ho, wo, 1 if in_nchw else 0,
+         fptr(scale), fptr(shift), stream())
+    return y
+
+
+def adaptive_pool_bwd(dy, in_shape, crop=None, in_nchw=True, scale=None, dx_acc=None):
+    """gradient of adaptive_pool w.r.t. its input (shape in_shape, the input's layout); accumulated into dx_acc if given."""
+    if in_nchw:
+        b, c, hi, wi = in_shape
+    else:
+        b, hi, wi, c = in_shape
+    y0, x0, hc, wc = crop if crop is not None else (0, 0, hi, wi)
+    ho, wo = dy.shape[1:3]
+    dx = dx_acc if dx_acc is not None else torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    call("e4s_adaptive_pool_bwd_f32", fptr(_f32(dy)), fptr(dx), b, c, hi, wi, y0, x0, hc, wc, ho, wo, 1 if in_nchw else 0,
+         fptr(scale), 1 if dx_acc is not None else 0, stream())
+    return dx
+
+
+def pack_smallcin(w):
+    """[Cout,Cin,k,k] -> [k*k*Cin, Cout] (tap-major; e4s_conv_smallcin_f32's operand) -- a one-off layout change."""
+    cout, cin, k, _ = w.shape
+    return w.detach().float().permute(2, 3, 1, 0).reshape(k * k * cin, cout).contiguous()
+
+
+def conv_smallcin(x, wp, bias, cout, k, stride, pad, relu=False):
+    b, hi, wi, cin = x.shape
+    ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+    y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32)
+    call("e4s_conv_smallcin_f32", fptr(x), fptr(wp), fptr(bias), fptr(y), b, hi, wi, cin, ho, wo, cout, k, stride, pad,
+         1 if relu else 0, stream())
+    return y
+
+
+def conv_smallcin_bwd(dy, wp, in_shape, k, stride, pad):
+    b, hi, wi, cin = in_shape
+    _, ho, wo, cout = dy.shape
+    dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    call("e4s_conv_smallcin_bwd_f32", fptr(_f32(dy)), fptr(wp), fptr(dx), b, hi, wi, cin, ho, wo, cout, k, stride, pad,
+         stream())
+    return dx
+
+
+def maxpool3s2(x):
+    b, hi, wi, c = x.shape
+    ho, wo = (hi - 3) // 2 + 1, (wi - 3) // 2 + 1
+    y = torch.empty(b, ho, wo, c, device=x.device, dtype=torch.float32)
+    idx = torch.empty(b, ho, wo, c, device=x.device, dtype=torch.uint8)
+    call("e4s_maxpool3s2_f32", fptr(x), fptr(y), ptr(idx), b, hi, wi, c, stream())
+    return y, idx
+
+
+def maxpool3s2_bwd(dy, idx, in_shape):
+    b, hi, wi, c = in_shape
+    dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    call("e4s_maxpool3s2_bwd_f32", fptr(_f32(dy)), ptr(idx), fptr(dx), b, hi, wi, c, stream())
+    return dx
+
+
+def lpips_layer(fx, fy, w):
+    """[B] = spatial mean of the lin-weighted squared distance of the unit-normalised features (NHWC)."""
+    b, h, wd, c = fx.shape
+    out = torch.empty(b, device=fx.device, dtype=torch.float32)
+    ws = torch.empty(lib.load().e4s_lpips_layer_ws_doubles(b, h * wd), device=fx.device, dtype=torch.float64)
+    call("e4s_lpips_layer_f32", fptr(fx), fptr(fy), fptr(w), fptr(out), ptr(ws), b, h * wd, c, stream())
+    return out
+
+
+def lpips_layer_bwd(fx, fy, w, gout, gmul, dfx_acc=None):
+    """dfx (+)= gout[0] * gmul * d(sum_b lpips_layer[b]) / d(fx)."""
+    b, h, wd, c = fx.shape
+    dfx = dfx_acc if dfx_acc is not None else torch.empty_like(fx)
+    call("e4s_lpips_layer_bwd_f32", fptr(fx), fptr(fy), fptr(w), fptr(gout), float(gmul), fptr(dfx), b, h * wd, c,
+         1 if dfx_acc is not None else 0, stream())
+    return dfx
+
+
+def instnorm_bwd_sums(dy, x, stats):
+    """[B,C,2] = {sum_p dy, sum_p dy * (x - mean) * rstd} (ordered)."""
+    b, h, w, c = x.shape
+    sums = torch.empty(b, c, 2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.load().e4s_instnorm_bwd_ws_doubles(b, h * w, c), device=x.device, dtype=torch.float64)
+    call("e4s_instnorm_bwd_sums_f32", fptr(_f32(dy)), fptr(x), fptr(stats), fptr(sums), ptr(ws), b, h * w, c, stream())
+    return sums
+
+
+def norm_bwd_frozen(dy, stats, gate=None, extra=None, dx_acc=None):
+    """dx (+)= rstd * (gate * dy + extra): backward of a normalisation whose statistics are constants."""
+    b, h, w, c = dy.shape
+    dx = dx_acc if dx_acc is not None else torch.empty_like(dy)
+    call("e4s_norm_bwd_frozen_f32", fptr(_f32(dy)), fptr(stats), fptr(gate), fptr(extra), fptr(dx), b, h * w, c,
+         1 if dx_acc is not None else 0, stream())
+    return dx
+
+
+def cosine(a, b):
+    """rows of a, b [B, D] -> [B,3] = {cos, alpha, beta}, d(cos)/da = alpha*b + beta*a."""
+    n, d = a.shape[0], a.numel() // a.shape[0]
+    out = torch.empty(n, 3, device=a.device, dtype=torch.float32)
+    ws = torch.empty(lib.load().e4s_cosine_ws_doubles(n, d), device=a.device, dtype=torch.float64)
+    call("e4s_cosine_f32", fptr(a), fptr(b), fptr(out), ptr(ws), n, d, stream())
+    return out
+
+
+def cosine_bwd(a, b, coef, gout, gmul, da_acc=None):
+    n, d = a.shape[0], a.numel() // a.shape[0]
+    da = da_acc if da_acc is not None else torch.empty_like(a)
+    call("e4s_cosine_bwd_f32", fptr(a), fptr(b), fptr(coef), fptr(gout), float(gmul), fptr(da), n, d,
+         1 if da_acc is not None else 0, stream())
+    return da

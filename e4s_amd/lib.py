@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe4s_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -127,9 +127,24 @@ SIGNATURES = {
     "e4s_tensor2im_u8": [c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_paste_u8": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_grouped_linear_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p],
+    "e4s_adaptive_pool_f32": [c_p, c_p] + [c_i] * 11 + [c_p, c_p, c_p],
+    "e4s_adaptive_pool_bwd_f32": [c_p, c_p] + [c_i] * 11 + [c_p, c_i, c_p],
+    "e4s_conv_smallcin_f32": [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_p],
+    "e4s_conv_smallcin_bwd_f32": [c_p, c_p, c_p] + [c_i] * 10 + [c_p],
+    "e4s_maxpool3s2_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_maxpool3s2_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_lpips_layer_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "e4s_lpips_layer_ws_doubles": [c_i, c_i],
+    "e4s_lpips_layer_bwd_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_instnorm_bwd_sums_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "e4s_norm_bwd_frozen_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_cosine_f32": [c_p, c_p, c_p, c_p, c_i, c_l, c_p],
+    "e4s_cosine_ws_doubles": [c_i, c_l],
+    "e4s_cosine_bwd_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_l, c_i, c_p],
 }
 
-INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats"}       # size queries: return a count, not an error code
+INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats", "e4s_lpips_layer_ws_doubles",
+                "e4s_cosine_ws_doubles"}       # size queries: return a count, not an error code
 
 _lib = None
 

@@ -281,3 +281,49 @@ def synth_labels_face(batch=1, size=512, num_cls=12, seed=0, tag="face"):
             lab[ell(cx - 0.55, cy + 0.27, 0.03, 0.05)] = 11     # ear ring
         out[b, 0] = lab.clamp_(max=num_cls - 1)
     return out
+
+
+def synth_module_state_dict(module, seed=0, tag="crit."):
+    """Seeded values for every entry of a frozen loss network's state_dict (IDLoss / LPIPS; their real
+    weights are downloads).  Chosen by key and shape only, so the reference module and e4s_amd.criteria's get identical
+    tensors: conv / linear weights fan-in scaled (x sqrt(2) in front of a ReLU), BatchNorm scale 1 +- 0.1 with running
+    statistics near (0, 1), PReLU slopes near 0.25, LPIPS lin weights non-negative; registered constants (mean / std) and
+    counters keep their values."""
+    out = {}
+    for k, v in module.state_dict().items():
+        g = _gen(tag + k, seed)
+        shape = tuple(v.shape)
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked" or k.endswith("net.mean") or k.endswith("net.std"):
+            out[k] = v.clone()
+            continue
+        x = torch.randn(shape, generator=g, dtype=torch.float32)
+        if leaf == "running_var":
+            out[k] = 0.75 + 0.5 * torch.rand(shape, generator=g, dtype=torch.float32)
+        elif leaf == "running_mean":
+            out[k] = 0.1 * x
+        elif leaf == "bias":
+            out[k] = 0.1 * x
+        elif len(shape) == 1:                       # BatchNorm scale / PReLU slope
+            is_prelu = "res_layer.2." in k or k.endswith("input_layer.2.weight")
+            out[k] = 0.25 + 0.05 * x if is_prelu else 1.0 + 0.1 * x
+        elif ".lin." in k or k.startswith("lin."):
+            out[k] = 0.1 * x.abs()
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            gain = math.sqrt(2.0) if ".layers." in k else 1.0
+            out[k] = gain * x / math.sqrt(fan_in)
+    return out
+
+
+def synth_image_pair(batch=1, size=1024, seed=0):
+    """(y_hat, y): a smooth seeded image in [-1, 1] and a perturbed copy (what a loss network compares during inversion)."""
+    import torch.nn.functional as F
+    base = torch.randn(batch, 3, 16, 16, generator=_gen("pair.base", seed))
+    mid = torch.randn(batch, 3, 64, 64, generator=_gen("pair.mid", seed))
+    pert = torch.randn(batch, 3, 32, 32, generator=_gen("pair.pert", seed))
+    up = lambda t: F.interpolate(t, size=(size, size), mode="bilinear", align_corners=False)
+    y = (0.6 * up(base) + 0.2 * up(mid)).clamp_(-1, 1)
+    return (y + 0.15 * up(pert)).clamp_(-1, 1), y

@@ -107,7 +107,7 @@ typedef struct {
     int Hi, Wi, Ho, Wo, Cin, Cout;
     int istride;             /* input coord = anchor*istride + tap - 1 (3x3) / anchor*istride (1x1) */
     int ostride;             /* output coord = anchor*ostride + phase */
-    int ntaps;               /* 9 or 1 */
+    int ntaps;               /* 9 (3x3) or 1 (1x1); 25 (5x5, pad 2) in e4s_conv_mfma_f32's per-tap gather mode (spatial = 0) */
     int ncls;                /* 1, or 4 = polyphase up-conv (phase-specific weights) */
     const float* in_scale;   /* [G][Cin] style modulation s, or NULL */
     const float* out_scale;  /* [G][Cout] demodulation coefficient (x conv scale), or NULL */
@@ -386,6 +386,47 @@ int e4s_region_mean_f32(const float* feats, const uint8_t* labels, int Hm, int W
  * W is [R][O][K] (stacked EqualLinear weights); act: 0 none, 1 leaky(alpha). */
 int e4s_grouped_linear_f32(const float* x, const float* W, const float* bias, const float* add, float* y,
                            int B, int R, int K, int O, float scale, int act, float alpha, void* stream);
+
+/* ---- loss networks of the optimisation loop (scripts/optimization.py:88-122) ---------------------- */
+/* F.adaptive_avg_pool2d of a crop, with the per-channel affine that follows it: y NHWC [B,Ho,Wo,C] =
+ * mean_bin(x[b, c, y0:y0+Hc, x0:x0+Wc]) * scale[c] + shift[c] (scale/shift NULL: none).  x is NCHW (in_nchw = 1, the
+ * reference's image layout) or NHWC.  Replaces face_pool_1 / crop / face_pool_2 of src/criteria/id_loss.py:26-29 and
+ * F.adaptive_avg_pool2d + BaseNet.z_score of optimization.py:103-106, src/criteria/lpips/networks.py:50-51. */
+int e4s_adaptive_pool_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int y0, int x0, int Hc, int Wc, int Ho,
+                          int Wo, int in_nchw, const float* scale, const float* shift, void* stream);
+/* its backward: dx (layout of x) (+)= ...; pixels outside the crop receive 0 */
+int e4s_adaptive_pool_bwd_f32(const float* dy, float* dx, int B, int C, int Hi, int Wi, int y0, int x0, int Hc, int Wc,
+                              int Ho, int Wo, int in_nchw, const float* scale, int accumulate, void* stream);
+/* k x k conv of an image with Cin <= 4 channels (AlexNet features[0]: 3 -> 64, k 11, stride 4, pad 2): x NHWC, wp
+ * [k*k*Cin][Cout] (tap-major), bias [Cout] or NULL, optional ReLU; Cout % 16 == 0.  *_bwd: the gradient w.r.t. x. */
+int e4s_conv_smallcin_f32(const float* x, const float* wp, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
+                          int Ho, int Wo, int Cout, int k, int stride, int pad, int relu, void* stream);
+int e4s_conv_smallcin_bwd_f32(const float* dy, const float* wp, float* dx, int B, int Hi, int Wi, int Cin, int Ho, int Wo,
+                              int Cout, int k, int stride, int pad, void* stream);
+/* nn.MaxPool2d(3, 2): x NHWC [B,Hi,Wi,C] -> y [B,(Hi-3)/2+1,(Wi-3)/2+1,C] and idx (uint8, same shape): position of the first
+ * maximum in the window (ATen's tie rule); the backward routes dy through idx. */
+int e4s_maxpool3s2_f32(const float* x, float* y, uint8_t* idx, int B, int Hi, int Wi, int C, void* stream);
+int e4s_maxpool3s2_bwd_f32(const float* dy, const uint8_t* idx, float* dx, int B, int Hi, int Wi, int C, void* stream);
+/* LPIPS distance of one feature level (src/criteria/lpips/lpips.py:32-33 with utils.py:normalize_activation): out[b] =
+ * mean_p sum_c w[c] (fx/(|fx|+1e-10) - fy/(|fy|+1e-10))^2, fx / fy NHWC [B,HW,C], C <= 512; ws:
+ * e4s_lpips_layer_ws_doubles(B, HW) doubles (ordered reduction).  *_bwd: dfx (+)= gout[0] * gmul * d(out[b])/d(fx). */
+int e4s_lpips_layer_f32(const float* fx, const float* fy, const float* w, float* out, double* ws, int B, int HW, int C,
+                        void* stream);
+int64_t e4s_lpips_layer_ws_doubles(int B, int HW);
+int e4s_lpips_layer_bwd_f32(const float* fx, const float* fy, const float* w, const float* gout, float gmul, float* dfx,
+                            int B, int HW, int C, int accumulate, void* stream);
+/* normalisation with FROZEN statistics (BatchNorm2d in eval mode inside IDLoss, helpers.py:108-113): the two ordered sums
+ * of e4s_instnorm_bwd_f32 alone (sums[b,c,1] = dL/dgate), and dx (+)= rstd[b,c] * (gate[b,c] * dy + extra[b,c]). */
+int e4s_instnorm_bwd_sums_f32(const float* dy, const float* x, const float* stats, float* sums, double* ws, int B, int HW,
+                              int C, void* stream);
+int e4s_norm_bwd_frozen_f32(const float* dy, const float* stats, const float* gate, const float* extra, float* dx, int B,
+                            int HW, int C, int accumulate, void* stream);
+/* cosine similarity of rows (id_loss.py:41-48 on l2-normalised features): out[b] = {sim, alpha, beta} with
+ * d(sim)/da = alpha*b + beta*a; ws: e4s_cosine_ws_doubles(B, D) doubles.  *_bwd: da (+)= gout[0]*gmul*(alpha*b + beta*a). */
+int e4s_cosine_f32(const float* a, const float* b, float* out, double* ws, int B, int64_t D, void* stream);
+int64_t e4s_cosine_ws_doubles(int B, int64_t D);
+int e4s_cosine_bwd_f32(const float* a, const float* b, const float* coef, const float* gout, float gmul, float* da, int B,
+                       int64_t D, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -451,3 +451,104 @@ def paste_u8(face_u8, target_u8, content_mask):
     h, w = face_u8.shape[1:3]
     m = F.interpolate(content_mask, (h, w), mode="bilinear", align_corners=False)[:, 0, :, :, None]
     return (face_u8.float() * m + target_u8.float() * (1 - m)).to(torch.uint8)
+
+
+# --------------------------------------------------------------------------
+# N3: loss networks of the optimisation loop (scripts/optimization.py:88-122)
+# --------------------------------------------------------------------------
+def _bn_eval(sd, pfx, x, eps=1e-5):
+    """nn.BatchNorm2d / BatchNorm1d in eval mode (running statistics)."""
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    rm, rv = sd[pfx + "running_mean"].to(x.dtype), sd[pfx + "running_var"].to(x.dtype)
+    y = (x - rm.view(shape)) / torch.sqrt(rv.view(shape) + eps)
+    if pfx + "weight" in sd:
+        y = y * sd[pfx + "weight"].to(x.dtype).view(shape) + sd[pfx + "bias"].to(x.dtype).view(shape)
+    return y
+
+
+def irse50_unit(sd, pfx, x, cin, depth, stride):
+    """bottleneck_IR_SE, src/models/encoders/helpers.py:97-119 (SEModule :56-72)."""
+    w = lambda k: sd[pfx + k].to(x.dtype)
+    if cin == depth:
+        sc = x[:, :, ::stride, ::stride]                                   # MaxPool2d(1, stride)
+    else:
+        sc = _bn_eval(sd, pfx + "shortcut_layer.1.", F.conv2d(x, w("shortcut_layer.0.weight"), stride=stride))
+    r = _bn_eval(sd, pfx + "res_layer.0.", x)
+    r = F.conv2d(r, w("res_layer.1.weight"), padding=1)
+    r = F.prelu(r, w("res_layer.2.weight"))
+    r = F.conv2d(r, w("res_layer.3.weight"), stride=stride, padding=1)
+    r = _bn_eval(sd, pfx + "res_layer.4.", r)
+    g = r.mean((2, 3), keepdim=True)
+    g = torch.sigmoid(F.conv2d(F.relu(F.conv2d(g, w("res_layer.5.fc1.weight"))), w("res_layer.5.fc2.weight")))
+    return r * g + sc
+
+
+def irse50_plan():
+    """get_blocks(50), helpers.py:30-53: (in_channel, depth, stride) of the 24 units."""
+    plan = []
+    for cin, depth, n in ((64, 64, 3), (64, 128, 4), (128, 256, 14), (256, 512, 3)):
+        plan += [(cin, depth, 2)] + [(depth, depth, 1)] * (n - 1)
+    return plan
+
+
+def irse50_features(sd, x112, multi_scale=True, pfx="facenet."):
+    """Backbone.forward, src/models/encoders/model_irse.py:44-69 (eval: Dropout is the identity): l2-normalised rows."""
+    x = F.conv2d(x112, sd[pfx + "input_layer.0.weight"].to(x112.dtype), padding=1)
+    x = F.prelu(_bn_eval(sd, pfx + "input_layer.1.", x), sd[pfx + "input_layer.2.weight"].to(x112.dtype))
+    taps = []
+    for i, (cin, depth, stride) in enumerate(irse50_plan()):
+        x = irse50_unit(sd, f"{pfx}body.{i}.", x, cin, depth, stride)
+        if i in (2, 6, 20, 23):
+            taps.append(x.reshape(x.shape[0], -1))
+    x = _bn_eval(sd, pfx + "output_layer.0.", x).reshape(x.shape[0], -1)
+    x = F.linear(x, sd[pfx + "output_layer.3.weight"].to(x.dtype), sd[pfx + "output_layer.3.bias"].to(x.dtype))
+    x = _bn_eval(sd, pfx + "output_layer.4.", x)
+    rows = (taps if multi_scale else []) + [x]
+    return [r / torch.norm(r, 2, 1, True) for r in rows]                  # l2_norm, helpers.py:14-17
+
+
+def id_loss(sd, y_hat, y, multi_scale=True):
+    """IDLoss.forward, src/criteria/id_loss.py:24-57 -> (loss, sim_improvement)."""
+    def extract(x):
+        if x.shape[2] != 256:
+            x = F.adaptive_avg_pool2d(x, (256, 256))
+        x = F.adaptive_avg_pool2d(x[:, :, 35:223, 32:220], (112, 112))
+        return irse50_features(sd, x, multi_scale)
+    fy = [f.detach() for f in extract(y)]
+    fh = extract(y_hat)
+    loss, imp = 0.0, 0.0
+    for a, b in zip(fh, fy):
+        sim = (a * b).sum(1)
+        loss = loss + (1 - sim).mean()
+        imp = imp + (sim - (b * b).sum(1)).mean()
+    return loss, imp
+
+
+def alexnet_features(sd, x, pfx="net."):
+    """BaseNet.forward over AlexNet, src/criteria/lpips/networks.py:50-83: z-score, torchvision alexnet.features (conv
+    11/4/2 -> ReLU -> maxpool 3/2 -> conv 5/1/2 -> ReLU -> maxpool -> 3 x (conv 3/1/1 -> ReLU)), outputs after modules
+    2, 5, 8, 10, 12 (1-based), each unit-normalised over channels (utils.py normalize_activation, eps 1e-10)."""
+    w = lambda k: sd[pfx + k].to(x.dtype)
+    x = (x - w("mean")) / w("std")
+    outs = []
+    x = F.relu(F.conv2d(x, w("layers.0.weight"), w("layers.0.bias"), stride=4, padding=2)); outs.append(x)
+    x = F.max_pool2d(x, 3, 2)
+    x = F.relu(F.conv2d(x, w("layers.3.weight"), w("layers.3.bias"), padding=2)); outs.append(x)
+    x = F.max_pool2d(x, 3, 2)
+    x = F.relu(F.conv2d(x, w("layers.6.weight"), w("layers.6.bias"), padding=1)); outs.append(x)
+    x = F.relu(F.conv2d(x, w("layers.8.weight"), w("layers.8.bias"), padding=1)); outs.append(x)
+    x = F.relu(F.conv2d(x, w("layers.10.weight"), w("layers.10.bias"), padding=1)); outs.append(x)
+    return [o / (torch.sqrt(torch.sum(o ** 2, dim=1, keepdim=True)) + 1e-10) for o in outs]
+
+
+def lpips(sd, x, y):
+    """LPIPS.forward, src/criteria/lpips/lpips.py:29-35."""
+    fx, fy = alexnet_features(sd, x), alexnet_features(sd, y)
+    res = [F.conv2d((a - b) ** 2, sd[f"lin.{k}.1.weight"].to(x.dtype)).mean((2, 3), True)
+           for k, (a, b) in enumerate(zip(fx, fy))]
+    return torch.sum(torch.cat(res, 0)) / x.shape[0]
+
+
+def lpips_multiscale(sd, x, y, sizes=(1024, 512, 256)):
+    """the LPIPS term of Optimizer.calc_loss, scripts/optimization.py:100-108."""
+    return sum(lpips(sd, F.adaptive_avg_pool2d(x, (s, s)), F.adaptive_avg_pool2d(y, (s, s))) for s in sizes)

@@ -116,6 +116,38 @@ def reference_gpen():
     return mod
 
 
+def reference_criteria(alexnet_features):
+    """The reference's own IDLoss (src/criteria/id_loss.py) and LPIPS (src/criteria/lpips/lpips.py), imported in place with
+    the reference's `src` winning over this repo's overlay.  torchvision is absent here: `alexnet_features` (a callable
+    returning torchvision's AlexNet `features` Sequential, restated) stands in for `models.alexnet(True).features`
+    (lpips/networks.py:76), and the LPIPS weight download (lpips/utils.py:11-20) is replaced by the LinLayers'
+    initialisation -- callers load seeded weights afterwards."""
+    if "crit" in _CACHE:
+        return _CACHE["crit"]
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    import importlib
+    stub_third_party()
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
+    saved_path = list(sys.path)
+    sys.path[:] = [REF_ROOT] + [p for p in saved_path
+                                if not os.path.isfile(os.path.join(p or os.getcwd(), "src", "__init__.py"))]
+    try:
+        idm = importlib.import_module("src.criteria.id_loss")
+        lpm = importlib.import_module("src.criteria.lpips.lpips")
+        netm = importlib.import_module("src.criteria.lpips.networks")
+        netm.models = types.SimpleNamespace(alexnet=lambda *a, **k: types.SimpleNamespace(features=alexnet_features()))
+        lpm.get_state_dict = lambda net_type="alex", version="0.1": netm.LinLayers([64, 192, 384, 256, 256]).state_dict()
+        ns = types.SimpleNamespace(IDLoss=idm.IDLoss, LPIPS=lpm.LPIPS)
+    finally:
+        sys.path[:] = saved_path
+        for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+            del sys.modules[k]
+    _CACHE["crit"] = ns
+    return ns
+
+
 def make_opts(out_size=1024, remaining_layer_idx=13, num_seg_cls=12):
     return types.SimpleNamespace(fsencoder_type="psp", remaining_layer_idx=remaining_layer_idx,
                                  num_seg_cls=num_seg_cls, out_size=out_size, train_G=False,

@@ -20,6 +20,11 @@ What is pinned:
               swap's style vectors and image (strided + crops), its uint8 image (tensor2im, torch_utils.py:63-69), and the
               gradient of a crop-sized MSE loss w.r.t. the [1,12,1280] style vectors through cal_style_codes -> gen_img
               (scripts/optimization.py:209-232) computed by the reference's own autograd.
+  criteria.pt the loss networks of the optimisation loop run by the reference's own classes on seeded weights
+              (e4s_amd.synth.synth_module_state_dict): IDLoss (src/criteria/id_loss.py, multi-scale, 256^2 and 1024^2 inputs)
+              and LPIPS-AlexNet (src/criteria/lpips/lpips.py; torchvision's AlexNet topology restated, see
+              oracle/ref_shim.reference_criteria) at 256^2 and as the three-scale sum of scripts/optimization.py:100-108 on a
+              1024^2 pair: loss values, feature heads, and the gradient w.r.t. the generated image (strided).
 """
 import os
 import sys
@@ -216,8 +221,57 @@ def realmask_case():
     return rec
 
 
+def criteria_case():
+    import tempfile
+    import types
+    import torch.nn.functional as F
+    from e4s_amd import criteria as C
+    ns = ref_shim.reference_criteria(C.alexnet_features)
+    rec = {}
+    # ---- IDLoss ----
+    sd = synth.synth_module_state_dict(C.IDLoss(types.SimpleNamespace()), 0, "id.")
+    tmp = tempfile.mkdtemp()
+    torch.save({k[len("facenet."):]: v for k, v in sd.items() if k.startswith("facenet.")}, os.path.join(tmp, "irse50.pth"))
+    ref = ns.IDLoss(types.SimpleNamespace(ir_se50_path=os.path.join(tmp, "irse50.pth"), id_loss_multiscale=True)).eval()
+    for size, stride in ((256, 4), (1024, 16)):
+        yh, y = synth.synth_image_pair(2, size, seed=3)
+        yh.requires_grad_(True)
+        loss, imp, _ = ref(yh, y)
+        loss.backward()
+        with torch.no_grad():
+            feats = ref.extract_feats(y)
+        rec[f"id{size}"] = dict(loss=loss.detach().clone(), improvement=float(imp),
+                                feat_heads=[f[:, :64].clone() for f in feats],
+                                grad_strided=yh.grad[:, :, ::stride, ::stride].clone(), grad_absmax=yh.grad.abs().max().clone(),
+                                grad_l2=yh.grad.norm().clone(), stride=stride)
+    # ---- LPIPS ----
+    sdl = synth.synth_module_state_dict(C.LPIPS(), 0, "lp.")
+    refl = ns.LPIPS(net_type="alex").eval()
+    refl.load_state_dict(sdl)
+    yh, y = synth.synth_image_pair(2, 256, seed=4)
+    yh.requires_grad_(True)
+    loss = refl(yh, y)
+    loss.backward()
+    with torch.no_grad():
+        feats = refl.net(y)
+    rec["lpips256"] = dict(loss=loss.detach().clone(), feat_heads=[f[:, :8, :4, :4].clone() for f in feats],
+                           grad_strided=yh.grad[:, :, ::4, ::4].clone(), grad_l2=yh.grad.norm().clone(), stride=4)
+    yh, y = synth.synth_image_pair(1, 1024, seed=5)
+    yh.requires_grad_(True)
+    loss = sum(refl(F.adaptive_avg_pool2d(yh, (1024 // 2 ** i,) * 2), F.adaptive_avg_pool2d(y, (1024 // 2 ** i,) * 2))
+               for i in range(3))                                        # scripts/optimization.py:100-108
+    loss.backward()
+    rec["lpips1024x3"] = dict(loss=loss.detach().clone(), grad_strided=yh.grad[:, :, ::16, ::16].clone(),
+                              grad_l2=yh.grad.norm().clone(), stride=16)
+    return rec
+
+
 def main():
     torch.manual_seed(0)
+    if "--criteria-only" in sys.argv:
+        torch.save(criteria_case(), os.path.join(HERE, "criteria.pt"))
+        print("criteria.pt done")
+        return
     if "--realmask-only" in sys.argv:
         torch.save(realmask_case(), os.path.join(HERE, "realmask.pt"))
         print("realmask.pt done")
@@ -242,6 +296,8 @@ def main():
     print("gpen64.pt done")
     torch.save(realmask_case(), os.path.join(HERE, "realmask.pt"))
     print("realmask.pt done")
+    torch.save(criteria_case(), os.path.join(HERE, "criteria.pt"))
+    print("criteria.pt done")
 
 
 if __name__ == "__main__":

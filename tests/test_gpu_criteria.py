@@ -1,0 +1,293 @@
+"""GPU parity of the loss networks of the optimisation loop (scripts/optimization.py:88-122): every new
+kernel against ATen on the CPU, one IR-SE unit and both networks against the oracle's fp64 autograd, and IDLoss / LPIPS
+end to end against tests/golden/criteria.pt (made by the reference's own classes on the same seeded weights)."""
+import types
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from e4s_amd import synth
+from oracle import e4s_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def maxabs(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def rel_l2(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(autouse=True)
+def _f32(monkeypatch):
+    from e4s_amd import kernels as K
+    monkeypatch.setattr(K, "PRECISION", "f32")
+
+
+# ---- kernels -----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hi,crop,out,nchw", [(64, None, 16, True), (40, (3, 5, 31, 29), 17, True), (256, (35, 32, 188, 188), 112, False),
+                                             (48, None, 48, True), (30, None, 7, False)])
+def test_adaptive_pool_vs_aten(hi, crop, out, nchw):
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, hi, hi + 2, generator=g, dtype=torch.float64, requires_grad=True)
+    y0, x0, hc, wc = crop if crop else (0, 0, hi, hi + 2)
+    scale, shift = torch.tensor([1.5, -0.5, 2.0]), torch.tensor([0.1, 0.2, -0.3])
+    ref = F.adaptive_avg_pool2d(x[:, :, y0:y0 + hc, x0:x0 + wc], (out, out + 1)) * scale.double().view(1, 3, 1, 1) \
+        + shift.double().view(1, 3, 1, 1)
+    wgt = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    (ref * wgt).sum().backward()
+    xin = x.detach().float() if nchw else x.detach().float().permute(0, 2, 3, 1).contiguous()
+    y = K.adaptive_pool(xin.to(DEV), (out, out + 1), crop=crop, in_nchw=nchw, scale=scale.to(DEV), shift=shift.to(DEV))
+    assert maxabs(y.permute(0, 3, 1, 2), ref) < 2e-6
+    dy = wgt.float().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx = K.adaptive_pool_bwd(dy, tuple(xin.shape), crop=crop, in_nchw=nchw, scale=scale.to(DEV))
+    dx = dx if nchw else dx.permute(0, 3, 1, 2)
+    assert maxabs(dx, x.grad) < 2e-6
+    acc = torch.ones_like(dx).contiguous() if nchw else torch.ones(xin.shape, device=DEV)
+    dx2 = K.adaptive_pool_bwd(dy, tuple(xin.shape), crop=crop, in_nchw=nchw, scale=scale.to(DEV), dx_acc=acc)
+    dx2 = dx2 if nchw else dx2.permute(0, 3, 1, 2)
+    assert maxabs(dx2, x.grad + 1.0) < 2e-6
+
+
+@pytest.mark.parametrize("k,stride,pad,hi,cout", [(11, 4, 2, 64, 64), (11, 4, 2, 47, 64), (3, 1, 1, 20, 64), (5, 2, 1, 33, 16)])
+def test_conv_smallcin_vs_aten(k, stride, pad, hi, cout):
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, hi, hi + 3, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, 3, k, k, generator=g, dtype=torch.float64) / (3 * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g, dtype=torch.float64)
+    ref = F.relu(F.conv2d(x, w, bias, stride=stride, padding=pad))
+    pre = F.conv2d(x, w, None, stride=stride, padding=pad)
+    wgt = torch.randn(pre.shape, generator=g, dtype=torch.float64)
+    (pre * wgt).sum().backward()
+    wp = K.pack_smallcin(w.float().to(DEV))
+    xin = x.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = K.conv_smallcin(xin, wp, bias.float().to(DEV), cout, k, stride, pad, relu=True)
+    assert maxabs(y.permute(0, 3, 1, 2), ref) < 5e-6
+    dx = K.conv_smallcin_bwd(wgt.float().permute(0, 2, 3, 1).contiguous().to(DEV), wp, tuple(xin.shape), k, stride, pad)
+    assert maxabs(dx.permute(0, 3, 1, 2), x.grad) < 2e-5
+
+
+@pytest.mark.parametrize("hi,wi,c", [(15, 15, 64), (63, 31, 192), (8, 9, 4)])
+def test_maxpool3s2_vs_aten(hi, wi, c):
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    x = torch.relu(torch.randn(2, c, hi, wi, generator=g)).requires_grad_(True)     # exact ties at 0, like a ReLU output
+    ref = F.max_pool2d(x, 3, 2)
+    wgt = torch.randn(ref.shape, generator=g)
+    (ref * wgt).sum().backward()
+    xin = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    y, idx = K.maxpool3s2(xin)
+    assert maxabs(y.permute(0, 3, 1, 2), ref) == 0.0
+    dx = K.maxpool3s2_bwd(wgt.permute(0, 2, 3, 1).contiguous().to(DEV), idx, tuple(xin.shape))
+    assert maxabs(dx.permute(0, 3, 1, 2), x.grad) < 1e-6
+
+
+@pytest.mark.parametrize("c,hw", [(64, 15), (192, 7), (384, 5), (256, 9)])
+def test_lpips_layer_vs_formula(c, hw):
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(4)
+    fx = torch.relu(torch.randn(2, c, hw, hw, generator=g, dtype=torch.float64)).requires_grad_(True)
+    fy = torch.relu(torch.randn(2, c, hw, hw, generator=g, dtype=torch.float64))
+    w = torch.rand(c, generator=g, dtype=torch.float64)
+    nrm = lambda t: t / (torch.sqrt(torch.sum(t ** 2, dim=1, keepdim=True)) + 1e-10)
+    ref = (((nrm(fx) - nrm(fy)) ** 2) * w.view(1, c, 1, 1)).sum(1).mean((1, 2))          # [B]
+    (ref.sum() * 0.7).backward()
+    to = lambda t: t.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = K.lpips_layer(to(fx), to(fy), w.float().to(DEV))
+    assert maxabs(out, ref) < 1e-6
+    gout = torch.tensor([0.7], device=DEV)
+    dfx = K.lpips_layer_bwd(to(fx), to(fy), w.float().to(DEV), gout, 1.0)
+    assert rel_l2(dfx.permute(0, 3, 1, 2), fx.grad) < 1e-5
+    acc = torch.full_like(dfx, 2.0)
+    dfx2 = K.lpips_layer_bwd(to(fx), to(fy), w.float().to(DEV), gout, 1.0, dfx_acc=acc)
+    assert maxabs(dfx2, dfx + 2.0) < 1e-6
+
+
+def test_cosine_and_frozen_norm():
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(3, 10000, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(3, 10000, generator=g, dtype=torch.float64)
+    sim = F.cosine_similarity(a, b, dim=1)
+    ((1 - sim).mean() * 1.3).backward()
+    ad, bd = a.detach().float().to(DEV), b.float().to(DEV)
+    coef = K.cosine(ad, bd)
+    assert maxabs(coef[:, 0], sim) < 1e-6
+    da = K.cosine_bwd(ad, bd, coef, torch.tensor([1.3], device=DEV), -1.0 / 3)
+    assert rel_l2(da, a.grad) < 1e-5
+    # dx = rstd * (gate * dy + extra)
+    dy = torch.randn(2, 5, 6, 64, generator=g)
+    stats = torch.rand(2, 64, 2, generator=g) + 0.5
+    gate, extra = torch.rand(2, 64, generator=g), torch.randn(2, 64, generator=g)
+    ref = stats[:, None, None, :, 1] * (gate[:, None, None] * dy + extra[:, None, None])
+    out = K.norm_bwd_frozen(dy.to(DEV), stats.to(DEV), gate=gate.to(DEV), extra=extra.to(DEV))
+    assert maxabs(out, ref) < 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,h,w,taps,prec", [(64, 192, 31, 31, 25, "f32"), (192, 64, 13, 17, 25, "f32"), (192, 384, 15, 15, 9, "f32"),
+                                                    (384, 256, 63, 63, 9, "bf16x3"), (256, 256, 7, 7, 9, "bf16x3"),
+                                                    (128, 128, 56, 56, 9, "bf16x3"), (64, 64, 14, 28, 9, "f32")])
+def test_conv_odd_sizes_bias_relu(cin, cout, h, w, taps, prec, monkeypatch):
+    """The AlexNet / IR-SE50 geometries (5x5 taps; maps that are not multiples of the 16x16 / 8x16 tiles)."""
+    from e4s_amd import kernels as K
+    from e4s_amd.criteria import _Taps, _pack
+    from e4s_amd.encoders import _conv3x3
+    monkeypatch.setattr(K, "PRECISION", prec)
+    g = torch.Generator().manual_seed(6)
+    k = 5 if taps == 25 else 3
+    x = torch.randn(2, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), padding=k // 2))
+    conv = _Taps(wt.to(DEV))
+    xin = K.nchw_to_nhwc(x.to(DEV))
+    if taps == 9:
+        y = _conv3x3(xin, conv, cout, bias=bias.to(DEV), act=1, alpha=0.0, gain=1.0)
+    else:
+        y = K.conv_mfma(xin, _pack(conv), cout, ntaps=25, spatial=False, bias=bias.to(DEV), act=1, alpha=0.0, gain=1.0)
+    assert maxabs(K.nhwc_to_nchw(y), ref) < (2e-5 if prec == "f32" else 1e-4)
+
+
+# ---- IR-SE50 -----------------------------------------------------------------------------------------------------
+def _unit_sd(cin, depth, seed):
+    from e4s_amd.criteria import bottleneck_IR_SE
+    unit = bottleneck_IR_SE(cin, depth, 1)
+    return synth.synth_module_state_dict(unit, seed, "unit.")
+
+
+@pytest.mark.parametrize("cin,depth,stride,res,prec", [(64, 64, 2, 28, "f32"), (64, 128, 2, 14, "f32"), (256, 256, 1, 14, "f32"),
+                                                       (512, 512, 1, 7, "f32"), (128, 128, 1, 28, "bf16x3")])
+def test_irse_unit_forward_backward_vs_oracle_f64(cin, depth, stride, res, prec, monkeypatch):
+    from e4s_amd import kernels as K
+    from e4s_amd.criteria import bottleneck_IR_SE
+    monkeypatch.setattr(K, "PRECISION", prec)
+    unit = bottleneck_IR_SE(cin, depth, stride)
+    sd = synth.synth_module_state_dict(unit, 2, "unit.")
+    unit.load_state_dict(sd)
+    unit = unit.to(DEV).eval()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, cin, res, res, generator=g) * 1.2 + 0.2
+    wgt = torch.randn(2, depth, res // stride, res // stride, generator=g)
+    x64 = x.double().requires_grad_(True)
+    y64 = orc.irse50_unit({k: v.double() for k, v in sd.items()}, "", x64, cin, depth, stride)
+    (y64 * wgt.double()).sum().backward()
+    tape = []
+    y = unit.run_nhwc(K.nchw_to_nhwc(x.to(DEV)), tape)
+    tol = 1e-4 if prec == "f32" else 5e-4
+    assert maxabs(K.nhwc_to_nchw(y), y64) < tol
+    dx = unit.backward_nhwc(tape[0], K.nchw_to_nhwc(wgt.to(DEV)))
+    assert rel_l2(K.nhwc_to_nchw(dx), x64.grad) < (2e-4 if prec == "f32" else 2e-3)
+
+
+def _id_modules(multiscale=True):
+    from e4s_amd.criteria import IDLoss
+    mod = IDLoss(types.SimpleNamespace(id_loss_multiscale=multiscale))
+    sd = synth.synth_module_state_dict(mod, 0, "id.")
+    mod.load_state_dict(sd)
+    return mod.to(DEV).eval(), sd
+
+
+@pytest.mark.parametrize("size", [256, 1024])
+def test_idloss_vs_reference_golden(size, golden):
+    gold = golden("criteria.pt")[f"id{size}"]
+    mod, _ = _id_modules()
+    yh, y = synth.synth_image_pair(2, size, seed=3)
+    yh = yh.to(DEV).requires_grad_(True)
+    y = y.to(DEV)
+    loss, imp, _ = mod(yh, y)
+    loss.backward()
+    assert abs(float(loss) - float(gold["loss"])) < 2e-5
+    assert abs(float(imp) - gold["improvement"]) < 2e-5
+    for f, ref in zip(mod.extract_feats(y), gold["feat_heads"]):
+        assert maxabs(f[:, :64], ref) < 2e-5
+    s = gold["stride"]
+    assert rel_l2(yh.grad[:, :, ::s, ::s], gold["grad_strided"]) < 5e-3       # fp32-vs-fp32 (PReLU sides flip on ~1e-7 inputs)
+    assert abs(float(yh.grad.norm()) / float(gold["grad_l2"]) - 1.0) < 2e-3
+    # same call again: cached target features, bit-identical loss and gradient
+    g1 = yh.grad.clone()
+    yh.grad = None
+    loss2, _, _ = mod(yh, y)
+    loss2.backward()
+    assert float(loss2) == float(loss) and torch.equal(yh.grad, g1)
+
+
+def test_idloss_gradient_vs_oracle_f64():
+    mod, sd = _id_modules()
+    yh, y = synth.synth_image_pair(1, 256, seed=8)
+    y64h = yh.double().requires_grad_(True)
+    l64, _ = orc.id_loss({k: v.double() for k, v in sd.items()}, y64h, y.double())
+    l64.backward()
+    yd = yh.to(DEV).requires_grad_(True)
+    loss, _, _ = mod(yd, y.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(l64)) < 1e-5
+    assert rel_l2(yd.grad, y64h.grad) < 2e-3
+
+
+def test_idloss_single_scale_and_bf16x3(monkeypatch):
+    from e4s_amd import kernels as K
+    mod, sd = _id_modules(multiscale=False)
+    yh, y = synth.synth_image_pair(2, 256, seed=9)
+    l_ref, _ = orc.id_loss(sd, yh, y, multi_scale=False)
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    yd = yh.to(DEV).requires_grad_(True)
+    loss, _, _ = mod(yd, y.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(l_ref)) < 1e-4
+    assert torch.isfinite(yd.grad).all() and float(yd.grad.abs().max()) > 0
+
+
+# ---- LPIPS -------------------------------------------------------------------------------------------------------
+def _lpips_module():
+    from e4s_amd.criteria import LPIPS
+    mod = LPIPS()
+    sd = synth.synth_module_state_dict(mod, 0, "lp.")
+    mod.load_state_dict(sd)
+    return mod.to(DEV).eval(), sd
+
+
+def test_lpips_vs_reference_golden(golden):
+    gold = golden("criteria.pt")
+    mod, _ = _lpips_module()
+    yh, y = synth.synth_image_pair(2, 256, seed=4)
+    yd = yh.to(DEV).requires_grad_(True)
+    loss = mod(yd, y.to(DEV))
+    loss.backward()
+    g = gold["lpips256"]
+    assert abs(float(loss) / float(g["loss"]) - 1.0) < 1e-4
+    for f, ref in zip(mod.net(y.to(DEV)), g["feat_heads"]):
+        assert maxabs(f[:, :8, :4, :4], ref) < 1e-5
+    assert rel_l2(yd.grad[:, :, ::4, ::4], g["grad_strided"]) < 2e-3
+    assert abs(float(yd.grad.norm()) / float(g["grad_l2"]) - 1.0) < 1e-3
+    # the three-scale term of scripts/optimization.py:100-108 on a 1024^2 pair, pooling fused
+    yh, y = synth.synth_image_pair(1, 1024, seed=5)
+    yd = yh.to(DEV).requires_grad_(True)
+    loss = mod.forward_pooled(yd, y.to(DEV), (1024, 512, 256))
+    loss.backward()
+    g = gold["lpips1024x3"]
+    assert abs(float(loss) / float(g["loss"]) - 1.0) < 1e-4
+    assert rel_l2(yd.grad[:, :, ::16, ::16], g["grad_strided"]) < 2e-3
+    assert abs(float(yd.grad.norm()) / float(g["grad_l2"]) - 1.0) < 1e-3
+
+
+def test_lpips_gradient_vs_oracle_f64_and_bf16x3(monkeypatch):
+    from e4s_amd import kernels as K
+    mod, sd = _lpips_module()
+    yh, y = synth.synth_image_pair(2, 160, seed=11)
+    x64 = yh.double().requires_grad_(True)
+    l64 = orc.lpips_multiscale({k: v.double() for k, v in sd.items()}, x64, y.double(), sizes=(160, 96))
+    l64.backward()
+    for prec, tol in (("f32", 5e-4), ("bf16x3", 2e-3)):
+        monkeypatch.setattr(K, "PRECISION", prec)
+        yd = yh.to(DEV).requires_grad_(True)
+        loss = mod.forward_pooled(yd, y.to(DEV), (160, 96))
+        loss.backward()
+        assert abs(float(loss) / float(l64) - 1.0) < 1e-4, prec
+        assert rel_l2(yd.grad, x64.grad) < tol, prec

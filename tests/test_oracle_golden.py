@@ -94,3 +94,36 @@ def test_gpen_full_generator_matches_reference(golden):
         y, w = orc.gpen_full_generator(sd, x, c["size"], c["n_mlp"])
     assert tuple(y.shape) == (2, 3, c["size"], c["size"]) and tuple(w.shape) == (2, 512)
     assert float((y - g["img"]).abs().max()) < 1e-5
+
+
+def test_loss_networks_match_reference(golden):
+    """the oracle's IDLoss / LPIPS restatement against the reference's own classes run on the same
+    seeded weights (tests/golden/make_golden.py:criteria_case): loss values, feature heads, image gradients."""
+    import types
+    from e4s_amd import criteria as C
+    gold = golden("criteria.pt")
+    sd = synth.synth_module_state_dict(C.IDLoss(types.SimpleNamespace()), 0, "id.")
+    yh, y = synth.synth_image_pair(2, 256, seed=3)
+    yh.requires_grad_(True)
+    loss, imp = orc.id_loss(sd, yh, y)
+    loss.backward()
+    g = gold["id256"]
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 and abs(float(imp) - g["improvement"]) < 1e-5
+    with torch.no_grad():
+        x112 = torch.nn.functional.adaptive_avg_pool2d(y[:, :, 35:223, 32:220], (112, 112))
+        for f, ref in zip(orc.irse50_features(sd, x112), g["feat_heads"]):
+            assert float((f[:, :64] - ref).abs().max()) < 1e-5
+    d = yh.grad[:, :, ::4, ::4] - g["grad_strided"]
+    assert float(d.norm() / g["grad_strided"].norm()) < 5e-3             # fp32 vs fp32: PReLU sides flip on ~1e-7 inputs
+    sdl = synth.synth_module_state_dict(C.LPIPS(), 0, "lp.")
+    yh, y = synth.synth_image_pair(2, 256, seed=4)
+    yh.requires_grad_(True)
+    loss = orc.lpips(sdl, yh, y)
+    loss.backward()
+    g = gold["lpips256"]
+    assert abs(float(loss) / float(g["loss"]) - 1.0) < 1e-5
+    with torch.no_grad():
+        for f, ref in zip(orc.alexnet_features(sdl, y), g["feat_heads"]):
+            assert float((f[:, :8, :4, :4] - ref).abs().max()) < 1e-6
+    d = yh.grad[:, :, ::4, ::4] - g["grad_strided"]
+    assert float(d.norm() / g["grad_strided"].norm()) < 1e-4

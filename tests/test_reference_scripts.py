@@ -41,9 +41,28 @@ def test_scripts_resolve_hot_path_to_e4s_amd_and_the_rest_to_the_reference(face_
     assert op.fused_leaky_relu is e4s_amd.op.fused_leaky_relu and op.upfirdn2d is e4s_amd.op.upfirdn2d
     assert hasattr(op.conv2d_gradfix, "no_weight_gradients")                   # src/criteria/adv_loss.py:34
     helpers = importlib.import_module("src.models.encoders.helpers")
-    assert hasattr(helpers, "l2_norm") and hasattr(helpers, "bottleneck_IR_SE")  # reference's (ID loss, parsing UNet)
+    assert hasattr(helpers, "l2_norm") and "/reference/" in helpers.bottleneck_IR.__init__.__code__.co_filename  # parsing UNet
+    import e4s_amd.criteria
     import e4s_amd.encoders
     assert helpers.bottleneck_IR_SE_Ours is e4s_amd.encoders.bottleneck_IR_SE_Ours
+    assert helpers.bottleneck_IR_SE is e4s_amd.criteria.bottleneck_IR_SE
+    # the loss networks of the optimisation loop (scripts/optimization.py:23-24) are the native ones
+    assert opt.IDLoss is e4s_amd.criteria.IDLoss and opt.LPIPS is e4s_amd.criteria.LPIPS
+    assert "/reference/" in opt.FaceParsingLoss.__init__.__code__.co_filename
+
+
+def test_loss_network_state_dicts_match_the_reference_classes():
+    """IDLoss / LPIPS: same keys and shapes as the reference's own modules, so its checkpoints load unchanged."""
+    import tempfile
+    import e4s_amd.criteria as C
+    ns = ref_shim.reference_criteria(C.alexnet_features)
+    mine = C.IDLoss(types.SimpleNamespace())
+    tmp = tempfile.mkdtemp()
+    torch.save(mine.facenet.state_dict(), tmp + "/irse50.pth")
+    ref = ns.IDLoss(types.SimpleNamespace(ir_se50_path=tmp + "/irse50.pth", id_loss_multiscale=True))
+    shapes = lambda m: {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert shapes(mine) == shapes(ref)
+    assert shapes(C.LPIPS()) == shapes(ns.LPIPS(net_type="alex"))
 
 
 @pytest.mark.parametrize("case", ["plain", "no_ear", "no_teeth", "below_face"])
