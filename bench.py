@@ -113,11 +113,13 @@ def headline_probe(net, batch, mask, reps):
             "avg_launch_ms": round(ms, 4), "flop_per_launch": flops, "exact_fp32_variant": exact}
 
 
-def optimisation_leg(net, one, steps):
-    """BASELINE.json configs[2] in miniature (scripts/optimization.py:209-232): Adam(lr=1e-2) on the [1,12,1280]
-    regional style vectors through cal_style_codes -> gen_img (fresh noise every step, as the script does) with an
-    MSE loss against the target; the LPIPS/ID/parsing loss networks are out of scope."""
-    import warnings
+def optimisation_leg(net, one, steps, losses="full"):
+    """BASELINE.json configs[2] (scripts/optimization.py:209-232): Adam(lr=1e-2) on the [1,12,1280] regional style
+    vectors through cal_style_codes -> gen_img (fresh noise every step, as the script does).  losses = "full": the
+    script's default objective without the parsing term -- l2 * 1.0 + LPIPS-AlexNet at 1024/512/256 * 0.8 + IR-SE50 identity
+    * 0.1 (optim_options.py:44-48, optimization.py:88-122) on the native loss networks (e4s_amd.criteria, synthetic
+    weights: the real ones are downloads); "mse": the l2 term alone."""
+    import types
     driven, dm, target, tm, sm, _noise = one
     for p in net.parameters():
         p.requires_grad = False
@@ -126,12 +128,22 @@ def optimisation_leg(net, one, steps):
     latent = sv.clone().requires_grad_(True)
     from e4s_amd.optim import FusedAdam
     opt = FusedAdam([latent], lr=1e-2)          # torch.optim.Adam's update as one kernel (e4s_adam_step_f32)
+    lpips = idl = None
+    if losses == "full":
+        from e4s_amd.criteria import IDLoss, LPIPS
+        lpips = LPIPS()
+        lpips.load_state_dict(synth.synth_module_state_dict(lpips, 0, "lp."))
+        idl = IDLoss(types.SimpleNamespace(id_loss_multiscale=True))
+        idl.load_state_dict(synth.synth_module_state_dict(idl, 0, "id."))
+        lpips, idl = lpips.to(target.device).eval(), idl.to(target.device).eval()
 
     def one_step():
         opt.zero_grad()
         codes = net.cal_style_codes(latent)
         img, _, _ = net.gen_img(None, codes, tm, randomize_noise=True)
         loss = torch.nn.functional.mse_loss(img, target)
+        if lpips is not None:
+            loss = loss + 0.8 * lpips.forward_pooled(img, target, (1024, 512, 256)) + 0.1 * idl(img, target)[0]
         loss.backward()
         opt.step()
     for _ in range(2):
@@ -281,7 +293,9 @@ def main():
         return
     if args.opt_only:
         one = [t[:1].contiguous() if torch.is_tensor(t) else [n[:1].contiguous() for n in t] for t in inputs]
-        print(json.dumps({"config3_opt_step_ms": optimisation_leg(net, one, args.opt_steps), "steps": args.opt_steps}))
+        print(json.dumps({"config3_opt_step_ms": optimisation_leg(net, one, args.opt_steps, "full"),
+                          "config3_mse_only_step_ms": optimisation_leg(net, one, args.opt_steps, "mse"),
+                          "steps": args.opt_steps}))
         return
 
     from e4s_amd import shard
@@ -381,10 +395,11 @@ def main():
         if args.train_steps > 0:
             out["config5_train_step_1gpu"] = train_leg(dev, lat, args.train_steps)
         if args.opt_steps > 0:
-            ms = optimisation_leg(net, one, args.opt_steps)
-            out["config3_opt_step_ms"] = ms
+            ms = optimisation_leg(net, one, args.opt_steps, "full")
+            out["config3_opt_step_ms"] = ms                       # l2 + LPIPS x3 scales + ID (native loss networks)
             out["config3_steps_run"] = args.opt_steps
             out["config3_total_s"] = round(ms * args.opt_steps / 1e3, 3)
+            out["config3_mse_only_step_ms"] = optimisation_leg(net, one, args.opt_steps, "mse")
         if not args.no_cpu_baseline:
             cb, err = cpu_baseline(sd, lat, inputs, img[0:1], img1[0:1])
             out["cpu_baseline"] = cb
