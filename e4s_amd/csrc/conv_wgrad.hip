@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_kernel(const e4s_conv_wgra
         for (int t = tid; t < NH * (BC / 4); t += NTHR) {
             const int h = t / (BC / 4), c4 = (t - h * (BC / 4)) * 4;
             const int hy = h / HWD, hx = h - hy * HWD;
-            const int iy = tyb * T::TH * IS + hy - (NTAPS == 9 ? 1 : 0), ix = txb * TW * IS + hx - (NTAPS == 9 ? 1 : 0);
+            const int iy = tyb * T::TH * IS + hy - (NTAPS == 9 ? 1 : 0) + p.tap_shift, ix = txb * TW * IS + hx - (NTAPS == 9 ? 1 : 0) + p.tap_shift;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && ci0 + c4 < p.Cin)
                 v = *reinterpret_cast<const f32x4*>(p.x + (((size_t)tb * p.Hi + iy) * p.Wi + ix) * p.Cin + ci0 + c4);

@@ -145,6 +145,25 @@ __global__ void strided_scatter_kernel(const float* __restrict__ in, float* __re
     *reinterpret_cast<f32x4*>(out + i * 4) = v;
 }
 
+// out[b, y*s + oy, x*s + ox, c] = in[b, y, x, c] on an output grid [B, Ho, Wo, C] of any size >= the last placed index; every
+// other position is 0 (the dgrad operand of a stride-s padding-0 conv: Discriminator ConvLayers, model.py:683-700)
+__global__ void strided_place_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int s, int oy,
+                                     int ox, int Ho, int Wo, int64_t n4) {
+    const int C4 = C / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over the OUTPUT [B, Ho, Wo, C4]
+    if (i >= n4) return;
+    const int c = (int)(i % C4) * 4;
+    int64_t r = i / C4;
+    const int x = (int)(r % Wo); r /= Wo;
+    const int y = (int)(r % Ho);
+    const int64_t b = r / Ho;
+    const int ry = y - oy, rx = x - ox;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ry >= 0 && rx >= 0 && ry % s == 0 && rx % s == 0 && ry / s < H && rx / s < W)
+        v = *reinterpret_cast<const f32x4*>(in + ((b * H + ry / s) * W + rx / s) * C + c);
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+}
+
 // ---- regional average pooling backward: dfeat[b,p,c] (+)= dcodes[b, r(p), off + c] / count[b, r(p)] -------------------
 __global__ void region_count_kernel(const uint8_t* __restrict__ labels, int Hm, int Wm, int* __restrict__ cnt, int H,
                                     int W, int R) {
@@ -254,6 +273,16 @@ extern "C" int e4s_strided_scatter_f32(const float* in, float* out, int B, int H
     const int64_t n4 = (int64_t)B * H * s * W * s * (C / 4);
     if (n4 <= 0) return 0;
     hipLaunchKernelGGL(strided_scatter_kernel, grid1(n4), dim3(256), 0, as_stream(stream), in, out, H, W, C, s, accumulate, n4);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_strided_place_f32(const float* in, float* out, int B, int H, int W, int C, int s, int oy, int ox, int Ho,
+                                     int Wo, void* stream) {
+    if (C % 4 || s < 1 || oy < 0 || ox < 0 || (H - 1) * s + oy >= Ho || (W - 1) * s + ox >= Wo) return (int)hipErrorInvalidValue;
+    const int64_t n4 = (int64_t)B * Ho * Wo * (C / 4);
+    if (n4 <= 0) return 0;
+    hipLaunchKernelGGL(strided_place_kernel, grid1(n4), dim3(256), 0, as_stream(stream), in, out, H, W, C, s, oy, ox, Ho, Wo, n4);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -531,7 +531,7 @@ def adam_step(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step):
 
 
 def conv_wgrad(gz, x, *, ntaps=9, istride=1, anchors=None, ostride=1, phase=(0, 0), s=None, d=None, labels=None,
-               num_regions=1):
+               num_regions=1, tap_shift=0):
     """dw [ntaps, Cout, Cin] of a 3x3 / 1x1 conv (see e4s_conv_wgrad_f32): gz NHWC [B,Ho,Wo,Cout], x NHWC [B,Hi,Wi,Cin].
     anchors default to the output grid (ostride 1) / the input grid (polyphase phase, ostride 2)."""
     b, ho, wo, cout = gz.shape
@@ -547,6 +547,7 @@ def conv_wgrad(gz, x, *, ntaps=9, istride=1, anchors=None, ostride=1, phase=(0, 
         p.labels, p.Hm, p.Wm, p.R = None, 0, 0, 1
     p.B, p.Hi, p.Wi, p.Cin, p.Ha, p.Wa, p.Ho, p.Wo, p.Cout = b, hi, wi, cin, anchors[0], anchors[1], ho, wo, cout
     p.istride, p.ostride, p.py, p.px, p.ntaps = istride, ostride, phase[0], phase[1], ntaps
+    p.tap_shift = int(tap_shift)
     p.ws = None
     ws = torch.empty(lib.load().e4s_conv_wgrad_ws_floats(ctypes.byref(p)), device=x.device, dtype=torch.float32)
     p.ws = fptr(ws)
@@ -592,6 +593,26 @@ def strided_scatter(src, s, out=None):
         out = torch.empty(b, h * s, w * s, c, device=src.device, dtype=torch.float32)
     call("e4s_strided_scatter_f32", fptr(_f32(src)), fptr(out), b, h, w, c, int(s), acc, stream())
     return out
+
+
+def strided_place(src, s, oy, ox, out_hw):
+    """[B,Ho,Wo,C] with out[b, y*s+oy, x*s+ox] = src[b, y, x] and zeros elsewhere."""
+    b, h, w, c = src.shape
+    out = torch.empty(b, out_hw[0], out_hw[1], c, device=src.device, dtype=torch.float32)
+    call("e4s_strided_place_f32", fptr(_f32(src)), fptr(out), b, h, w, c, int(s), int(oy), int(ox), out_hw[0], out_hw[1],
+         stream())
+    return out
+
+
+def torgb_bwd_w(drgb, x):
+    """dws[b,c,ci] = sum_p drgb[b,c,p] * x[b,p,ci] (drgb NCHW [B,3,H,W], x NHWC [B,H,W,C]) -> [B,3,C]."""
+    b, h, w, c = x.shape
+    dws = torch.empty(b, 3, c, device=x.device, dtype=torch.float32)
+    L = lib.load()
+    scratch = torch.empty(L.e4s_reduce_parts_ws_floats(L.e4s_seg_reduce_nsplit(b, h, w, c), dws.numel()), device=x.device,
+                          dtype=torch.float32)
+    call("e4s_torgb_bwd_w_f32", fptr(_f32(drgb)), fptr(x), None, 0, 0, 1, fptr(dws), fptr(scratch), b, h, w, c, stream())
+    return dws
 
 
 def region_mean_bwd(dcodes, labels, num_regions, shape, off, dfeat_acc=None):

@@ -53,7 +53,7 @@ class ConvWgradParams(ctypes.Structure):
         ("gz", c_p), ("x", c_p), ("dw", c_p), ("ws", c_p), ("s", c_p), ("d", c_p), ("labels", c_p),
         ("Hm", c_i), ("Wm", c_i), ("R", c_i),
         ("B", c_i), ("Hi", c_i), ("Wi", c_i), ("Cin", c_i), ("Ha", c_i), ("Wa", c_i), ("Ho", c_i), ("Wo", c_i), ("Cout", c_i),
-        ("istride", c_i), ("ostride", c_i), ("py", c_i), ("px", c_i), ("ntaps", c_i),
+        ("istride", c_i), ("ostride", c_i), ("py", c_i), ("px", c_i), ("ntaps", c_i), ("tap_shift", c_i),
     ]
 
 
@@ -113,6 +113,7 @@ SIGNATURES = {
     "e4s_prelu_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p],
     "e4s_prelu_bwd_ws_floats": [c_l, c_i],
     "e4s_strided_scatter_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "e4s_strided_place_f32": [c_p, c_p] + [c_i] * 9 + [c_p],
     "e4s_region_mean_bwd_f32": [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_conv1x1_small_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_p],
     "e4s_noise_half_f32": [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_f, c_p],

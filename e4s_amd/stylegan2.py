@@ -640,8 +640,9 @@ def equal_linear_lrelu(lin, x):
     return y.squeeze(1)
 
 
-# ---- Discriminator (config 5): native forward on the MFMA conv kernels when no gradient is asked for; with autograd the
-# convs go through conv2d_gradfix -> ATen exactly as the reference does (its R1 penalty needs double backward) ----
+# ---- Discriminator (config 5): native forward on the MFMA conv kernels; under autograd the same kernels as closed families
+# of autograd Functions (disc_autograd.py) that can be differentiated twice (the R1 penalty).  CPU tensors take the module
+# tree's own torch forward (conv2d_gradfix -> ATen), which exists for state_dict / API parity with the reference ----
 class ConvLayer(nn.Sequential):
     """model.py:670-716"""
 
@@ -719,8 +720,11 @@ class Discriminator(nn.Module):
         return equal_linear_lrelu(self.final_linear[1], equal_linear_lrelu(self.final_linear[0], flat))
 
     def forward(self, input):
-        if input.is_cuda and not self._needs_autograd(input):
-            return self.forward_native(input)
+        if input.is_cuda:
+            if not self._needs_autograd(input):
+                return self.forward_native(input)
+            from .disc_autograd import discriminator_forward      # native graph, differentiable twice (R1, adv_loss.py:48-60)
+            return discriminator_forward(self, input)
         out = self.convs(input)
         batch, channel, height, width = out.shape
         group = min(batch, self.stddev_group)

@@ -215,6 +215,7 @@ typedef struct {
     int istride;             /* 1 or 2 */
     int ostride, py, px;     /* 1,0,0; or 2 and the phase of a polyphase up-conv (one call per phase) */
     int ntaps;               /* 9 or 1 */
+    int tap_shift;           /* 0; 1 = padding-0 3x3 conv (input coord = a*istride + tap), as e4s_conv_params.tap_shift */
 } e4s_conv_wgrad_params;
 int e4s_conv_wgrad_f32(const e4s_conv_wgrad_params* p, void* stream);
 int64_t e4s_conv_wgrad_ws_floats(const e4s_conv_wgrad_params* p);
@@ -276,6 +277,10 @@ int64_t e4s_prelu_bwd_ws_floats(int64_t npix, int C);
 /* out[b, y*s, x*s, :] (+)= in[b, y, x, :], in NHWC [B,H,W,C], out NHWC [B,H*s,W*s,C]; without accumulate the other
  * positions are zero-filled (zero insertion: the stride-2 conv's dgrad; with accumulate: MaxPool2d(1, s)'s backward) */
 int e4s_strided_scatter_f32(const float* in, float* out, int B, int H, int W, int C, int s, int accumulate, void* stream);
+/* out[b, y*s + oy, x*s + ox, :] = in[b, y, x, :] on an output grid NHWC [B,Ho,Wo,C], zero elsewhere: the dgrad operand of a
+ * stride-s padding-0 conv (Discriminator ConvLayers, model.py:683-700) */
+int e4s_strided_place_f32(const float* in, float* out, int B, int H, int W, int C, int s, int oy, int ox, int Ho, int Wo,
+                          void* stream);
 /* backward of e4s_region_mean_f32: dfeat[b,p,c] (+)= dcodes[b, label(p), off + c] / count[b, label(p)];
  * counts: int scratch [B*R] */
 int e4s_region_mean_bwd_f32(const float* dcodes, const uint8_t* labels, int Hm, int Wm, int* counts, float* dfeat, int B,
