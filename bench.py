@@ -113,12 +113,13 @@ def headline_probe(net, batch, mask, reps):
             "avg_launch_ms": round(ms, 4), "flop_per_launch": flops, "exact_fp32_variant": exact}
 
 
-def optimisation_leg(net, one, steps, losses="full"):
+def optimisation_leg(net, one, steps, losses="full", graphed=False):
     """BASELINE.json configs[2] (scripts/optimization.py:209-232): Adam(lr=1e-2) on the [1,12,1280] regional style
     vectors through cal_style_codes -> gen_img (fresh noise every step, as the script does).  losses = "full": the
     script's default objective without the parsing term -- l2 * 1.0 + LPIPS-AlexNet at 1024/512/256 * 0.8 + IR-SE50 identity
     * 0.1 (optim_options.py:44-48, optimization.py:88-122) on the native loss networks (e4s_amd.criteria, synthetic
-    weights: the real ones are downloads); "mse": the l2 term alone."""
+    weights: the real ones are downloads); "mse": the l2 term alone.  graphed: the whole step (forward, losses, backward, Adam with
+    its step count on the device) replayed as one HIP graph (e4s_amd.optim.GraphedStep)."""
     import types
     driven, dm, target, tm, sm, _noise = one
     for p in net.parameters():
@@ -127,7 +128,7 @@ def optimisation_leg(net, one, steps, losses="full"):
         sv, _ = net.get_style_vectors(target, tm)
     latent = sv.clone().requires_grad_(True)
     from e4s_amd.optim import FusedAdam
-    opt = FusedAdam([latent], lr=1e-2)          # torch.optim.Adam's update as one kernel (e4s_adam_step_f32)
+    opt = FusedAdam([latent], lr=1e-2, capturable=graphed)      # torch.optim.Adam's update as one kernel
     lpips = idl = None
     if losses == "full":
         from e4s_amd.criteria import IDLoss, LPIPS
@@ -137,8 +138,7 @@ def optimisation_leg(net, one, steps, losses="full"):
         idl.load_state_dict(synth.synth_module_state_dict(idl, 0, "id."))
         lpips, idl = lpips.to(target.device).eval(), idl.to(target.device).eval()
 
-    def one_step():
-        opt.zero_grad()
+    def body():
         codes = net.cal_style_codes(latent)
         img, _, _ = net.gen_img(None, codes, tm, randomize_noise=True)
         loss = torch.nn.functional.mse_loss(img, target)
@@ -146,14 +146,41 @@ def optimisation_leg(net, one, steps, losses="full"):
             loss = loss + 0.8 * lpips.forward_pooled(img, target, (1024, 512, 256)) + 0.1 * idl(img, target)[0]
         loss.backward()
         opt.step()
+        return loss.detach()
+    if graphed:
+        from e4s_amd.optim import GraphedStep
+        gs = GraphedStep(opt, body, warmup=2)       # 2 eager steps, then the step as ONE HIP graph
+        gs.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gs.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if int(gs.flags.item()) != 0 or not bool(torch.isfinite(gs.loss)):
+            raise RuntimeError("graphed optimisation step: invalid mask or non-finite loss")
+        return round(dt / steps * 1e3, 3)
     for _ in range(2):
-        one_step()
+        opt.zero_grad(set_to_none=True)
+        body()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        one_step()
+        opt.zero_grad(set_to_none=True)
+        body()
     torch.cuda.synchronize()
     return round((time.perf_counter() - t0) / steps * 1e3, 3)
+
+
+def config3_legs(net, one, args):
+    modes = args.opt_modes.split(",")
+    out = {}
+    if "full" in modes:
+        out["config3_opt_step_ms"] = optimisation_leg(net, one, args.opt_steps, "full", graphed=args.opt_graph)
+    if "mse" in modes:
+        out["config3_mse_only_step_ms"] = optimisation_leg(net, one, args.opt_steps, "mse", graphed=args.opt_graph)
+    out["config3_graphed"] = bool(args.opt_graph)
+    return out
 
 
 def gpen_leg(dev, reps=10):
@@ -239,6 +266,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the ~700 launches per step eagerly instead of "
                                                             "replaying one captured HIP graph")
+    ap.add_argument("--opt-modes", default="full,mse",
+                    help="config-3 legs to run: full = l2 + LPIPS x3 + ID, mse = l2 only")
+    ap.add_argument("--opt-graph", action="store_true",
+                    help="replay each config-3 step as one HIP graph (e4s_amd.optim.GraphedStep); measured 11.6 vs 11.9 ms on the "
+                         "l2-only step -- the loop is bound by the duration of its many small kernels, not by launch overhead")
     ap.add_argument("--opt-steps", type=int, default=200,
                     help="configs[2] leg: run this many W+ optimisation steps (scripts/optimization.py runs 200: "
                          "cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam each) and report the measured total")
@@ -293,9 +325,7 @@ def main():
         return
     if args.opt_only:
         one = [t[:1].contiguous() if torch.is_tensor(t) else [n[:1].contiguous() for n in t] for t in inputs]
-        print(json.dumps({"config3_opt_step_ms": optimisation_leg(net, one, args.opt_steps, "full"),
-                          "config3_mse_only_step_ms": optimisation_leg(net, one, args.opt_steps, "mse"),
-                          "steps": args.opt_steps}))
+        print(json.dumps(dict(config3_legs(net, one, args), steps=args.opt_steps)))
         return
 
     from e4s_amd import shard
@@ -395,11 +425,10 @@ def main():
         if args.train_steps > 0:
             out["config5_train_step_1gpu"] = train_leg(dev, lat, args.train_steps)
         if args.opt_steps > 0:
-            ms = optimisation_leg(net, one, args.opt_steps, "full")
-            out["config3_opt_step_ms"] = ms                       # l2 + LPIPS x3 scales + ID (native loss networks)
+            out.update(config3_legs(net, one, args))
             out["config3_steps_run"] = args.opt_steps
-            out["config3_total_s"] = round(ms * args.opt_steps / 1e3, 3)
-            out["config3_mse_only_step_ms"] = optimisation_leg(net, one, args.opt_steps, "mse")
+            if "config3_opt_step_ms" in out:
+                out["config3_total_s"] = round(out["config3_opt_step_ms"] * args.opt_steps / 1e3, 3)
         if not args.no_cpu_baseline:
             cb, err = cpu_baseline(sd, lat, inputs, img[0:1], img1[0:1])
             out["cpu_baseline"] = cb

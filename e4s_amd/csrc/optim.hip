@@ -117,6 +117,30 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gra
     p[i] = pv - step_size * (mi / denom);                       // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+// capturable form (a HIP graph replays the same launch every step): the step count lives in device memory, is advanced by
+// the first kernel and read by the second, which computes the bias corrections in double as the host path does
+__global__ void adam_advance_kernel(int64_t* step) { *step += 1; }
+
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
+                                float* __restrict__ v, int64_t n, double lr, double beta1, double beta2, float eps, float wd,
+                                const int64_t* __restrict__ step) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double t = (double)*step;
+    const float step_size = (float)(lr / (1.0 - pow(beta1, t)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
+    const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    float g = grad[i];
+    const float pv = p[i];
+    if (wd != 0.f) g += wd * pv;
+    const float mi = m[i] + omb1 * (g - m[i]);
+    const float vi = v[i] * b2 + omb2 * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pv - step_size * (mi / denom);
+}
+
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 int linear_t_nsplit(int R, int O, int K) {
@@ -202,6 +226,21 @@ extern "C" int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v
     hipLaunchKernelGGL(adam_kernel, grid1(n), dim3(256), 0, as_stream(stream), p, grad, m, v, n, (float)(lr / bc1),
                        (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)(1.0 - beta1),
                        (float)(1.0 - beta2), (float)bc2_sqrt);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_adam_step_dev_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
+                                     double beta2, double eps, double weight_decay, int64_t* step, int advance, void* stream) {
+    if (!step) return (int)hipErrorInvalidValue;
+    hipStream_t st = as_stream(stream);
+    if (advance) {
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, step);
+        E4S_CHECK_LAUNCH();
+    }
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(adam_dev_kernel, grid1(n), dim3(256), 0, st, p, grad, m, v, n, lr, beta1, beta2, (float)eps,
+                       (float)weight_decay, step);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -530,6 +530,14 @@ def adam_step(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step):
          float(eps), float(weight_decay), int(step), stream())
 
 
+def adam_step_dev(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step, advance):
+    """adam_step with the step count in a device int64[1] tensor (capturable in a HIP graph); advance: increment it first."""
+    if step.dtype != torch.int64 or not step.is_cuda:
+        raise RuntimeError("adam_step_dev: step must be a device int64 tensor")
+    call("e4s_adam_step_dev_f32", fptr(p), fptr(_f32(grad)), fptr(m), fptr(v), p.numel(), float(lr), float(beta1),
+         float(beta2), float(eps), float(weight_decay), ptr(step), 1 if advance else 0, stream())
+
+
 def conv_wgrad(gz, x, *, ntaps=9, istride=1, anchors=None, ostride=1, phase=(0, 0), s=None, d=None, labels=None,
                num_regions=1, tap_shift=0):
     """dw [ntaps, Cout, Cin] of a 3x3 / 1x1 conv (see e4s_conv_wgrad_f32): gz NHWC [B,Ho,Wo,Cout], x NHWC [B,Hi,Wi,Cin].

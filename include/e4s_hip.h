@@ -324,6 +324,11 @@ int e4s_batch_sum_f32(const float* x, float* out, int B, int64_t n, void* stream
  * bias corrections are evaluated in double on the host as torch does */
 int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                       double eps, double weight_decay, int step, void* stream);
+/* the same update with the step count in DEVICE memory (int64, advanced by this call when `advance`): nothing step-dependent
+ * is computed on the host, so the launch can be captured in a HIP graph and replayed (one `step` per optimiser, advanced by
+ * the first parameter's call) */
+int e4s_adam_step_dev_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                          double eps, double weight_decay, int64_t* step, int advance, void* stream);
 
 /* ---- device pre/post-processing of the face-swap pipeline ------------------------------- */
 /* labelMap2OneHot (src/utils/torch_utils.py:166-172): labels u8 [B,H,W] -> one-hot fp32 [B,R,H,W] */

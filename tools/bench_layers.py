@@ -37,11 +37,34 @@ CASES += [("s2 128->128 @256->128", 16, 256, 128, 128, "s2"), ("s2 256->256 @128
           ("s2 512->512 @64->32", 16, 64, 512, 512, "s2"), ("s2 512->512 @32->16", 16, 32, 512, 512, "s2"),
           ("sc 64->128 @256->128", 16, 256, 64, 128, "sc"), ("sc 128->256 @128->64", 16, 128, 128, 256, "sc"),
           ("sc 256->512 @64->32", 16, 64, 256, 512, "sc")]
+# masked up-convs (region-select): exact fp32 (one pass per region present in a tile) vs polyphase split-bf16
+CASES += [("mup 512->512 ->64", 8, 32, 512, 512, "mup"), ("mup 512->256 ->128", 8, 64, 512, 256, "mup"),
+          ("mup 256->128 ->256", 8, 128, 256, 128, "mup")]
 only = sys.argv[1:]
 for tag, b, res, cin, cout, kind in CASES:
     if only and not any(o in tag for o in only):
         continue
     x = torch.randn(b, res, res, cin, device=dev)
+    if kind == "mup":
+        from e4s_amd import synth
+        R = 12
+        lab = torch.cat([synth.synth_labels_face(1, 512, seed=40 + i) for i in range(b)], 0)
+        labels, _ = K.mask_labels(synth.onehot(lab).to(dev))
+        w = torch.randn(4, 9, cout, cin, device=dev) / (3 * cin ** 0.5)
+        w3 = torch.randn(1, 9, cout, cin, device=dev) / (3 * cin ** 0.5)
+        ws = K.split_bf16x2(w)
+        s = torch.rand(b * R, cin, device=dev) + 0.5
+        d = torch.rand(b * R, cout, device=dev) + 0.5
+        nz = torch.randn(b, 1, 2 * res, 2 * res, device=dev)
+        kw = dict(in_scale=s, out_scale=d, noise=nz, noise_w=torch.tensor([0.1], device=dev), bias=torch.randn(cout, device=dev),
+                  act=1, labels=labels, num_regions=R)
+        row = {"layer": tag, "gflop_alg": 2.0 * b * res * res * cin * cout * 9 / 1e9}
+        row["f32_exact_ms"] = timeit(lambda: K.upconv_mfma(x, w3, cout, k4, **kw))
+        row["bf16x3_ms"] = timeit(lambda: K.conv_mfma(x, w, cout, ncls=4, ostride=2, w_split=ws, **kw))
+        row = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items()}
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+        continue
     if kind in ("s2", "sc"):
         nt = 9 if kind == "s2" else 1
         w = torch.randn(1, nt, cout, cin, device=dev) / (nt * cin) ** 0.5
