@@ -168,46 +168,66 @@ __global__ void instnorm_apply_stats_kernel(const float* __restrict__ x, const f
                                             const float* __restrict__ res_stats, const float* __restrict__ slope,
                                             float* __restrict__ y, double* __restrict__ ws, int H, int W, int C, int rs,
                                             int nsplit) {
+    // 16 lanes x float4 walk the 64 channels of the slab, 16 pixel groups: a wave instruction moves 4 pixels x 256 B
     const int slabs = C / 64, HW = H * W;
     const int split = blockIdx.x % nsplit;
     const int slab = (blockIdx.x / nsplit) % slabs;
     const int b = blockIdx.x / (nsplit * slabs);
-    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int cl = (threadIdx.x & 15) * 4, pg = threadIdx.x >> 4;
     const int c = slab * 64 + cl;
     const int per = (HW + nsplit - 1) / nsplit;
     const int p0 = split * per, p1 = (p0 + per < HW) ? p0 + per : HW;
     const int64_t bc = (int64_t)b * C + c;
-    const float mean = stats[bc * 2], rstd = stats[bc * 2 + 1];
-    const float g = gate ? gate[bc] : 1.f;
-    const float rmean = res_stats ? res_stats[bc * 2] : 0.f, rrstd = res_stats ? res_stats[bc * 2 + 1] : 1.f;
-    const float sl = slope ? slope[c] : 0.f;
+    f32x4 mean, rstd, g, rmean, rrstd, sl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        mean[e] = stats[(bc + e) * 2];
+        rstd[e] = stats[(bc + e) * 2 + 1];
+        g[e] = gate ? gate[bc + e] : 1.f;
+        rmean[e] = res_stats ? res_stats[(bc + e) * 2] : 0.f;
+        rrstd[e] = res_stats ? res_stats[(bc + e) * 2 + 1] : 1.f;
+        sl[e] = slope ? slope[c + e] : 0.f;
+    }
     const int Wr = W * rs;
-    double s = 0.0, q = 0.0;
-    for (int p = p0 + pg; p < p1; p += 4) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int p = p0 + pg; p < p1; p += 16) {
         const int64_t idx = ((int64_t)b * HW + p) * C + c;
-        float o = (x[idx] - mean) * rstd;
+        f32x4 o = (*reinterpret_cast<const f32x4*>(x + idx) - mean) * rstd;
         if (gate) o *= g;
         if (res) {
             const int yy = p / W, xx = p - yy * W;
-            float t = res[(((int64_t)b * H * rs + (int64_t)yy * rs) * Wr + (int64_t)xx * rs) * C + c];
+            f32x4 t = *reinterpret_cast<const f32x4*>(res + (((int64_t)b * H * rs + (int64_t)yy * rs) * Wr + (int64_t)xx * rs) * C + c);
             if (res_stats) t = (t - rmean) * rrstd;
             o += t;
         }
-        if (slope) o = o > 0.f ? o : o * sl;
-        y[idx] = o;
-        s += (double)o;
-        q += (double)o * (double)o;
+        if (slope) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * sl[e];
+        }
+        *reinterpret_cast<f32x4*>(y + idx) = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s[e] += (double)o[e];
+            q[e] += (double)o[e] * (double)o[e];
+        }
     }
-    __shared__ double red[2][4][64];
-    red[0][pg][cl] = s;
-    red[1][pg][cl] = q;
+    __shared__ double red[2][16][64];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][pg][cl + e] = s[e];
+        red[1][pg][cl + e] = q[e];
+    }
     __syncthreads();
-    if (pg == 0) {
-        s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        q = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-        double* slot = ws + (bc * nsplit + split) * 2;
-        slot[0] = s;
-        slot[1] = q;
+    if (threadIdx.x < 64) {
+        double a = 0.0, d = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                 // pixel groups added in order
+            a += red[0][k][threadIdx.x];
+            d += red[1][k][threadIdx.x];
+        }
+        double* slot = ws + (((int64_t)b * C + slab * 64 + threadIdx.x) * nsplit + split) * 2;
+        slot[0] = a;
+        slot[1] = d;
     }
 }
 

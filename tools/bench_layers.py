@@ -40,11 +40,22 @@ CASES += [("s2 128->128 @256->128", 16, 256, 128, 128, "s2"), ("s2 256->256 @128
 # masked up-convs (region-select): exact fp32 (one pass per region present in a tile) vs polyphase split-bf16
 CASES += [("mup 512->512 ->64", 8, 32, 512, 512, "mup"), ("mup 512->256 ->128", 8, 64, 512, 256, "mup"),
           ("mup 256->128 ->256", 8, 128, 256, 128, "mup")]
+CASES += [("inapply 512@32", 16, 32, 512, 512, "inapply"), ("inapply 256@64", 16, 64, 256, 256, "inapply"),
+          ("inapply 128@128", 16, 128, 128, 128, "inapply")]
 only = sys.argv[1:]
 for tag, b, res, cin, cout, kind in CASES:
     if only and not any(o in tag for o in only):
         continue
     x = torch.randn(b, res, res, cin, device=dev)
+    if kind == "inapply":
+        st, _ = K.instnorm_stats(x)
+        gate = torch.rand(b, cin, device=dev)
+        res = torch.randn_like(x)
+        ms = timeit(lambda: K.instnorm_apply(x, st, gate=gate, res=res, want_stats=True), 20)
+        row = {"layer": tag, "apply_stats_ms": round(ms, 4), "tb_per_s": round(3 * x.numel() * 4 / ms / 1e9, 2)}
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+        continue
     if kind == "mup":
         from e4s_amd import synth
         R = 12
