@@ -42,11 +42,20 @@ CASES += [("mup 512->512 ->64", 8, 32, 512, 512, "mup"), ("mup 512->256 ->128", 
           ("mup 256->128 ->256", 8, 128, 256, 128, "mup")]
 CASES += [("inapply 512@32", 16, 32, 512, 512, "inapply"), ("inapply 256@64", 16, 64, 256, 256, "inapply"),
           ("inapply 128@128", 16, 128, 128, 128, "inapply")]
+CASES += [("stem 3->64@256", 16, 256, 32, 64, "stem")]
 only = sys.argv[1:]
 for tag, b, res, cin, cout, kind in CASES:
     if only and not any(o in tag for o in only):
         continue
     x = torch.randn(b, res, res, cin, device=dev)
+    if kind == "stem":
+        xs = torch.randn(b, res, res, 3, device=dev)
+        ws_ = torch.randn(cout, 3, 3, 3, device=dev)
+        ms = timeit(lambda: K.conv3x3_small(xs, ws_), 20)
+        row = {"layer": tag, "ms": round(ms, 4), "tflops": round(2 * 27 * cout * b * res * res / ms / 1e9, 1)}
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+        continue
     if kind == "inapply":
         st, _ = K.instnorm_stats(x)
         gate = torch.rand(b, cin, device=dev)
