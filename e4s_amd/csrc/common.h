@@ -47,4 +47,7 @@ static inline int e4s_ensure_dyn_smem(const void* fn, int bytes, std::atomic<uin
     return 0;
 }
 
+// conv_bf16x3.hip: second stage of a split-K conv launch (shared with conv_mfma.hip)
+int e4s_splitk_epilogue(const e4s_conv_params& p, int ksplit, hipStream_t st);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1183,6 +1183,20 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     return launch_xf<CfgS, false>(p, st);
 }
 
+// second stage of every split-K launch (also e4s_conv_mfma_f32's): slabs p.splitk_ws[k] (raw sums x demodulation) are added in
+// order, then noise / bias / activation
+int e4s_splitk_epilogue(const e4s_conv_params& p, int ksplit, hipStream_t st) {
+    if (!p.splitk_ws || ksplit < 2 || p.Cout % 4) return (int)hipErrorInvalidValue;
+    e4s_conv_params q = p;
+    q.out_scale = nullptr;
+    const int ycs = p.y_cstride ? p.y_cstride : p.Cout;
+    const int64_t n4 = (int64_t)p.B * p.Ho * p.Wo * (p.Cout / 4);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, q, ksplit, ycs,
+                       (int64_t)p.Ho * p.Wo, n4);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int64_t e4s_conv_bf16x3_ws_floats(const e4s_conv_params* pp) {
     const e4s_conv_params& p = *pp;
     if (p.istride != 1 || p.ntaps != 9 || p.Cin % KC) return 0;                  // gather kernels: no split-K

@@ -43,7 +43,7 @@ struct SmemLayout {
 
 template <int BM, int BN, int WM, int WN, bool SPATIAL, int PF>
 __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_params p, const int ntn,
-                                                            const int tiles_per_cls) {
+                                                            const int tiles_per_cls, const int ksplit, const int cper) {
     using L = SmemLayout<BM, BN, SPATIAL>;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int TH = L::TH, TW = L::TW, HALO_W = L::HALO_W, HALO = L::HALO;
@@ -164,7 +164,13 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
         unsigned ok;      // bit j: a[j] is a real (in-image) sample; applied when the registers are written to LDS, so
                           // that nothing consumes a load result before the stage that needs it
     };
-    const int ntaps = p.ntaps, nchunk = p.Cin / KC, nstage = nchunk * ntaps;
+    // split-K (ksplit > 1: launches whose tiles alone leave most CUs idle -- 14x14 / 7x7 maps, batch-1 low resolutions):
+    // blockIdx.y owns the input-channel chunks [c_lo, c_hi), stores its raw partial sums (x demodulation) into slab
+    // blockIdx.y of p.splitk_ws, and a second kernel adds the slabs in order and applies the epilogue
+    const int ntaps = p.ntaps, nchunk = p.Cin / KC;
+    const int ks = blockIdx.y;
+    const int c_lo = ks * cper, c_hi = (c_lo + cper < nchunk) ? c_lo + cper : nchunk;
+    const int nstage = (c_hi - c_lo) * ntaps, cbeg = c_lo * KC;
 
     auto fetch = [&](Pref& P, int tap, int c0) {
         const bool new_chunk = (tap == 0);
@@ -288,9 +294,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     Pref P0, P1;
     P0.s = P1.s = f32x4{1.f, 1.f, 1.f, 1.f};
     P0.ok = P1.ok = 0u;
-    int tap = 0, c0 = 0, t1 = 0, c1 = 0;
+    int tap = 0, c0 = cbeg, t1 = 0, c1 = cbeg;
     advance(t1, c1);
-    fetch(P0, 0, 0);
+    fetch(P0, 0, cbeg);
     store(P0, 0, true);
     if (PF == 2 && nstage > 1) fetch(P1, t1, c1);
     __syncthreads();
@@ -364,6 +370,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     const float nzw = nz_pc ? p.noise_w[0] : 0.f;
     const bool row_scale = SPATIAL && p.out_scale;
     const int ycs = p.y_cstride ? p.y_cstride : p.Cout;
+    const bool raw = ksplit > 1;
+    float* yo = raw ? p.splitk_ws + (size_t)ks * ((size_t)p.B * p.Ho * p.Wo * ycs) : p.y;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -376,14 +384,38 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int ncol = (wn * TN + tn) * 32 + li;
-                const float nzv = nz_pc ? nzw * p.noise[(size_t)__float_as_int(nz) * p.Cout + n0 + ncol] : nz;
                 const float sc = row_scale ? drow[ncol] : osc[tn];
-                float v = acc[tm][tn][r] * sc + nzv + bsv[tn];
-                if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
-                p.y[(size_t)off * ycs + n0 + ncol] = v;
+                float v = acc[tm][tn][r] * sc;
+                if (!raw) {
+                    const float nzv = nz_pc ? nzw * p.noise[(size_t)__float_as_int(nz) * p.Cout + n0 + ncol] : nz;
+                    v += nzv + bsv[tn];
+                    if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
+                }
+                yo[(size_t)off * ycs + n0 + ncol] = v;
             }
         }
     }
+}
+
+// Split-K policy of the fp32 kernel.  It depends on the geometry of ONE sample only (never on the batch), so that a sample's
+// result does not depend on what it is batched with: split when a sample yields <= 32 blocks, towards ~128 blocks per sample,
+// every split keeping >= 2 input-channel chunks.
+inline void f32_split(const e4s_conv_params& p, int64_t blocks_per_sample, int& ksplit, int& cper) {
+    const int nchunk = p.Cin / KC;
+    ksplit = 1;
+    cper = nchunk;
+    if (blocks_per_sample > 32 || blocks_per_sample < 1 || nchunk < 4 || p.noise_per_channel || !p.splitk_ws) return;
+    int want = (int)((128 + blocks_per_sample - 1) / blocks_per_sample);
+    if (want > nchunk / 2) want = nchunk / 2;
+    if (want < 2) return;
+    cper = (nchunk + want - 1) / want;
+    ksplit = (nchunk + cper - 1) / cper;
+}
+
+template <int BM, bool SPATIAL>
+int64_t tiles_per_sample(const e4s_conv_params& p) {
+    if (SPATIAL) return (int64_t)((p.Ha + 7) / 8) * ((p.Wa + BM / 8 - 1) / (BM / 8)) * p.ncls;
+    return (((int64_t)p.Ha * p.Wa + BM - 1) / BM + (p.tiles ? 1 : 0)) * p.ncls;
 }
 
 template <int BM, int BN, int WM, int WN, bool SPATIAL, int PF = 1>
@@ -405,8 +437,11 @@ int launch(const e4s_conv_params& p, hipStream_t st) {
         mtiles = tiles_per_cls * p.ncls;
     }
     if (mtiles <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(mtiles * ntn), dim3(NTHR), L::BYTES, st, p, ntn, tiles_per_cls);
+    int ksplit, cper;
+    f32_split(p, tiles_per_sample<BM, SPATIAL>(p) * ntn, ksplit, cper);
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntn, ksplit), dim3(NTHR), L::BYTES, st, p, ntn, tiles_per_cls, ksplit, cper);
     E4S_CHECK_LAUNCH();
+    if (ksplit > 1) return e4s_splitk_epilogue(p, ksplit, st);     // slabs already carry the demodulation
     return 0;
 }
 
@@ -423,6 +458,25 @@ int pick_bn(const e4s_conv_params& p, int64_t mtiles) {
 }
 
 }  // namespace
+
+// the tile the dispatch below picks for a launch with few blocks per sample (the only launches that split)
+extern "C" int64_t e4s_conv_mfma_ws_floats(const e4s_conv_params* pp, int spatial) {
+    e4s_conv_params p = *pp;
+    if (p.Cin % KC || p.Cout % 32) return 0;
+    float dummy;
+    p.splitk_ws = &dummy;                                        // "the caller will provide one"
+    const int64_t per = spatial ? tiles_per_sample<128, true>(p) : tiles_per_sample<128, false>(p);
+    int best = 1;
+    const int bns[3] = {128, 64, 32};
+    for (int i = 0; i < 3; ++i) {                               // upper bound over the column tiles the dispatch may pick
+        if (p.Cout % bns[i]) continue;
+        int ksplit, cper;
+        f32_split(p, per * (p.Cout / bns[i]), ksplit, cper);
+        if (ksplit > best) best = ksplit;
+    }
+    if (best <= 1) return 0;
+    return (int64_t)best * p.B * p.Ho * p.Wo * (p.y_cstride ? p.y_cstride : p.Cout);
+}
 
 extern "C" int e4s_conv_mfma_f32(const e4s_conv_params* pp, int spatial, void* stream) {
     const e4s_conv_params& p = *pp;

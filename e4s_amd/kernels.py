@@ -307,6 +307,9 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     elif in_stats is not None:
         raise RuntimeError("fused InstanceNorm staging exists only in e4s_conv_bf16x3_f32")
     else:
+        nws = lib.load().e4s_conv_mfma_ws_floats(ctypes.byref(p), 1 if spatial else 0)     # split-K slabs (few-block launches)
+        skws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
+        p.splitk_ws = fptr(skws)
         call("e4s_conv_mfma_f32", ctypes.byref(p), 1 if spatial else 0, stream())
     if want_stats:
         return y, instnorm_stats(y, want_pooled=True)

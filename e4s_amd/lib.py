@@ -73,6 +73,7 @@ SIGNATURES = {
     "e4s_upconv_mfma_f32": [ctypes.POINTER(ConvParams), c_p, c_p],
     "e4s_conv_bf16x3_f32": [ctypes.POINTER(ConvParams), c_p],
     "e4s_conv_bf16x3_ws_floats": [ctypes.POINTER(ConvParams)],
+    "e4s_conv_mfma_ws_floats": [ctypes.POINTER(ConvParams), c_i],
     "e4s_split_bf16x2_f32": [c_p, c_p, c_l, c_i, c_p],
     "e4s_upconv_blocks_per_cu": [],
     "e4s_instnorm_ws_doubles": [c_i, c_i, c_i],
@@ -145,7 +146,7 @@ SIGNATURES = {
     "e4s_cosine_bwd_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_l, c_i, c_p],
 }
 
-INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats", "e4s_lpips_layer_ws_doubles",
+INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats", "e4s_lpips_layer_ws_doubles", "e4s_conv_mfma_ws_floats",
                 "e4s_cosine_ws_doubles"}       # size queries: return a count, not an error code
 
 _lib = None

@@ -129,7 +129,7 @@ typedef struct {
     int y_cstride;           /* channels per pixel of the buffer y points into (0 = Cout): the conv may write the first Cout
                                 channels of a wider NHWC tensor -- GPEN's StyledConv concatenates its noise (the encoder
                                 feature map) behind the conv output (gpen_model.py:343-353).  Plain (unlabelled) kernels */
-    float* splitk_ws;        /* e4s_conv_bf16x3_f32, unlabelled 3x3: scratch of e4s_conv_bf16x3_ws_floats(p) floats (0 -> may be
+    float* splitk_ws;        /* scratch of e4s_conv_bf16x3_ws_floats(p) / e4s_conv_mfma_ws_floats(p, spatial) floats (0 -> may be
                                 NULL): launches with too few tiles to fill the chip (batch-1 latency runs) split the input
                                 channels over several blocks per tile; the raw partial sums land here and are added in a
                                 fixed order by a second kernel that also applies the epilogue */
@@ -151,6 +151,11 @@ typedef struct {
  * Requirements: Cin % 32 == 0, Cout % 32 == 0.  `spatial` selects the halo-tiled loader
  * (natural order, istride == 1, Ha % 8 == 0, Wa % 16 == 0). */
 int e4s_conv_mfma_f32(const e4s_conv_params* p, int spatial, void* stream);
+/* floats of p->splitk_ws this launch may use (0: none).  When a SAMPLE yields <= 32 blocks (14x14 / 7x7 maps, the 4^2-16^2
+ * generator layers) the input-channel chunks are split over blockIdx.y; partial sums are added in a fixed order by the
+ * second stage that applies the epilogue.  The policy looks at one sample's geometry only, so results do not depend on the
+ * batch.  With splitk_ws == NULL the launch never splits. */
+int64_t e4s_conv_mfma_ws_floats(const e4s_conv_params* p, int spatial);
 
 /* Exact up-sampling StyledConv: conv_transpose2d(stride 2) + 4x4 blur (model.py:287-300) with the transposed conv's
  * minimal 9*Cin*Cout MACs per input pixel on the matrix cores and the blur applied from an LDS-resident intermediate

@@ -4,6 +4,7 @@ max-abs on the 1024^2 outputs.  With E4S_PRECISION=f32 (pinned by a fixture for 
 otherwise) the kernels compute in exact fp32 (v_mfma_f32_32x32x2_f32), so the op/layer tests use much tighter
 bounds (written next to each assert); the split-bf16 kernels (E4S_PRECISION=bf16x3/auto) have their own tests
 against 1e-4 of the output scale per layer and the 1e-3 bound end to end."""
+import ctypes
 import math
 
 import pytest
@@ -972,3 +973,29 @@ def test_fused_output_statistics_equal_the_separate_pass(b, h, w, cin, cout, str
     out, st_out = K.instnorm_apply(y, st_ref, gate=gate, res=res, slope=slope, want_stats=True)
     assert torch.equal(out, K.instnorm_apply(y, st_ref, gate=gate, res=res, slope=slope))
     assert maxabs(st_out, K.instnorm_stats(out)[0]) < 2e-6 * float(st_out.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride", [(256, 256, 14, 14, 1), (512, 512, 7, 7, 1), (512, 512, 14, 14, 2), (128, 128, 28, 28, 1),
+                                                 (512, 64, 8, 8, 1)])
+def test_f32_conv_split_k_small_maps(cin, cout, h, w, stride):
+    """e4s_conv_mfma_f32 on maps that yield <= 32 blocks per sample (IR-SE50's 14x14 / 7x7 layers, the generator's 4^2-16^2
+    layers): the input channels are split over blockIdx.y and added in order -- same values as the fp64 reference, and a
+    sample's result does not depend on the batch it is computed in (the split policy never looks at the batch)."""
+    from e4s_amd import kernels as K
+    from e4s_amd import lib
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(3, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn(cout, generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), bias.double(), stride=stride, padding=1), 0.2) * (2 ** 0.5)
+    wp = K.pack_taps(wt.to(DEV))
+    xd = K.nchw_to_nhwc(x.to(DEV))
+    kw = dict(bias=bias.to(DEV), act=1) if stride == 1 else dict(bias=bias.to(DEV), act=1, istride=2, ntaps=9)
+    y3 = K.conv_mfma(xd, wp, cout, **kw)
+    assert maxabs(K.nhwc_to_nchw(y3), ref) < 5e-5
+    y1 = K.conv_mfma(xd[1:2].contiguous(), wp, cout, **kw)
+    assert torch.equal(y1[0], y3[1])
+    # the launch really split (otherwise this test pins nothing)
+    p = lib.ConvParams()
+    p.B, p.Ha, p.Wa, p.Ho, p.Wo, p.Cin, p.Cout, p.ncls, p.ntaps = 3, h // stride, w // stride, h // stride, w // stride, cin, cout, 1, 9
+    assert lib.load().e4s_conv_mfma_ws_floats(ctypes.byref(p), 1 if stride == 1 else 0) > 0
