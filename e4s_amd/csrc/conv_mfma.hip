@@ -397,17 +397,17 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     }
 }
 
-// Split-K policy of the fp32 kernel.  It depends on the geometry of ONE sample only (never on the batch), so that a sample's
-// result does not depend on what it is batched with: split when a sample yields <= 32 blocks, towards ~128 blocks per sample,
-// every split keeping >= 2 input-channel chunks.
-inline void f32_split(const e4s_conv_params& p, int64_t blocks_per_sample, int& ksplit, int& cper) {
+// Split-K policy of the fp32 kernel.  It depends on ONE sample's pixel tiles and the channel count only -- never on the batch
+// or on the column tile the dispatch picks (which follows the batch) -- so a sample's result does not depend on what it is
+// batched with: maps of <= 2 pixel tiles (<= 16x16: IR-SE50's 14x14 / 7x7 layers, the generator's 4^2-16^2 layers) split
+// their input-channel chunks up to 8 ways, every split keeping >= 2 chunks.
+inline void f32_split(const e4s_conv_params& p, int64_t tiles_per_sample, int& ksplit, int& cper) {
     const int nchunk = p.Cin / KC;
     ksplit = 1;
     cper = nchunk;
-    if (blocks_per_sample > 32 || blocks_per_sample < 1 || nchunk < 4 || p.noise_per_channel || !p.splitk_ws) return;
-    int want = (int)((128 + blocks_per_sample - 1) / blocks_per_sample);
-    if (want > nchunk / 2) want = nchunk / 2;
-    if (want < 2) return;
+    if (tiles_per_sample > 2 || tiles_per_sample < 1 || nchunk < 4 || p.noise_per_channel || !p.splitk_ws) return;
+    int want = nchunk / 2;
+    if (want > 8) want = 8;
     cper = (nchunk + want - 1) / want;
     ksplit = (nchunk + cper - 1) / cper;
 }
@@ -438,7 +438,7 @@ int launch(const e4s_conv_params& p, hipStream_t st) {
     }
     if (mtiles <= 0) return 0;
     int ksplit, cper;
-    f32_split(p, tiles_per_sample<BM, SPATIAL>(p) * ntn, ksplit, cper);
+    f32_split(p, tiles_per_sample<BM, SPATIAL>(p) / p.ncls, ksplit, cper);
     hipLaunchKernelGGL(kern, dim3(mtiles * ntn, ksplit), dim3(NTHR), L::BYTES, st, p, ntn, tiles_per_cls, ksplit, cper);
     E4S_CHECK_LAUNCH();
     if (ksplit > 1) return e4s_splitk_epilogue(p, ksplit, st);     // slabs already carry the demodulation
@@ -465,15 +465,9 @@ extern "C" int64_t e4s_conv_mfma_ws_floats(const e4s_conv_params* pp, int spatia
     if (p.Cin % KC || p.Cout % 32) return 0;
     float dummy;
     p.splitk_ws = &dummy;                                        // "the caller will provide one"
-    const int64_t per = spatial ? tiles_per_sample<128, true>(p) : tiles_per_sample<128, false>(p);
-    int best = 1;
-    const int bns[3] = {128, 64, 32};
-    for (int i = 0; i < 3; ++i) {                               // upper bound over the column tiles the dispatch may pick
-        if (p.Cout % bns[i]) continue;
-        int ksplit, cper;
-        f32_split(p, per * (p.Cout / bns[i]), ksplit, cper);
-        if (ksplit > best) best = ksplit;
-    }
+    const int64_t per = (spatial ? tiles_per_sample<128, true>(p) : tiles_per_sample<128, false>(p)) / p.ncls;
+    int best, cper;
+    f32_split(p, per, best, cper);
     if (best <= 1) return 0;
     return (int64_t)best * p.B * p.Ho * p.Wo * (p.y_cstride ? p.y_cstride : p.Cout);
 }

@@ -151,10 +151,10 @@ typedef struct {
  * Requirements: Cin % 32 == 0, Cout % 32 == 0.  `spatial` selects the halo-tiled loader
  * (natural order, istride == 1, Ha % 8 == 0, Wa % 16 == 0). */
 int e4s_conv_mfma_f32(const e4s_conv_params* p, int spatial, void* stream);
-/* floats of p->splitk_ws this launch may use (0: none).  When a SAMPLE yields <= 32 blocks (14x14 / 7x7 maps, the 4^2-16^2
- * generator layers) the input-channel chunks are split over blockIdx.y; partial sums are added in a fixed order by the
- * second stage that applies the epilogue.  The policy looks at one sample's geometry only, so results do not depend on the
- * batch.  With splitk_ws == NULL the launch never splits. */
+/* floats of p->splitk_ws this launch may use (0: none).  Maps of <= 2 pixel tiles per sample (<= 16x16: 14x14 / 7x7 layers,
+ * the 4^2-16^2 generator layers) split their input-channel chunks up to 8 ways over blockIdx.y; partial sums are added in a
+ * fixed order by the second stage that applies the epilogue.  The policy looks at one sample's geometry only, so results do
+ * not depend on the batch.  With splitk_ws == NULL the launch never splits. */
 int64_t e4s_conv_mfma_ws_floats(const e4s_conv_params* p, int spatial);
 
 /* Exact up-sampling StyledConv: conv_transpose2d(stride 2) + 4x4 blur (model.py:287-300) with the transposed conv's

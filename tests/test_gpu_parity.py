@@ -975,10 +975,10 @@ def test_fused_output_statistics_equal_the_separate_pass(b, h, w, cin, cout, str
     assert maxabs(st_out, K.instnorm_stats(out)[0]) < 2e-6 * float(st_out.abs().max())
 
 
-@pytest.mark.parametrize("cin,cout,h,w,stride", [(256, 256, 14, 14, 1), (512, 512, 7, 7, 1), (512, 512, 14, 14, 2), (128, 128, 28, 28, 1),
+@pytest.mark.parametrize("cin,cout,h,w,stride", [(256, 256, 14, 14, 1), (512, 512, 7, 7, 1), (512, 512, 14, 14, 2), (128, 128, 16, 16, 1),
                                                  (512, 64, 8, 8, 1)])
 def test_f32_conv_split_k_small_maps(cin, cout, h, w, stride):
-    """e4s_conv_mfma_f32 on maps that yield <= 32 blocks per sample (IR-SE50's 14x14 / 7x7 layers, the generator's 4^2-16^2
+    """e4s_conv_mfma_f32 on maps of <= 2 pixel tiles per sample (IR-SE50's 14x14 / 7x7 layers, the generator's 4^2-16^2
     layers): the input channels are split over blockIdx.y and added in order -- same values as the fp64 reference, and a
     sample's result does not depend on the batch it is computed in (the split policy never looks at the batch)."""
     from e4s_amd import kernels as K
