@@ -116,8 +116,8 @@ def headline_probe(net, batch, mask, reps):
 def optimisation_leg(net, one, steps, losses="full", graphed=False):
     """BASELINE.json configs[2] (scripts/optimization.py:209-232): Adam(lr=1e-2) on the [1,12,1280] regional style
     vectors through cal_style_codes -> gen_img (fresh noise every step, as the script does).  losses = "full": the
-    script's default objective without the parsing term -- l2 * 1.0 + LPIPS-AlexNet at 1024/512/256 * 0.8 + IR-SE50 identity
-    * 0.1 (optim_options.py:44-48, optimization.py:88-122) on the native loss networks (e4s_amd.criteria, synthetic
+    script's default objective -- l2 * 1.0 + LPIPS-AlexNet at 1024/512/256 * 0.8 + IR-SE50 identity * 0.1 + parsing-UNet
+    features * 0.1 (optim_options.py:44-48, optimization.py:88-122) on the native loss networks (e4s_amd.criteria, synthetic
     weights: the real ones are downloads); "mse": the l2 term alone.  graphed: the whole step (forward, losses, backward, Adam with
     its step count on the device) replayed as one HIP graph (e4s_amd.optim.GraphedStep)."""
     import types
@@ -129,21 +129,24 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
     latent = sv.clone().requires_grad_(True)
     from e4s_amd.optim import FusedAdam
     opt = FusedAdam([latent], lr=1e-2, capturable=graphed)      # torch.optim.Adam's update as one kernel
-    lpips = idl = None
+    lpips = idl = fpl = None
     if losses == "full":
-        from e4s_amd.criteria import IDLoss, LPIPS
+        from e4s_amd.criteria import FaceParsingLoss, IDLoss, LPIPS
         lpips = LPIPS()
         lpips.load_state_dict(synth.synth_module_state_dict(lpips, 0, "lp."))
         idl = IDLoss(types.SimpleNamespace(id_loss_multiscale=True))
         idl.load_state_dict(synth.synth_module_state_dict(idl, 0, "id."))
-        lpips, idl = lpips.to(target.device).eval(), idl.to(target.device).eval()
+        fpl = FaceParsingLoss(types.SimpleNamespace())
+        fpl.load_state_dict(synth.synth_module_state_dict(fpl, 0, "fp."))
+        lpips, idl, fpl = lpips.to(target.device).eval(), idl.to(target.device).eval(), fpl.to(target.device).eval()
 
     def body():
         codes = net.cal_style_codes(latent)
         img, _, _ = net.gen_img(None, codes, tm, randomize_noise=True)
         loss = torch.nn.functional.mse_loss(img, target)
         if lpips is not None:
-            loss = loss + 0.8 * lpips.forward_pooled(img, target, (1024, 512, 256)) + 0.1 * idl(img, target)[0]
+            loss = loss + 0.8 * lpips.forward_pooled(img, target, (1024, 512, 256)) + 0.1 * idl(img, target)[0] \
+                + 0.1 * fpl(img, target)[0]
         loss.backward()
         opt.step()
         return loss.detach()
@@ -267,7 +270,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue the ~700 launches per step eagerly instead of "
                                                             "replaying one captured HIP graph")
     ap.add_argument("--opt-modes", default="full,mse",
-                    help="config-3 legs to run: full = l2 + LPIPS x3 + ID, mse = l2 only")
+                    help="config-3 legs to run: full = l2 + LPIPS x3 + ID + parsing, mse = l2 only")
     ap.add_argument("--opt-graph", action="store_true",
                     help="replay each config-3 step as one HIP graph (e4s_amd.optim.GraphedStep); measured 11.6 vs 11.9 ms on the "
                          "l2-only step -- the loop is bound by the duration of its many small kernels, not by launch overhead")

@@ -1,8 +1,9 @@
 """Loss networks of the optimisation loop -- MI355X-native.
 
 `IDLoss` (src/criteria/id_loss.py:6-57 over the IR-SE50 `Backbone`, src/models/encoders/model_irse.py:10-69,
-helpers.py:97-119) and `LPIPS` (src/criteria/lpips/lpips.py:8-35 over torchvision's AlexNet `features`,
-src/criteria/lpips/networks.py:28-83) as scripts/optimization.py:88-122 calls them: frozen networks whose only gradient is
+helpers.py:97-119), `LPIPS` (src/criteria/lpips/lpips.py:8-35 over torchvision's AlexNet `features`,
+src/criteria/lpips/networks.py:28-83) and `FaceParsingLoss` (src/criteria/face_parsing/face_parsing_loss.py:20-78 over the
+encoder half of the parsing `unet`, unet.py:6-92) as scripts/optimization.py:88-122 calls them: frozen networks whose only gradient is
 the one back to the generated image.  Module trees / state_dict keys equal the reference's, so its checkpoints load
 unchanged; execution is a fixed schedule of HIP kernels on NHWC tensors with a tape:
 
@@ -16,8 +17,10 @@ unchanged; execution is a fixed schedule of HIP kernels on NHWC tensors with a t
     Linear(25088, 512) + BN1d       one e4s_grouped_linear_f32 with both BatchNorms folded into the packed weight
     cosine / LPIPS distance         e4s_cosine_f32, e4s_lpips_layer_f32 (+ backward)
 
+    parsing UNet encoder            conv + BatchNorm(eval) folded into ONE conv with bias + ReLU epilogue (16-channel maps
+                                    zero-padded to the 32-channel K step), e4s_maxpool2_f32, e4s_relu_bwd_f32
+
 The target image's features are cached per target tensor (the reference recomputes them every step, id_loss.py:33-35).
-Face-parsing loss (src/criteria/face_parsing/face_parsing_loss.py) is not built.
 """
 import os
 
@@ -491,3 +494,201 @@ class LPIPS(Module):
 
     def forward(self, x, y):
         return self.forward_pooled(x, y, (x.shape[2],))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Face-parsing loss (UNet encoder features)
+# ---------------------------------------------------------------------------------------------------------------
+class unetConv2(Module):
+    """src/criteria/face_parsing/model_utils.py:177-203 (is_batchnorm=True)"""
+
+    def __init__(self, in_size, out_size, is_batchnorm=True):
+        super().__init__()
+        assert is_batchnorm
+        self.conv1 = Sequential(Conv2d(in_size, out_size, 3, 1, 1), BatchNorm2d(out_size), ReLU())
+        self.conv2 = Sequential(Conv2d(out_size, out_size, 3, 1, 1), BatchNorm2d(out_size), ReLU())
+
+    def forward(self, x):
+        return self.conv2(self.conv1(x))
+
+
+class unetUp(Module):
+    """model_utils.py:206-221 (is_deconv=True): decoder half, a parameter holder with the torch forward -- the loss never runs
+    it (face_parsing_loss.py:47-50 uses extract_feats only)."""
+
+    def __init__(self, in_size, out_size, is_deconv=True, is_batchnorm=True):
+        super().__init__()
+        self.conv = unetConv2(in_size, out_size, is_batchnorm)
+        self.up = nn.ConvTranspose2d(in_size, out_size, kernel_size=2, stride=2)
+
+    def forward(self, inputs1, inputs2):
+        outputs2 = self.up(inputs2)
+        offset = outputs2.size()[2] - inputs1.size()[2]
+        return self.conv(torch.cat([nn.functional.pad(inputs1, 2 * [offset // 2, offset // 2]), outputs2], 1))
+
+
+def _folded(seq, cin_pad, cout_pad):
+    """Conv2d -> BatchNorm2d(eval) of a unetConv2 stage as ONE conv: W' = W * s[co], b' = (b - m) * s + beta, zero-padded to
+    (cout_pad, cin_pad) channels (16-channel maps ride the 32-channel K step; the padded channels stay exactly 0 through
+    bias-free ReLU, so cosines over the padded maps equal those over the real ones).  Returns a `_Taps` holder with .bias."""
+    conv, bn = seq[0], seq[1]
+    key = (param_key(conv.weight), param_key(bn.weight), bn.running_var._version, cin_pad, cout_pad)
+    if getattr(seq, "_e4s_fold", None) is None or seq._e4s_fold[0] != key:
+        with torch.no_grad():
+            s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            w = conv.weight.float() * s[:, None, None, None]
+            b = (conv.bias.float() - bn.running_mean.float()) * s + bn.bias.float()
+            cout, cin = w.shape[:2]
+            w = nn.functional.pad(w, (0, 0, 0, 0, 0, cin_pad - cin, 0, cout_pad - cout)).contiguous()
+            t = _Taps(w)
+            t.bias = nn.functional.pad(b, (0, cout_pad - cout)).contiguous()
+            seq._e4s_fold = (key, t)
+    return seq._e4s_fold[1]
+
+
+class unet(Module):
+    """src/criteria/face_parsing/unet.py:6-92 (feature_scale 4, 19 classes, deconv, batchnorm)."""
+
+    def __init__(self, feature_scale=4, n_classes=19, is_deconv=True, in_channels=3, is_batchnorm=True):
+        super().__init__()
+        assert is_deconv and is_batchnorm and in_channels == 3
+        f = [int(x / feature_scale) for x in (64, 128, 256, 512, 1024)]
+        self.filters = f
+        self.conv1, self.maxpool1 = unetConv2(in_channels, f[0]), MaxPool2d(kernel_size=2)
+        self.conv2, self.maxpool2 = unetConv2(f[0], f[1]), MaxPool2d(kernel_size=2)
+        self.conv3, self.maxpool3 = unetConv2(f[1], f[2]), MaxPool2d(kernel_size=2)
+        self.conv4, self.maxpool4 = unetConv2(f[2], f[3]), MaxPool2d(kernel_size=2)
+        self.center = unetConv2(f[3], f[4])
+        self.up_concat4, self.up_concat3 = unetUp(f[4], f[3]), unetUp(f[3], f[2])
+        self.up_concat2, self.up_concat1 = unetUp(f[2], f[1]), unetUp(f[1], f[0])
+        self.final = Conv2d(f[0], n_classes, 1)
+
+    def forward(self, inputs):
+        """label logits (unet.py:47-66): the module tree's torch forward -- inference is off the optimisation path."""
+        c1 = self.conv1(inputs)
+        c2 = self.conv2(self.maxpool1(c1))
+        c3 = self.conv3(self.maxpool2(c2))
+        c4 = self.conv4(self.maxpool3(c3))
+        center = self.center(self.maxpool4(c4))
+        up = self.up_concat4(c4, center)
+        up = self.up_concat3(c3, up)
+        up = self.up_concat2(c2, up)
+        return self.final(self.up_concat1(c1, up))
+
+    def _stages(self):
+        pad = lambda c: (c + 31) // 32 * 32
+        f = self.filters
+        blocks = [self.conv1, self.conv2, self.conv3, self.conv4, self.center]
+        cins = [3] + [pad(c) for c in f[:4]]
+        return [(blk, cins[i], pad(f[i])) for i, blk in enumerate(blocks)]
+
+    def features_nhwc(self, x512, tape=None):
+        """x512 NHWC [B,512,512,3] -> the five encoder maps (unet.py:69-91), NHWC, channels zero-padded to 32."""
+        feats = []
+        x = x512
+        for i, (blk, cin, cout) in enumerate(self._stages()):
+            t1, t2 = _folded(blk.conv1, cin, cout), _folded(blk.conv2, cout, cout)
+            if i == 0:
+                a = K.conv_smallcin(x, _smallcin_pack(t1), t1.bias, cout, 3, 1, 1, relu=True)
+            else:
+                a = _conv3x3(x, t1, cout, bias=t1.bias, act=1, alpha=0.0, gain=1.0)
+            f = _conv3x3(a, t2, cout, bias=t2.bias, act=1, alpha=0.0, gain=1.0)
+            feats.append(f)
+            rec = dict(a=a, f=f, x_shape=tuple(x.shape))
+            if i < 4:
+                x, rec["idx"] = K.maxpool2(f)
+            if tape is not None:
+                tape.append(rec)
+        return feats
+
+    def backward_nhwc(self, tape, dfeats):
+        """dfeats[k] = dL/d(feats[k]) -> dL/d(x512) NHWC."""
+        stages = self._stages()
+        d = None
+        for i in reversed(range(5)):
+            blk, cin, cout = stages[i]
+            rec = tape[i]
+            g = dfeats[i] if d is None else K.add_scale(d, dfeats[i], 1.0)
+            t1, t2 = _folded(blk.conv1, cin, cout), _folded(blk.conv2, cout, cout)
+            da = _conv3x3(K.relu_bwd(g, rec["f"]), _transposed(t2), cout)
+            du = K.relu_bwd(da, rec["a"])
+            if i == 0:
+                return K.conv_smallcin_bwd(du, _smallcin_pack(t1), rec["x_shape"], 3, 1, 1)
+            dp = _conv3x3(du, _transposed(t1), cin)
+            d = K.maxpool2_bwd(dp, tape[i - 1]["idx"], tuple(tape[i - 1]["f"].shape))
+
+    def extract_feats(self, inputs):
+        """unet.py:69-91: l2-normalised rows of the five encoder maps (NCHW flatten order), no gradient."""
+        with torch.no_grad():
+            feats = self.features_nhwc(K.nchw_to_nhwc(inputs))
+            rows = [K.nhwc_to_nchw(f)[:, :c].reshape(f.shape[0], -1) for f, c in zip(feats, self.filters)]
+            return [r / torch.norm(r, 2, 1, True) for r in rows]
+
+
+class _ParsingLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_hat, mod, y_feats):
+        tape = []
+        x512 = mod._prep(y_hat)
+        feats = mod.G.features_nhwc(x512, tape)
+        coefs = [K.cosine(f, t) for f, t in zip(feats, y_feats)]
+        sims = torch.stack([c[:, 0] for c in coefs])
+        ctx.mod, ctx.tape, ctx.feats, ctx.y_feats, ctx.coefs, ctx.n = mod, tape, feats, y_feats, coefs, y_hat.shape[0]
+        ctx.in_shape = tuple(y_hat.shape)
+        ctx.mark_non_differentiable(sims)
+        return (1.0 - sims).mean(1).sum(), sims
+
+    @staticmethod
+    def backward(ctx, gloss, _gsims):
+        mod = ctx.mod
+        g = gloss.reshape(1).to(torch.float32).contiguous()
+        dfeats = [K.cosine_bwd(f, t, c, g, -1.0 / ctx.n) for f, t, c in zip(ctx.feats, ctx.y_feats, ctx.coefs)]
+        dx512 = mod.G.backward_nhwc(ctx.tape, dfeats)
+        ctx.tape = None
+        return K.adaptive_pool_bwd(dx512, ctx.in_shape), None, None
+
+
+class FaceParsingLoss(Module):
+    """src/criteria/face_parsing/face_parsing_loss.py:20-78: cosine distance between the parsing UNet's five encoder maps of
+    y_hat and y (pooled to 512^2).  `opts.face_parsing_model_path` is loaded when it names an existing file."""
+
+    def __init__(self, opts):
+        super().__init__()
+        self.opts = opts
+        self.face_pool = torch.nn.AdaptiveAvgPool2d((512, 512))
+        self.G = unet()
+        path = getattr(opts, "face_parsing_model_path", None)
+        if path and os.path.exists(path):
+            self.G.load_state_dict(torch.load(path, map_location="cpu"))
+        self.G.eval()
+        self.set_requires_grad(False)
+        self._target = None
+
+    def set_requires_grad(self, flag=True):
+        for p in self.parameters():
+            p.requires_grad = flag
+
+    def _prep(self, x):
+        return K.adaptive_pool(x.detach(), (512, 512))          # NCHW -> NHWC [B,512,512,3] (identity bins at 512^2)
+
+    def extract_feats(self, x):
+        with torch.no_grad():
+            feats = self.G.features_nhwc(self._prep(x))
+            rows = [K.nhwc_to_nchw(f)[:, :c].reshape(f.shape[0], -1) for f, c in zip(feats, self.G.filters)]
+            return [r / torch.norm(r, 2, 1, True) for r in rows]
+
+    def inference(self, x):
+        raise NotImplementedError("label-map inference (face_parsing_loss.py:37-45: numpy / colour-map post-processing) is "
+                                  "off the optimisation path; call self.G(x) for the logits")
+
+    def _target_feats(self, y):
+        key = (y.data_ptr(), y._version, tuple(y.shape))
+        if self._target is None or self._target[0] != key:
+            with torch.no_grad():
+                self._target = (key, self.G.features_nhwc(self._prep(y)))
+        return self._target[1]
+
+    def forward(self, y_hat, y):
+        """-> (loss, sim_improvement) as the reference; sim_improvement is a 0-dim tensor."""
+        loss, sims = _ParsingLossFn.apply(y_hat, self, self._target_feats(y))
+        return loss, (sims - 1.0).mean(1).sum()

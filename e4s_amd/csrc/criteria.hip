@@ -223,6 +223,68 @@ __global__ void maxpool3s2_bwd_kernel(const float* __restrict__ dy, const unsign
     *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
 }
 
+// ---- MaxPool2d(2) (parsing UNet encoder, src/criteria/face_parsing/unet.py:27-36) ------------------------------------
+__global__ void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, int Hi,
+                                int Wi, int Ho, int Wo, int C, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int C4 = C / 4;
+    const int c = (int)(i % C4) * 4;
+    const int ox = (int)((i / C4) % Wo), oy = (int)((i / ((int64_t)C4 * Wo)) % Ho);
+    const int64_t b = i / ((int64_t)C4 * Wo * Ho);
+    f32x4 m;
+    unsigned char am[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((b * Hi + oy * 2 + (k >> 1)) * Wi + ox * 2 + (k & 1)) * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k == 0 || v[e] > m[e]) {                  // first maximum in scan order
+                m[e] = v[e];
+                am[e] = (unsigned char)k;
+            }
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = m;
+    *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4(am[0], am[1], am[2], am[3]);
+}
+
+// windows do not overlap: each input element belongs to exactly one (or, on an odd trailing row / column, to none)
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx,
+                                    int Hi, int Wi, int Ho, int Wo, int C, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int C4 = C / 4;
+    const int c = (int)(i % C4) * 4;
+    const int x = (int)((i / C4) % Wi), y = (int)((i / ((int64_t)C4 * Wi)) % Hi);
+    const int64_t b = i / ((int64_t)C4 * Wi * Hi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int oy = y >> 1, ox = x >> 1;
+    if (oy < Ho && ox < Wo) {
+        const int64_t o = ((b * Ho + oy) * Wo + ox) * C + c;
+        const uchar4 a = *reinterpret_cast<const uchar4*>(idx + o);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        const unsigned char me = (unsigned char)((y & 1) * 2 + (x & 1));
+        if (a.x == me) acc[0] = g[0];
+        if (a.y == me) acc[1] = g[1];
+        if (a.z == me) acc[2] = g[2];
+        if (a.w == me) acc[3] = g[3];
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+}
+
+// dx (+)= dy * [y > 0]   (ReLU backward from the OUTPUT; any channel count % 4)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                int accumulate, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4), v = *reinterpret_cast<const f32x4*>(y + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? g[e] : 0.f;
+    if (accumulate) o += *reinterpret_cast<const f32x4*>(dx + i * 4);
+    *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+}
+
 // ---- LPIPS distance layer (lpips.py:32-33, utils.py normalize_activation) ---------------------------------------------
 // d(pixel) = sum_c w_c (fx_c/(|fx|+eps) - fy_c/(|fy|+eps))^2; one wave per pixel, <= 8 channels per lane (C <= 512).
 constexpr int LP_MAXPL = 8;
@@ -485,6 +547,33 @@ extern "C" int e4s_maxpool3s2_bwd_f32(const float* dy, const unsigned char* idx,
     const int Ho = (Hi - 3) / 2 + 1, Wo = (Wi - 3) / 2 + 1;
     const int64_t n4 = (int64_t)B * Hi * Wi * (C / 4);
     hipLaunchKernelGGL(maxpool3s2_bwd_kernel, grid1(n4), dim3(256), 0, as_stream(stream), dy, idx, dx, Hi, Wi, Ho, Wo, C, n4);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_maxpool2_f32(const float* x, float* y, unsigned char* idx, int B, int Hi, int Wi, int C, void* stream) {
+    if (C % 4 || Hi < 2 || Wi < 2) return (int)hipErrorInvalidValue;
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    const int64_t n4 = (int64_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool2_kernel, grid1(n4), dim3(256), 0, as_stream(stream), x, y, idx, Hi, Wi, Ho, Wo, C, n4);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_maxpool2_bwd_f32(const float* dy, const unsigned char* idx, float* dx, int B, int Hi, int Wi, int C,
+                                    void* stream) {
+    if (C % 4 || Hi < 2 || Wi < 2) return (int)hipErrorInvalidValue;
+    const int64_t n4 = (int64_t)B * Hi * Wi * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, grid1(n4), dim3(256), 0, as_stream(stream), dy, idx, dx, Hi, Wi, Hi / 2, Wi / 2, C,
+                       n4);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int accumulate, void* stream) {
+    if (n % 4) return (int)hipErrorInvalidValue;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(relu_bwd_kernel, grid1(n / 4), dim3(256), 0, as_stream(stream), dy, y, dx, accumulate, n / 4);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -836,6 +836,28 @@ def maxpool3s2_bwd(dy, idx, in_shape):
     return dx
 
 
+def maxpool2(x):
+    b, hi, wi, c = x.shape
+    y = torch.empty(b, hi // 2, wi // 2, c, device=x.device, dtype=torch.float32)
+    idx = torch.empty(b, hi // 2, wi // 2, c, device=x.device, dtype=torch.uint8)
+    call("e4s_maxpool2_f32", fptr(x), fptr(y), ptr(idx), b, hi, wi, c, stream())
+    return y, idx
+
+
+def maxpool2_bwd(dy, idx, in_shape):
+    b, hi, wi, c = in_shape
+    dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    call("e4s_maxpool2_bwd_f32", fptr(_f32(dy)), ptr(idx), fptr(dx), b, hi, wi, c, stream())
+    return dx
+
+
+def relu_bwd(dy, y, dx_acc=None):
+    """dx (+)= dy * [y > 0], from the ReLU's output."""
+    dx = dx_acc if dx_acc is not None else torch.empty_like(y)
+    call("e4s_relu_bwd_f32", fptr(_f32(dy)), fptr(y), fptr(dx), y.numel(), 1 if dx_acc is not None else 0, stream())
+    return dx
+
+
 def lpips_layer(fx, fy, w):
     """[B] = spatial mean of the lin-weighted squared distance of the unit-normalised features (NHWC)."""
     b, h, wd, c = fx.shape

@@ -136,6 +136,9 @@ SIGNATURES = {
     "e4s_conv_smallcin_bwd_f32": [c_p, c_p, c_p] + [c_i] * 10 + [c_p],
     "e4s_maxpool3s2_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_maxpool3s2_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_maxpool2_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_maxpool2_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_relu_bwd_f32": [c_p, c_p, c_p, c_l, c_i, c_p],
     "e4s_lpips_layer_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_lpips_layer_ws_doubles": [c_i, c_i],
     "e4s_lpips_layer_bwd_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p],

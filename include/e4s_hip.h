@@ -422,6 +422,11 @@ int e4s_conv_smallcin_bwd_f32(const float* dy, const float* wp, float* dx, int B
  * maximum in the window (ATen's tie rule); the backward routes dy through idx. */
 int e4s_maxpool3s2_f32(const float* x, float* y, uint8_t* idx, int B, int Hi, int Wi, int C, void* stream);
 int e4s_maxpool3s2_bwd_f32(const float* dy, const uint8_t* idx, float* dx, int B, int Hi, int Wi, int C, void* stream);
+/* nn.MaxPool2d(2) (the parsing UNet's encoder, src/criteria/face_parsing/unet.py:27-36): y [B,Hi/2,Wi/2,C], idx as above */
+int e4s_maxpool2_f32(const float* x, float* y, uint8_t* idx, int B, int Hi, int Wi, int C, void* stream);
+int e4s_maxpool2_bwd_f32(const float* dy, const uint8_t* idx, float* dx, int B, int Hi, int Wi, int C, void* stream);
+/* ReLU backward from the output: dx (+)= dy * [y > 0]; n % 4 == 0 */
+int e4s_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int accumulate, void* stream);
 /* LPIPS distance of one feature level (src/criteria/lpips/lpips.py:32-33 with utils.py:normalize_activation): out[b] =
  * mean_p sum_c w[c] (fx/(|fx|+1e-10) - fy/(|fy|+1e-10))^2, fx / fy NHWC [B,HW,C], C <= 512; ws:
  * e4s_lpips_layer_ws_doubles(B, HW) doubles (ordered reduction).  *_bwd: dfx (+)= gout[0] * gmul * d(out[b])/d(fx). */

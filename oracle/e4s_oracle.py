@@ -552,3 +552,34 @@ def lpips(sd, x, y):
 def lpips_multiscale(sd, x, y, sizes=(1024, 512, 256)):
     """the LPIPS term of Optimizer.calc_loss, scripts/optimization.py:100-108."""
     return sum(lpips(sd, F.adaptive_avg_pool2d(x, (s, s)), F.adaptive_avg_pool2d(y, (s, s))) for s in sizes)
+
+
+def unet_encoder_features(sd, x, pfx="G."):
+    """unet.extract_feats, src/criteria/face_parsing/unet.py:69-91: five unetConv2 stages (conv3x3 + BatchNorm(eval) + ReLU,
+    twice; model_utils.py:177-203) with MaxPool2d(2) between them; l2-normalised flattened maps."""
+    feats = []
+    for i, name in enumerate(("conv1", "conv2", "conv3", "conv4", "center")):
+        if i:
+            x = F.max_pool2d(x, 2)
+        for sub in ("conv1", "conv2"):
+            p = f"{pfx}{name}.{sub}."
+            x = F.conv2d(x, sd[p + "0.weight"].to(x.dtype), sd[p + "0.bias"].to(x.dtype), padding=1)
+            x = F.relu(_bn_eval(sd, p + "1.", x))
+        feats.append(x)
+    return [f.reshape(f.shape[0], -1) / torch.norm(f.reshape(f.shape[0], -1), 2, 1, True) for f in feats]
+
+
+def face_parsing_loss(sd, y_hat, y):
+    """FaceParsingLoss.forward, src/criteria/face_parsing/face_parsing_loss.py:52-78 -> (loss, sim_improvement)."""
+    def extract(x):
+        if x.shape[2] != 512:
+            x = F.adaptive_avg_pool2d(x, (512, 512))
+        return unet_encoder_features(sd, x)
+    fy = [f.detach() for f in extract(y)]
+    fh = extract(y_hat)
+    loss, imp = 0.0, 0.0
+    for a, b in zip(fh, fy):
+        sim = (a * b).sum(1)
+        loss = loss + (1 - sim).mean()
+        imp = imp + (sim - (b * b).sum(1)).mean()
+    return loss, imp

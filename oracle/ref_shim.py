@@ -117,7 +117,8 @@ def reference_gpen():
 
 
 def reference_criteria(alexnet_features):
-    """The reference's own IDLoss (src/criteria/id_loss.py) and LPIPS (src/criteria/lpips/lpips.py), imported in place with
+    """The reference's own IDLoss (src/criteria/id_loss.py), LPIPS (src/criteria/lpips/lpips.py) and FaceParsingLoss
+    (src/criteria/face_parsing/face_parsing_loss.py), imported in place with
     the reference's `src` winning over this repo's overlay.  torchvision is absent here: `alexnet_features` (a callable
     returning torchvision's AlexNet `features` Sequential, restated) stands in for `models.alexnet(True).features`
     (lpips/networks.py:76), and the LPIPS weight download (lpips/utils.py:11-20) is replaced by the LinLayers'
@@ -139,7 +140,8 @@ def reference_criteria(alexnet_features):
         netm = importlib.import_module("src.criteria.lpips.networks")
         netm.models = types.SimpleNamespace(alexnet=lambda *a, **k: types.SimpleNamespace(features=alexnet_features()))
         lpm.get_state_dict = lambda net_type="alex", version="0.1": netm.LinLayers([64, 192, 384, 256, 256]).state_dict()
-        ns = types.SimpleNamespace(IDLoss=idm.IDLoss, LPIPS=lpm.LPIPS)
+        fpm = importlib.import_module("src.criteria.face_parsing.face_parsing_loss")
+        ns = types.SimpleNamespace(IDLoss=idm.IDLoss, LPIPS=lpm.LPIPS, FaceParsingLoss=fpm.FaceParsingLoss)
     finally:
         sys.path[:] = saved_path
         for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:

@@ -127,3 +127,15 @@ def test_loss_networks_match_reference(golden):
             assert float((f[:, :8, :4, :4] - ref).abs().max()) < 1e-6
     d = yh.grad[:, :, ::4, ::4] - g["grad_strided"]
     assert float(d.norm() / g["grad_strided"].norm()) < 1e-4
+    sdp = synth.synth_module_state_dict(C.FaceParsingLoss(types.SimpleNamespace()), 0, "fp.")
+    yh, y = synth.synth_image_pair(1, 512, seed=6)
+    yh.requires_grad_(True)
+    loss, imp = orc.face_parsing_loss(sdp, yh, y)
+    loss.backward()
+    g = gold["parsing512"]
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 and abs(float(imp) - g["improvement"]) < 1e-5
+    with torch.no_grad():
+        for f, ref in zip(orc.unet_encoder_features(sdp, y), g["feat_heads"]):
+            assert float((f[:, :64] - ref).abs().max()) < 1e-6
+    d = yh.grad[:, :, ::8, ::8] - g["grad_strided"]
+    assert float(d.norm() / g["grad_strided"].norm()) < 1e-3

@@ -48,7 +48,7 @@ def test_scripts_resolve_hot_path_to_e4s_amd_and_the_rest_to_the_reference(face_
     assert helpers.bottleneck_IR_SE is e4s_amd.criteria.bottleneck_IR_SE
     # the loss networks of the optimisation loop (scripts/optimization.py:23-24) are the native ones
     assert opt.IDLoss is e4s_amd.criteria.IDLoss and opt.LPIPS is e4s_amd.criteria.LPIPS
-    assert "/reference/" in opt.FaceParsingLoss.__init__.__code__.co_filename
+    assert opt.FaceParsingLoss is e4s_amd.criteria.FaceParsingLoss
 
 
 def test_loss_network_state_dicts_match_the_reference_classes():
@@ -63,6 +63,9 @@ def test_loss_network_state_dicts_match_the_reference_classes():
     shapes = lambda m: {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert shapes(mine) == shapes(ref)
     assert shapes(C.LPIPS()) == shapes(ns.LPIPS(net_type="alex"))
+    minep = C.FaceParsingLoss(types.SimpleNamespace())
+    torch.save(minep.G.state_dict(), tmp + "/unet.pth")
+    assert shapes(minep) == shapes(ns.FaceParsingLoss(types.SimpleNamespace(face_parsing_model_path=tmp + "/unet.pth")))
 
 
 @pytest.mark.parametrize("case", ["plain", "no_ear", "no_teeth", "below_face"])
