@@ -208,11 +208,15 @@ def gpen_leg(dev, reps=10):
     return out
 
 
-def train_leg(dev, lat, steps=3, batch=2):
+def train_leg(dev, lat, steps=3, batch=2, losses="full"):
     """BASELINE.json configs[4] on ONE GPU: Net3.forward (encoder + LocalMLPs trainable, G frozen -- the reference's
-    default, networks.py:63-66) on a batch of 2 (train_options.py:24) at 1024^2 -> MSE loss -> backward through the HIP
-    generator / MLP / encoder backward kernels -> fused Adam.  The adversarial / LPIPS / ID terms of coach.py:340-356 need
-    the loss networks and are not part of this leg."""
+    default, networks.py:63-66) on a batch of 2 (train_options.py:24) at 1024^2 -> loss -> backward through the HIP
+    generator / MLP / encoder backward kernels -> fused Adam.  losses = "full": the generator step of coach.py:340-356 with
+    calc_loss's default terms (coach.py:403-453, train_options.py:47-54): parsing * 0.1 + ID * 0.1 + l2 + LPIPS x3 * 0.8 on the
+    native loss networks, plus the non-saturating adversarial term * 0.01 through the native Discriminator graph
+    (adv_loss.py:8-32; D itself is updated every 15th step in the reference and is frozen here); "mse": the l2 term alone.
+    Synthetic weights everywhere."""
+    import types
     from e4s_amd.optim import FusedAdam
     net = Net3(make_opts(out_size=SIZE))
     net.load_state_dict(synth.synth_state_dict(SIZE, KREM), strict=True)
@@ -223,11 +227,28 @@ def train_leg(dev, lat, steps=3, batch=2):
     mask = synth.onehot(synth.synth_labels_face(batch, 512, seed=21)).to(dev)
     params = [p for p in net.parameters() if p.requires_grad]
     opt = FusedAdam(params, lr=1e-4)
+    crit = None
+    if losses == "full":
+        from e4s_amd.criteria import FaceParsingLoss, IDLoss, LPIPS
+        from e4s_amd.stylegan2 import Discriminator
+        lp, idl, fpl = LPIPS(), IDLoss(types.SimpleNamespace(id_loss_multiscale=True)), FaceParsingLoss(types.SimpleNamespace())
+        for m, tag in ((lp, "lp."), (idl, "id."), (fpl, "fp.")):
+            m.load_state_dict(synth.synth_module_state_dict(m, 0, tag))
+        disc = Discriminator(SIZE)
+        disc.load_state_dict(synth.synth_disc_state_dict(SIZE), strict=True)
+        for p in disc.parameters():
+            p.requires_grad = False
+        crit = [m.to(dev).eval() for m in (lp, idl, fpl)] + [disc.to(dev).eval()]
 
     def one_step():
         opt.zero_grad()
         out, _ = net(img, mask)
-        torch.nn.functional.mse_loss(out, target).backward()
+        loss = torch.nn.functional.mse_loss(out, target)
+        if crit is not None:
+            lp, idl, fpl, disc = crit
+            loss = loss + 0.8 * lp.forward_pooled(out, target, (1024, 512, 256)) + 0.1 * idl(out, target)[0] \
+                + 0.1 * fpl(out, target)[0] + 0.01 * torch.nn.functional.softplus(-disc(out)).mean()
+        loss.backward()
         opt.step()
     one_step()
     torch.cuda.synchronize()
@@ -237,7 +258,7 @@ def train_leg(dev, lat, steps=3, batch=2):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     return {"ms_per_step": round(ms, 2), "batch": batch, "images_per_s": round(batch * 1e3 / ms, 2),
-            "trainable_parameters": int(sum(p.numel() for p in params))}
+            "trainable_parameters": int(sum(p.numel() for p in params)), "losses": losses}
 
 
 def cpu_baseline(sd, lat, inputs, hip_img0, hip_img0_b1):
@@ -269,6 +290,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the ~700 launches per step eagerly instead of "
                                                             "replaying one captured HIP graph")
+    ap.add_argument("--train-only", action="store_true", help="run only the configs[4] train-step legs")
     ap.add_argument("--opt-modes", default="full,mse",
                     help="config-3 legs to run: full = l2 + LPIPS x3 + ID + parsing, mse = l2 only")
     ap.add_argument("--opt-graph", action="store_true",
@@ -325,6 +347,10 @@ def main():
 
     if args.probe_only:
         print(json.dumps(headline_probe(net, B, inputs[4], args.probe_reps)))
+        return
+    if args.train_only:
+        print(json.dumps({"config5_train_step_1gpu": train_leg(dev, lat, args.train_steps, losses="full"),
+                          "config5_train_step_1gpu_mse_only": train_leg(dev, lat, args.train_steps, losses="mse")}))
         return
     if args.opt_only:
         one = [t[:1].contiguous() if torch.is_tensor(t) else [n[:1].contiguous() for n in t] for t in inputs]
@@ -426,7 +452,8 @@ def main():
             del g32
         out["gpen512"] = gpen_leg(dev)
         if args.train_steps > 0:
-            out["config5_train_step_1gpu"] = train_leg(dev, lat, args.train_steps)
+            out["config5_train_step_1gpu"] = train_leg(dev, lat, args.train_steps, losses="full")
+            out["config5_train_step_1gpu_mse_only"] = train_leg(dev, lat, args.train_steps, losses="mse")
         if args.opt_steps > 0:
             out.update(config3_legs(net, one, args))
             out["config3_steps_run"] = args.opt_steps
