@@ -407,12 +407,19 @@ __global__ void norm_bwd_frozen_kernel(const float* __restrict__ dy, const float
 }
 
 // ---- cosine terms of the identity loss (id_loss.py:41-52 on l2-normalised features, helpers.py:14-17) ----------------
-constexpr int COS_CHUNK = 4096;      // elements per block
+// elements per block: 4096, grown so that a row never needs more than 256 partial slots (the finalize pass adds a row's
+// slots serially; the parsing UNet's first map has 8.4 M elements per row)
+__host__ __device__ inline int64_t cos_chunk(int64_t D) {
+    int64_t c = (D + 255) / 256;
+    c = (c + 255) / 256 * 256;
+    return c < 4096 ? 4096 : c;
+}
 
 __global__ void cosine_partial_kernel(const float* __restrict__ a, const float* __restrict__ bv, double* __restrict__ part,
                                       int64_t D, int nchunk) {
     const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
-    const int64_t lo = (int64_t)ch * COS_CHUNK, hi = (lo + COS_CHUNK < D) ? lo + COS_CHUNK : D;
+    const int64_t chunk = cos_chunk(D);
+    const int64_t lo = (int64_t)ch * chunk, hi = (lo + chunk < D) ? lo + chunk : D;
     double ab = 0.0, aa = 0.0, bb = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const double x = (double)a[(int64_t)b * D + i], y = (double)bv[(int64_t)b * D + i];
@@ -615,11 +622,14 @@ extern "C" int e4s_norm_bwd_frozen_f32(const float* dy, const float* stats, cons
     return 0;
 }
 
-extern "C" int64_t e4s_cosine_ws_doubles(int B, int64_t D) { return (int64_t)3 * B * ((D + COS_CHUNK - 1) / COS_CHUNK); }
+extern "C" int64_t e4s_cosine_ws_doubles(int B, int64_t D) {
+    const int64_t chunk = cos_chunk(D);
+    return (int64_t)3 * B * ((D + chunk - 1) / chunk);
+}
 
 extern "C" int e4s_cosine_f32(const float* a, const float* b, float* out, double* ws, int B, int64_t D, void* stream) {
     if (B < 1 || D < 1) return (int)hipErrorInvalidValue;
-    const int nchunk = (int)((D + COS_CHUNK - 1) / COS_CHUNK);
+    const int nchunk = (int)((D + cos_chunk(D) - 1) / cos_chunk(D));
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(cosine_partial_kernel, dim3((unsigned)(B * nchunk)), dim3(256), 0, st, a, b, ws, D, nchunk);
     E4S_CHECK_LAUNCH();
