@@ -145,8 +145,13 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
         img, _, _ = net.gen_img(None, codes, tm, randomize_noise=True)
         loss = torch.nn.functional.mse_loss(img, target)
         if lpips is not None:
-            loss = loss + 0.8 * lpips.forward_pooled(img, target, (1024, 512, 256)) + 0.1 * idl(img, target)[0] \
-                + 0.1 * fpl(img, target)[0]
+            terms = os.environ.get("E4S_BENCH_TERMS", "lpips,id,parsing").split(",")      # debugging aid: subset of the terms
+            if "lpips" in terms:
+                loss = loss + 0.8 * lpips.forward_pooled(img, target, (1024, 512, 256))
+            if "id" in terms:
+                loss = loss + 0.1 * idl(img, target)[0]
+            if "parsing" in terms:
+                loss = loss + 0.1 * fpl(img, target)[0]
         loss.backward()
         opt.step()
         return loss.detach()
