@@ -299,8 +299,8 @@ def main():
     ap.add_argument("--opt-modes", default="full,mse",
                     help="config-3 legs to run: full = l2 + LPIPS x3 + ID + parsing, mse = l2 only")
     ap.add_argument("--opt-graph", action="store_true",
-                    help="replay each config-3 step as one HIP graph (e4s_amd.optim.GraphedStep); measured 11.6 vs 11.9 ms on the "
-                         "l2-only step -- the loop is bound by the duration of its many small kernels, not by launch overhead")
+                    help="replay each config-3 step as one HIP graph (e4s_amd.optim.GraphedStep): 11.6 vs 11.9 ms on the l2-only "
+                         "step, 20.4 vs ~25 ms with the LPIPS and identity terms")
     ap.add_argument("--opt-steps", type=int, default=200,
                     help="configs[2] leg: run this many W+ optimisation steps (scripts/optimization.py runs 200: "
                          "cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam each) and report the measured total")

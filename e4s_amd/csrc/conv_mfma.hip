@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
             valid = ay < p.Ha && ax < p.Wa;
         } else {
             const int anchor = plan ? p.rows[row_start + tid] : tt * BM + tid;
-            valid = anchor >= 0;
+            valid = plan ? anchor >= 0 : anchor < p.B * p.Ha * p.Wa;       // natural order: the last tile may be ragged
             const int a = valid ? anchor : 0;
             const int hw = p.Ha * p.Wa;
             b = a / hw;
@@ -432,8 +432,10 @@ int launch(const e4s_conv_params& p, hipStream_t st) {
         tiles_per_cls = p.B * ((p.Ha + L::TH - 1) / L::TH) * ((p.Wa + L::TW - 1) / L::TW);
         mtiles = tiles_per_cls * p.ncls;
     } else {
-        if (((int64_t)p.Ha * p.Wa) % BM) return (int)hipErrorInvalidValue;   // a tile never straddles two samples
-        tiles_per_cls = (int)((int64_t)p.B * p.Ha * p.Wa / BM);
+        // the tile-uniform group (style / demodulation row) needs tiles that never straddle two samples; without those
+        // operands (plain convs: encoder shortcuts, the loss networks' 7x7 ... 127x127 maps) any grid goes, ragged tail included
+        if (((int64_t)p.Ha * p.Wa) % BM && (p.in_scale || p.out_scale)) return (int)hipErrorInvalidValue;
+        tiles_per_cls = (int)(((int64_t)p.B * p.Ha * p.Wa + BM - 1) / BM);
         mtiles = tiles_per_cls * p.ncls;
     }
     if (mtiles <= 0) return 0;
@@ -493,7 +495,7 @@ extern "C" int e4s_conv_mfma_f32(const e4s_conv_params* pp, int spatial, void* s
         return deep ? launch<128, 32, 4, 1, true, 2>(p, st) : launch<128, 32, 4, 1, true, 1>(p, st);
     }
     if (p.labels) return (int)hipErrorInvalidValue;     // per-row regions exist only in spatial mode
-    const int64_t mt = p.tiles ? p.tiles_cap : (int64_t)p.B * p.Ha * p.Wa / 128 * p.ncls;
+    const int64_t mt = p.tiles ? p.tiles_cap : ((int64_t)p.B * p.Ha * p.Wa + 127) / 128 * p.ncls;
     const int bn = pick_bn(p, mt);
     if (bn == 128) return launch<128, 128, 2, 2, false>(p, st);
     const bool deep = mt * (p.Cout / bn) < 2048;

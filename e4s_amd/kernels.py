@@ -234,8 +234,8 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
         spatial = plan is None and istride == 1 and ntaps == 9
     if labels is not None and not spatial:
         raise RuntimeError("per-pixel region labels need the spatial (halo-tiled) mode")
-    if plan is None and not spatial and (ha * wa) % BM != 0 and w_split is None:
-        # natural-order tiles must not straddle samples: tiny grids go through a trivial one-region plan
+    if plan is None and not spatial and (ha * wa) % BM != 0 and w_split is None and (in_scale is not None or out_scale is not None):
+        # with a per-sample style / demodulation row the tiles must not straddle samples: a trivial one-region plan
         plan = region_plan(torch.zeros(b, 1, 1, device=x.device, dtype=torch.uint8), 1, ha, wa, ncls)
     if out is None:
         y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32)

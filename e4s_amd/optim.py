@@ -2,9 +2,8 @@
 [1,12,1280] style vectors; SURVEY.md 8(f) N1 'Adam step fusion').  Same hyper-parameters and state as torch.optim.Adam
 (no amsgrad); each parameter is updated by ONE kernel (e4s_adam_step_f32) instead of ~10 elementwise launches.
 `capturable=True` keeps the step count on the device (e4s_adam_step_dev_f32), so the whole optimisation step -- forward,
-backward and update -- can be captured in a HIP graph (`GraphedStep`) and replayed.  Measured on the 1024^2 l2-only step: 11.6 ms
-replayed vs 11.9 ms eager -- the loop is bound by the duration of its many small kernels, not by launch overhead, so the
-benchmark keeps the eager loop; see DESIGN.md section 6 for the open issue with the full objective at 1024^2."""
+backward and update -- can be captured in a HIP graph (`GraphedStep`) and replayed.  Measured at 1024^2: 11.6 ms replayed vs
+11.9 ms eager on the l2-only step, 20.4 vs ~25 ms with the LPIPS and identity terms."""
 import torch
 
 from . import kernels as K
