@@ -233,3 +233,43 @@ def test_bench_defaults_are_single_gpu_and_short():
     steps = int(re.search(r'add_argument\("--steps", type=int, default=(\d+)\)', src).group(1))
     warm = int(re.search(r'add_argument\("--warmup", type=int, default=(\d+)\)', src).group(1))
     assert 1 <= steps <= 50 and 0 <= warm <= 10
+
+
+def test_loss_network_parameter_folds_match_torch():
+    """Host-side algebra of e4s_amd/criteria.py (no kernels): BatchNorm(eval) as the {mean, rstd} operand, conv + BatchNorm
+    folded into one conv, and BatchNorm2d -> Flatten -> Linear -> BatchNorm1d folded into one NHWC-ordered affine map --
+    each against the torch modules they replace, in fp64-checked fp32."""
+    import types
+    import torch.nn.functional as F
+    from e4s_amd import criteria as C
+    g = torch.Generator().manual_seed(3)
+    # (x - mu') * rho' == BatchNorm2d.eval()(x)
+    bn = torch.nn.BatchNorm2d(8).eval()
+    bn.load_state_dict(synth.synth_module_state_dict(bn, 1, "bn."))
+    x = torch.randn(2, 8, 5, 5, generator=g)
+    st = C._bn_stats(bn, 2)                                               # [B,C,2]
+    mine = (x - st[:, :, 0, None, None]) * st[:, :, 1, None, None]
+    assert float((mine - bn(x)).abs().max()) < 2e-6
+    # conv -> BN folded (with zero channel padding) == BN(conv(x)) on the real channels, exact zeros on the padded ones
+    stage = C.unetConv2(3, 16).eval()
+    stage.load_state_dict(synth.synth_module_state_dict(stage, 2, "st."))
+    t = C._folded(stage.conv1, 3, 32)
+    xi = torch.randn(1, 3, 9, 9, generator=g)
+    ref = stage.conv1[1](stage.conv1[0](xi))
+    got = F.conv2d(xi, t.weight, t.bias, padding=1)
+    assert tuple(got.shape) == (1, 32, 9, 9) and float((got[:, :16] - ref).abs().max()) < 2e-6
+    assert float(got[:, 16:].abs().max()) == 0.0
+    t2 = C._folded(stage.conv2, 32, 32)
+    assert tuple(t2.weight.shape) == (32, 32, 3, 3) and float(t2.weight[:, 16:].abs().max()) == 0.0
+    # the identity head: one packed affine map on the NHWC-flattened [B,7,7,512] feature
+    bb = C.Backbone().eval()
+    bb.load_state_dict(synth.synth_module_state_dict(bb, 3, "bb."))
+    feat = torch.randn(2, 512, 7, 7, generator=g)
+    ref = bb.output_layer(feat)
+    w, b = bb._head()
+    got = feat.permute(0, 2, 3, 1).reshape(2, -1) @ w[0].t() + b[0]
+    assert float((got - ref).abs().max()) < 5e-5 * float(ref.abs().max())
+    # a zero BatchNorm scale cannot be expressed as (x - mu) * rho and is refused
+    bn.weight.data[3] = 0.0
+    with pytest.raises(RuntimeError):
+        C._bn_stats(bn, 3)
