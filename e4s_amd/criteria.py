@@ -169,7 +169,9 @@ class Backbone(Module):
         """BatchNorm2d(512) -> Flatten (NCHW order) -> Linear -> BatchNorm1d as ONE affine map on the NHWC-flattened feature:
         (W'' [1,512,25088], b'' [1,512]), cached."""
         bn2, _, _, lin, bn1 = self.output_layer
-        key = (param_key(lin.weight), param_key(bn2.weight), bn2.running_var._version, bn1.running_var._version)
+        key = (param_key(lin.weight), param_key(lin.bias), param_key(bn2.weight), param_key(bn2.bias), bn2.running_mean._version,
+               bn2.running_var._version, bn1.running_mean._version, bn1.running_var._version,
+               param_key(bn1.weight) if bn1.affine else None)
         if getattr(self, "_e4s_head", None) is None or self._e4s_head[0] != key:
             with torch.no_grad():
                 s2 = bn2.weight.float() / torch.sqrt(bn2.running_var.float() + bn2.eps)           # [512] per channel
@@ -532,7 +534,8 @@ def _folded(seq, cin_pad, cout_pad):
     (cout_pad, cin_pad) channels (16-channel maps ride the 32-channel K step; the padded channels stay exactly 0 through
     bias-free ReLU, so cosines over the padded maps equal those over the real ones).  Returns a `_Taps` holder with .bias."""
     conv, bn = seq[0], seq[1]
-    key = (param_key(conv.weight), param_key(bn.weight), bn.running_var._version, cin_pad, cout_pad)
+    key = (param_key(conv.weight), param_key(conv.bias), param_key(bn.weight), param_key(bn.bias), bn.running_mean._version,
+           bn.running_var._version, cin_pad, cout_pad)
     if getattr(seq, "_e4s_fold", None) is None or seq._e4s_fold[0] != key:
         with torch.no_grad():
             s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
