@@ -455,12 +455,19 @@ def main():
             out["ms_per_step_f32"] = round(dt32 * 1e3, 3)
             out["max_abs_default_vs_f32"] = float((img32 - img).abs().max())
             del g32
-        out["gpen512"] = gpen_leg(dev)
+        # side legs: a failure in one of them is reported in the line, it must not cost the headline measurement above
+        def side(key, fn):
+            try:
+                res = fn()
+                out.update(res if key is None else {key: res})
+            except Exception as e:      # noqa: BLE001
+                out[(key or "config3") + "_error"] = f"{type(e).__name__}: {e}"[:300]
+        side("gpen512", lambda: gpen_leg(dev))
         if args.train_steps > 0:
-            out["config5_train_step_1gpu"] = train_leg(dev, lat, args.train_steps, losses="full")
-            out["config5_train_step_1gpu_mse_only"] = train_leg(dev, lat, args.train_steps, losses="mse")
+            side("config5_train_step_1gpu", lambda: train_leg(dev, lat, args.train_steps, losses="full"))
+            side("config5_train_step_1gpu_mse_only", lambda: train_leg(dev, lat, args.train_steps, losses="mse"))
         if args.opt_steps > 0:
-            out.update(config3_legs(net, one, args))
+            side(None, lambda: config3_legs(net, one, args))
             out["config3_steps_run"] = args.opt_steps
             if "config3_opt_step_ms" in out:
                 out["config3_total_s"] = round(out["config3_opt_step_ms"] * args.opt_steps / 1e3, 3)
