@@ -286,7 +286,7 @@ def cpu_baseline(sd, lat, inputs, hip_img0, hip_img0_b1):
             "seconds": round(dt * reps, 2)}, err
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -319,7 +319,11 @@ def main():
     ap.add_argument("--probe-only", action="store_true", help="run only the headline-kernel probe (for rocprofv3)")
     ap.add_argument("--probe-reps", type=int, default=20)
     ap.add_argument("--opt-only", action="store_true", help="run only the configs[2] optimisation leg (for rocprofv3)")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = build_parser().parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
