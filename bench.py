@@ -131,7 +131,9 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
     opt = FusedAdam([latent], lr=1e-2, capturable=graphed)      # torch.optim.Adam's update as one kernel
     lpips = idl = fpl = None
     if losses == "full":
+        from e4s_amd import criteria
         from e4s_amd.criteria import FaceParsingLoss, IDLoss, LPIPS
+        criteria.ALLOW_UNINITIALIZED = True                  # seeded synthetic state dicts are loaded right below
         lpips = LPIPS()
         lpips.load_state_dict(synth.synth_module_state_dict(lpips, 0, "lp."))
         idl = IDLoss(types.SimpleNamespace(id_loss_multiscale=True))
@@ -165,8 +167,7 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
             gs.step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if int(gs.flags.item()) != 0 or not bool(torch.isfinite(gs.loss)):
-            raise RuntimeError("graphed optimisation step: invalid mask or non-finite loss")
+        gs.validate()                               # one-hot masks, finite loss (one sync, untimed)
         return round(dt / steps * 1e3, 3)
     for _ in range(2):
         opt.zero_grad(set_to_none=True)
@@ -213,57 +214,68 @@ def gpen_leg(dev, reps=10):
     return out
 
 
-def train_leg(dev, lat, steps=3, batch=2, losses="full"):
-    """BASELINE.json configs[4] on ONE GPU: Net3.forward (encoder + LocalMLPs trainable, G frozen -- the reference's
-    default, networks.py:63-66) on a batch of 2 (train_options.py:24) at 1024^2 -> loss -> backward through the HIP
-    generator / MLP / encoder backward kernels -> fused Adam.  losses = "full": the generator step of coach.py:340-356 with
-    calc_loss's default terms (coach.py:403-453, train_options.py:47-54): parsing * 0.1 + ID * 0.1 + l2 + LPIPS x3 * 0.8 on the
-    native loss networks, plus the non-saturating adversarial term * 0.01 through the native Discriminator graph
-    (adv_loss.py:8-32; D itself is updated every 15th step in the reference and is frozen here); "mse": the l2 term alone.
-    Synthetic weights everywhere."""
+def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3):
+    """BASELINE.json configs[4] on ONE GPU -- the body of Coach.train() (coach.py:280-398) through e4s_amd.train.TrainIteration:
+    G step = Net3.forward (encoder + LocalMLPs trainable, G frozen: SURVEY.md 8(d)'s opts) on a batch of 2
+    (train_options.py:24) at 1024^2 -> calc_loss's default terms (coach.py:403-453, train_options.py:47-54: parsing * 0.1 + ID * 0.1
+    + l2 + LPIPS x3 * 0.8 on the native loss networks) + g_adv_lambda * AdvGLoss through the native Discriminator graph ->
+    backward through the HIP loss-network / generator / MLP / encoder kernels -> fused Adam -> EMA of the weights;
+    D step (every d_every = 15th iteration) = Net3 forward without a graph + D(real) + D(fake) + AdvDLoss backward + fused
+    Adam on D; R1 step (d_reg_every; off by default in the reference, timed here at 16) = the second-order pass.
+    `ms_per_step` is the G step (every iteration runs one); `ms_per_iteration_amortised` adds d_step / 15.
+    losses = "mse": the l2 term alone, no Discriminator.  Synthetic weights everywhere; `warmup` untimed + `steps` timed."""
+    import copy
     import types
     from e4s_amd.optim import FusedAdam
+    from e4s_amd.train import LossOpts, TrainIteration
     net = Net3(make_opts(out_size=SIZE))
     net.load_state_dict(synth.synth_state_dict(SIZE, KREM), strict=True)
     net.latent_avg = lat.to(dev)
     net = net.to(dev).train()
     img = synth.synth_image(batch, SIZE, seed=7, tag="train_img").to(dev)
-    target = synth.synth_image(batch, SIZE, seed=7, tag="train_tgt").to(dev)
     mask = synth.onehot(synth.synth_labels_face(batch, 512, seed=21)).to(dev)
     params = [p for p in net.parameters() if p.requires_grad]
     opt = FusedAdam(params, lr=1e-4)
-    crit = None
+    crit, disc, opt_d = {}, None, None
+    lo = LossOpts(d_reg_every=16)
     if losses == "full":
+        from e4s_amd import criteria
         from e4s_amd.criteria import FaceParsingLoss, IDLoss, LPIPS
         from e4s_amd.stylegan2 import Discriminator
+        criteria.ALLOW_UNINITIALIZED = True                  # seeded synthetic state dicts are loaded right below
         lp, idl, fpl = LPIPS(), IDLoss(types.SimpleNamespace(id_loss_multiscale=True)), FaceParsingLoss(types.SimpleNamespace())
         for m, tag in ((lp, "lp."), (idl, "id."), (fpl, "fp.")):
             m.load_state_dict(synth.synth_module_state_dict(m, 0, tag))
+        crit = {"lpips": lp.to(dev).eval(), "id": idl.to(dev).eval(), "parsing": fpl.to(dev).eval()}
         disc = Discriminator(SIZE)
         disc.load_state_dict(synth.synth_disc_state_dict(SIZE), strict=True)
-        for p in disc.parameters():
-            p.requires_grad = False
-        crit = [m.to(dev).eval() for m in (lp, idl, fpl)] + [disc.to(dev).eval()]
+        disc = disc.to(dev).train()
+        opt_d = FusedAdam(disc.parameters(), lr=1e-4)
+    else:
+        lo.face_parsing_lambda = lo.id_lambda = lo.lpips_lambda = 0.0
+    net_ema = copy.deepcopy(net).eval() if losses == "full" else None      # coach.py:60-67
+    it = TrainIteration(net, disc, crit, opt, opt_d, lo=lo, net_ema=net_ema)
 
-    def one_step():
-        opt.zero_grad()
-        out, _ = net(img, mask)
-        loss = torch.nn.functional.mse_loss(out, target)
-        if crit is not None:
-            lp, idl, fpl, disc = crit
-            loss = loss + 0.8 * lp.forward_pooled(out, target, (1024, 512, 256)) + 0.1 * idl(out, target)[0] \
-                + 0.1 * fpl(out, target)[0] + 0.01 * torch.nn.functional.softplus(-disc(out)).mean()
-        loss.backward()
-        opt.step()
-    one_step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one_step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"ms_per_step": round(ms, 2), "batch": batch, "images_per_s": round(batch * 1e3 / ms, 2),
-            "trainable_parameters": int(sum(p.numel() for p in params)), "losses": losses}
+    def timed(fn, n, w):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    g_ms = timed(lambda: it.g_step(img, mask), steps, warmup)
+    out = {"ms_per_step": round(g_ms, 2), "g_step_ms": round(g_ms, 2), "batch": batch, "steps": steps, "warmup": warmup,
+           "images_per_s": round(batch * 1e3 / g_ms, 2), "trainable_parameters": int(sum(p.numel() for p in params)),
+           "losses": losses, "ema": net_ema is not None}
+    if disc is not None:
+        d_ms = timed(lambda: it.d_step(img, mask), max(2, steps // 2), 1)
+        r1_ms = timed(lambda: it.r1_step(img), max(2, steps // 3), 1)
+        out.update(d_step_ms=round(d_ms, 2), r1_step_ms=round(r1_ms, 2), d_every=lo.d_every, d_reg_every=lo.d_reg_every,
+                   ms_per_iteration_amortised=round(g_ms + d_ms / lo.d_every, 2),
+                   discriminator_parameters=int(sum(p.numel() for p in disc.parameters())))
+    return out
 
 
 def cpu_baseline(sd, lat, inputs, hip_img0, hip_img0_b1):
@@ -273,8 +285,9 @@ def cpu_baseline(sd, lat, inputs, hip_img0, hip_img0_b1):
     cores = min(os.cpu_count() or 1, 16)      # oneDNN at 1024^2 B=1 stops scaling (and oversubscribes) beyond this
     torch.set_num_threads(cores)
     driven, dm, target, tm, sm, noise = [t[:1].cpu() if torch.is_tensor(t) else [n[:1].cpu() for n in t] for t in inputs]
-    reps = 3                                   # ~15 s of CPU work on the GPU box's host cores
+    reps = 3                                   # 1 warm-up + 3 timed: ~20 s of CPU work on the host cores
     with torch.no_grad():
+        orc.face_swap_core(sd, driven, dm, target, tm, sm, lat, noise, SIZE, KREM)
         t0 = time.perf_counter()
         for _ in range(reps):
             img = orc.face_swap_core(sd, driven, dm, target, tm, sm, lat, noise, SIZE, KREM)
@@ -282,7 +295,7 @@ def cpu_baseline(sd, lat, inputs, hip_img0, hip_img0_b1):
     err = (float((img - hip_img0.cpu()).abs().max()), float((img - hip_img0_b1.cpu()).abs().max()))
     return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "1 swap (2 encoder passes + 12 LocalMLPs + 1024^2 generator, B=1), same seeded inputs as sample 0 "
-                      "of the GPU batch, mean of %d runs, torch %d threads" % (reps, cores),
+                      "of the GPU batch, 1 warm-up + mean of %d runs, torch %d threads" % (reps, cores),
             "seconds": round(dt * reps, 2)}, err
 
 
@@ -306,8 +319,9 @@ def build_parser():
                          "cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam each) and report the measured total")
     ap.add_argument("--f32-steps", type=int, default=5, help="also time this many steps with E4S_PRECISION=f32 (exact "
                                                              "fp32 MFMA everywhere) and report value_f32 / ms_per_step_f32")
-    ap.add_argument("--train-steps", type=int, default=3, help="configs[4] leg on one GPU: time this many joint train steps "
-                                                               "(batch 2 at 1024^2, encoder + LocalMLPs trainable)")
+    ap.add_argument("--train-steps", type=int, default=10, help="configs[4] leg on one GPU: time this many joint train steps "
+                                                                "after 3 warm-ups (batch 2 at 1024^2, encoder + LocalMLPs "
+                                                                "trainable; + D step and R1 step timed separately)")
     ap.add_argument("--gather-fp32", action="store_true",
                     help="N>1: all-gather the fp32 [B,3,H,W] images (100 MB per 8 swaps) instead of the default uint8 HWC "
                          "images the pipeline ends with (torch_utils.tensor2im, packed on the device: 25 MB)")
@@ -319,6 +333,11 @@ def build_parser():
     ap.add_argument("--probe-only", action="store_true", help="run only the headline-kernel probe (for rocprofv3)")
     ap.add_argument("--probe-reps", type=int, default=20)
     ap.add_argument("--opt-only", action="store_true", help="run only the configs[2] optimisation leg (for rocprofv3)")
+    ap.add_argument("--stub-swap", action="store_true",
+                    help="TEST ONLY (tests/test_bench_gloo.py): replace the HIP face swap by a trivial CPU function of the "
+                         "inputs so that the N>1 plumbing of main() -- shard seeds, overlapped uint8 gather, drain, barrier, "
+                         "MAX-reduced timing, the JSON line -- runs on CPU ranks over gloo.  The line says data: stub; it is "
+                         "not a measurement")
     return ap
 
 
@@ -328,31 +347,44 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    backend = os.environ.get("E4S_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; gloo only to exercise the N>1 code path
+    stub = bool(args.stub_swap)
+    if stub and backend != "gloo":
+        raise SystemExit("--stub-swap is the CPU/gloo plumbing test (E4S_DIST_BACKEND=gloo); it never runs beside the HIP path")
+    if not torch.cuda.is_available() and not stub:
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    dev_index = local_rank % torch.cuda.device_count()      # == local_rank on a real N-GPU node
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    if stub:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        dev_index = local_rank % torch.cuda.device_count()      # == local_rank on a real N-GPU node
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+        sync = torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("E4S_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only to exercise the
-        if backend == "nccl":                                  # N>1 code path on a 1-GPU box
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
 
-    sd = synth.synth_state_dict(SIZE, KREM)
-    lat = synth.synth_latent_avg(SIZE)
-    net = Net3(make_opts(out_size=SIZE))
-    net.load_state_dict(sd, strict=True)
-    net.latent_avg = lat.to(dev)
-    net = net.to(dev).eval()
     B = args.batch
-    inputs = build_inputs(B, dev, seed_base=100 + rank)
+    if stub:
+        net = sd = lat = None
+        g = torch.Generator().manual_seed(100 + rank)           # per-rank shard seed, as build_inputs(seed_base=100 + rank)
+        inputs = [torch.rand(B, 3, 8, 8, generator=g) * 2 - 1 for _ in range(5)] + [[torch.zeros(B, 1, 4, 4)]]
+    else:
+        sd = synth.synth_state_dict(SIZE, KREM)
+        lat = synth.synth_latent_avg(SIZE)
+        net = Net3(make_opts(out_size=SIZE))
+        net.load_state_dict(sd, strict=True)
+        net.latent_avg = lat.to(dev)
+        net = net.to(dev).eval()
+        inputs = build_inputs(B, dev, seed_base=100 + rank)
 
     if args.probe_only:
         print(json.dumps(headline_probe(net, B, inputs[4], args.probe_reps)))
@@ -368,13 +400,27 @@ def main():
 
     from e4s_amd import shard
 
-    swap = (lambda *a, noise: face_swap_core(net, *a, noise=noise)) if args.no_graph else None
-    if swap is None:
+    graphed = None
+    if stub:
+        swap = lambda d, dm, t, tm, sm, noise: 0.5 * d + 0.25 * t          # any deterministic function of the rank's shard
+    elif args.no_graph:
+        swap = lambda *a, noise: face_swap_core(net, *a, noise=noise)
+    else:
         graphed = GraphedFaceSwap(net, B)
         swap = lambda *a, noise: graphed(*a, noise)          # copies the inputs into the graph's static buffers
 
-    from e4s_amd import postproc
-    pack = None if args.gather_fp32 else postproc.tensor2im
+    if stub:
+        def pack(local, out=None):                           # the contract of postproc.tensor2im (torch_utils.tensor2im)
+            u8 = ((local.clamp(-1, 1) + 1) * 127.5).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+            if out is None:
+                return u8
+            out.copy_(u8)
+            return out
+    else:
+        from e4s_amd import postproc
+        pack = postproc.tensor2im
+    if args.gather_fp32:
+        pack = None
     overlap = shard.OverlappedGather(world * B, pack=pack) if (world > 1 and not args.sync_gather) else None
 
     def step():
@@ -390,7 +436,7 @@ def main():
             overlap.drain()                           # every submitted gather completes inside the timed region
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for _ in range(args.warmup):
         img = step()
@@ -400,7 +446,7 @@ def main():
         img = step()
     fence()
     dt = time.perf_counter() - t0
-    if not args.no_graph:
+    if graphed is not None:
         graphed.validate()                            # the one-hot precondition of the replayed graph (one sync, untimed)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -410,7 +456,8 @@ def main():
 
     out = {"metric": "1024^2 face-swap images/sec", "value": round(value, 3), "unit": "images/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[K.PRECISION], "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[K.PRECISION],
+           "data": "stub (CPU plumbing test, not a measurement)" if stub else "synthetic",
            "config": {"workload": "E4S-core face swap at 1024^2 (2x Net3 encoder @256^2, style swap, 12 LocalMLPs, "
                                   "mask-guided StyleGAN2 generator K=13), BASELINE.json configs[3] shard: "
                                   f"{B} swaps per GPU per step", "per_gpu_batch": B, "global_batch": B * world,
@@ -423,7 +470,19 @@ def main():
                           (", RCCL all_gather of the " + ("fp32 [B,3,H,W]" if args.gather_fp32 else "uint8 [B,H,W,3]")
                            + " outputs" + ("" if args.sync_gather else " overlapped with the next step"))
                           if world > 1 else "")}}
-    if rank == 0 and world == 1 and not args.steps_only:
+    if stub:
+        # what the plumbing test asserts: the last step's gathered uint8 batch holds rank r's shard at rows [r*B, (r+1)*B)
+        gathered = overlap.drain() if overlap is not None else (
+            shard.gather_outputs(pack(img) if pack is not None else img, world * B) if world > 1 else (pack(img) if pack else img))
+        want = []
+        for r in range(world):
+            g = torch.Generator().manual_seed(100 + r)
+            ins = [torch.rand(B, 3, 8, 8, generator=g) * 2 - 1 for _ in range(5)]
+            o = 0.5 * ins[0] + 0.25 * ins[2]
+            want.append(pack(o) if pack is not None else o)
+        out["stub_gather_ok"] = bool(torch.equal(gathered, torch.cat(want, 0)))
+        out["stub_gather_shape"] = list(gathered.shape)
+    if rank == 0 and world == 1 and not args.steps_only and not stub:
         # configs[1]: single-swap latency
         one = [t[:1].contiguous() if torch.is_tensor(t) else [n[:1].contiguous() for n in t] for t in inputs]
         swap1 = (lambda *a, noise: face_swap_core(net, *a, noise=noise)) if args.no_graph else None

@@ -13,6 +13,7 @@ modulation-weight / polyphase-fold outer products are plain matmuls on [G,C]-siz
 import math
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import kernels as K
 
@@ -99,6 +100,7 @@ class GeneratorFn(torch.autograd.Function):
         return image, feats
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dimage, dfeats):
         gen, tape, lat = ctx.gen, ctx.tape, ctx.lat
         b, r, nl, _ = lat.shape
@@ -192,6 +194,7 @@ class StyleCodesFn(torch.autograd.Function):
         return codes
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dcodes):
         sv, h, w0, w2 = ctx.saved_tensors
         s0, s2 = 1.0 / math.sqrt(w0.shape[2]), 1.0 / math.sqrt(w2.shape[2])

@@ -26,11 +26,34 @@ import os
 
 import torch
 from torch import nn
+from torch.autograd.function import once_differentiable
 from torch.nn import (BatchNorm1d, BatchNorm2d, Conv2d, Dropout, Linear, MaxPool2d, Module, PReLU, ReLU, Sequential)
 
 from . import kernels as K
 from .encoders import SEModule, _conv3x3, _conv_strided, get_block
 from .packs import param_key
+
+# The reference ALWAYS loads trained weights into its loss networks (id_loss.py:15, face_parsing_loss.py:29, lpips/utils.py:11-20
+# + torchvision's pretrained AlexNet) and fails when they are missing.  Same here: a loss network without weights is an error
+# unless this switch is on -- benchmarks and tests set it because they load seeded synthetic state dicts right after construction.
+ALLOW_UNINITIALIZED = os.environ.get("E4S_ALLOW_UNINITIALIZED_LOSS_NETS", "0") == "1"
+
+
+def _have_weights(what, path):
+    if path and os.path.exists(path):
+        return True
+    if ALLOW_UNINITIALIZED:
+        return False
+    raise FileNotFoundError(
+        f"{what}: no weights at {path!r}.  The reference loads trained weights here; optimising against a randomly initialised "
+        "loss network is silently meaningless.  Point the option at the checkpoint, or set e4s_amd.criteria.ALLOW_UNINITIALIZED "
+        "= True (env E4S_ALLOW_UNINITIALIZED_LOSS_NETS=1) when a state dict is loaded afterwards (synthetic-weight runs).")
+
+
+def _target_key(y):
+    """Cache key of a target image's features.  The entry also HOLDS y (so its storage cannot be freed and handed to a new
+    tensor with the same pointer and version 0 -- the caching allocator does exactly that); _version catches in-place edits."""
+    return (y.data_ptr(), y._version, tuple(y.shape), y.device)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -257,8 +280,12 @@ class _IDLossFn(torch.autograd.Function):
         return loss, sims
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gloss, _gsims):
         mod = ctx.mod
+        if ctx.tape is None:
+            raise RuntimeError("IDLoss: the activation tape was released by the first backward; run the forward again "
+                               "(retain_graph / double backward through this node are not supported)")
         g = gloss.reshape(1).to(torch.float32).contiguous()
         dfeats = [K.cosine_bwd(f, t, c, g, -1.0 / ctx.n) for f, t, c in zip(ctx.feats, ctx.y_feats, ctx.coefs)]
         if not mod.opts_multiscale:
@@ -280,7 +307,7 @@ class IDLoss(Module):
         self.face_pool_1 = torch.nn.AdaptiveAvgPool2d((256, 256))
         self.facenet = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se")
         path = getattr(opts, "ir_se50_path", None)
-        if path and os.path.exists(path):
+        if _have_weights("IDLoss (opts.ir_se50_path)", path):
             self.facenet.load_state_dict(torch.load(path, map_location="cpu"))
         self.face_pool_2 = torch.nn.AdaptiveAvgPool2d((112, 112))
         self.facenet.eval()
@@ -317,11 +344,11 @@ class IDLoss(Module):
             return [r / torch.norm(r, 2, 1, True) for r in rows]
 
     def _target_feats(self, y):
-        key = (y.data_ptr(), y._version, tuple(y.shape))
-        if self._target is None or self._target[0] != key:
+        key = _target_key(y)
+        if self._target is None or self._target[0] != key or self._target[1] is not y:
             with torch.no_grad():
-                self._target = (key, self.facenet.features_nhwc(self._prep(y)[0], self.opts_multiscale))
-        return self._target[1]
+                self._target = (key, y, self.facenet.features_nhwc(self._prep(y)[0], self.opts_multiscale))
+        return self._target[2]
 
     def forward(self, y_hat, y):
         """-> (loss, sim_improvement, None).  sim_improvement is a 0-dim tensor (float() of it is the reference's number;
@@ -450,8 +477,12 @@ class _LPIPSFn(torch.autograd.Function):
         return total.sum() / b
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout):
         mod = ctx.mod
+        if ctx.tapes is None:
+            raise RuntimeError("LPIPS: the activation tape was released by the first backward; run the forward again "
+                               "(retain_graph / double backward through this node are not supported)")
         g = gout.reshape(1).to(torch.float32).contiguous()
         dimg = None
         for tape, fx, fy in zip(ctx.tapes, ctx.feats, ctx.y_feats):
@@ -473,7 +504,8 @@ class LPIPS(Module):
         super().__init__()
         self.net = AlexNet()
         self.lin = LinLayers(self.net.n_channels_list)
-        if weights is not None:
+        weights = weights or os.environ.get("E4S_LPIPS_WEIGHTS")
+        if _have_weights("LPIPS (weights= / $E4S_LPIPS_WEIGHTS: torchvision AlexNet + the LPIPS v0.1 lin layers)", weights):
             sd = torch.load(weights, map_location="cpu")
             (self if any(k.startswith("net.") for k in sd) else self.lin).load_state_dict(sd)
         self._target = None
@@ -482,11 +514,11 @@ class LPIPS(Module):
         return self.lin[k][1].weight.detach().view(-1)
 
     def _target_feats(self, y, sizes):
-        key = (y.data_ptr(), y._version, tuple(y.shape), tuple(sizes))
-        if self._target is None or self._target[0] != key:
+        key = _target_key(y) + (tuple(sizes),)
+        if self._target is None or self._target[0] != key or self._target[1] is not y:
             with torch.no_grad():
-                self._target = (key, [self.net.features_nhwc(y, s) for s in sizes])
-        return self._target[1]
+                self._target = (key, y, [self.net.features_nhwc(y, s) for s in sizes])
+        return self._target[2]
 
     def forward_pooled(self, x, y, sizes):
         """sum_s LPIPS(adaptive_avg_pool2d(x, s), adaptive_avg_pool2d(y, s)) -- the three-scale term of
@@ -642,8 +674,12 @@ class _ParsingLossFn(torch.autograd.Function):
         return (1.0 - sims).mean(1).sum(), sims
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gloss, _gsims):
         mod = ctx.mod
+        if ctx.tape is None:
+            raise RuntimeError("FaceParsingLoss: the activation tape was released by the first backward; run the forward again "
+                               "(retain_graph / double backward through this node are not supported)")
         g = gloss.reshape(1).to(torch.float32).contiguous()
         dfeats = [K.cosine_bwd(f, t, c, g, -1.0 / ctx.n) for f, t, c in zip(ctx.feats, ctx.y_feats, ctx.coefs)]
         dx512 = mod.G.backward_nhwc(ctx.tape, dfeats)
@@ -661,7 +697,7 @@ class FaceParsingLoss(Module):
         self.face_pool = torch.nn.AdaptiveAvgPool2d((512, 512))
         self.G = unet()
         path = getattr(opts, "face_parsing_model_path", None)
-        if path and os.path.exists(path):
+        if _have_weights("FaceParsingLoss (opts.face_parsing_model_path)", path):
             self.G.load_state_dict(torch.load(path, map_location="cpu"))
         self.G.eval()
         self.set_requires_grad(False)
@@ -685,11 +721,11 @@ class FaceParsingLoss(Module):
                                   "off the optimisation path; call self.G(x) for the logits")
 
     def _target_feats(self, y):
-        key = (y.data_ptr(), y._version, tuple(y.shape))
-        if self._target is None or self._target[0] != key:
+        key = _target_key(y)
+        if self._target is None or self._target[0] != key or self._target[1] is not y:
             with torch.no_grad():
-                self._target = (key, self.G.features_nhwc(self._prep(y)))
-        return self._target[1]
+                self._target = (key, y, self.G.features_nhwc(self._prep(y)))
+        return self._target[2]
 
     def forward(self, y_hat, y):
         """-> (loss, sim_improvement) as the reference; sim_improvement is a 0-dim tensor."""

@@ -70,12 +70,17 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     const int mt = logical / ntn, nt = logical - mt * ntn;
     const int n0 = nt * BN;
     const bool plan = (p.tiles != nullptr);
-    int row_start = 0, g = 0, cls = 0, tt = mt, tb = 0, tyb = 0, txb = 0;
+    int row_start = 0, g = 0, cls = 0, tt = mt, tb = 0, tyb = 0, txb = 0, plan_rows = 0;
     if (plan) {
-        if (mt >= p.meta[0]) return;
+        if (mt >= p.meta[0] || mt >= p.tiles_cap) return;
         row_start = p.tiles[mt * 4 + 0];
         g = p.tiles[mt * 4 + 1];
         cls = p.tiles[mt * 4 + 2];
+        plan_rows = p.tiles[mt * 4 + 3];               // real rows of this tile; the rest of its BM slots are padding
+        // a plan that does not describe THIS launch (stale or clobbered tables) must not become an address
+        if (row_start < 0 || plan_rows < 0 || plan_rows > BM || (unsigned)g >= (unsigned)(p.B * p.groups_per_batch) ||
+            (unsigned)cls >= (unsigned)p.ncls)
+            return;
     } else {
         cls = mt / tiles_per_cls;
         tt = mt - cls * tiles_per_cls;
@@ -102,8 +107,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
             ax = txb * TW + tid % TW;
             valid = ay < p.Ha && ax < p.Wa;
         } else {
-            const int anchor = plan ? p.rows[row_start + tid] : tt * BM + tid;
-            valid = plan ? anchor >= 0 : anchor < p.B * p.Ha * p.Wa;       // natural order: the last tile may be ragged
+            const int anchor = plan ? (tid < plan_rows ? p.rows[row_start + tid] : -1) : tt * BM + tid;
+            valid = anchor >= 0 && anchor < p.B * p.Ha * p.Wa;             // natural order: the last tile may be ragged
             const int a = valid ? anchor : 0;
             const int hw = p.Ha * p.Wa;
             b = a / hw;

@@ -141,6 +141,15 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
     p[i] = pv - step_size * (mi / denom);
 }
 
+// exponential moving average of the weights (src/utils/torch_utils.py:189-194, coach.py:396-398): dst = dst*decay + src*(1-decay),
+// in the operation order of `par1.data.mul_(decay).add_(par2.data, alpha=1 - decay)` (two roundings)
+__global__ void ema_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n, float decay, float omd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = dst[i] * decay;
+    dst[i] = __fmaf_rn(src[i], omd, a);
+}
+
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 int linear_t_nsplit(int R, int O, int K) {
@@ -226,6 +235,13 @@ extern "C" int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v
     hipLaunchKernelGGL(adam_kernel, grid1(n), dim3(256), 0, as_stream(stream), p, grad, m, v, n, (float)(lr / bc1),
                        (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)(1.0 - beta1),
                        (float)(1.0 - beta2), (float)bc2_sqrt);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_ema_f32(float* dst, const float* src, int64_t n, double decay, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(ema_kernel, grid1(n), dim3(256), 0, as_stream(stream), dst, src, n, (float)decay, (float)(1.0 - decay));
     E4S_CHECK_LAUNCH();
     return 0;
 }

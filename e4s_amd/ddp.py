@@ -1,11 +1,30 @@
 """Data-parallel gradient averaging for the joint train step (BASELINE.json configs[4]; the reference wraps Net3 in
-torch DDP, src/training/coach.py:46-85).  One process per GPU; after backward every rank holds the full gradient of its
-shard of the batch, and the ranks average them with bucketed all-reduces (RCCL over xGMI with backend "nccl"; gloo in the
-CPU tests).  Buckets are flat fp32 buffers of ~64 MB: the 164 M-parameter Net3 (644 MB of gradients) goes out as ~10
-collectives whose ring time is bound by one xGMI link each, issued asynchronously in reverse parameter
-order -- the order backward produces them -- and waited for together."""
+torch DDP, src/training/coach.py:46-85).  One process per GPU; every rank computes the gradient of its shard of the batch and
+the ranks average them with bucketed all-reduces (RCCL over xGMI with backend "nccl"; gloo in the CPU tests).
+
+Buckets are flat fp32 buffers of ~64 MB in REVERSE parameter order -- the order backward produces gradients: the 134 M
+trainable parameters of Net3 (536 MB of gradients; 644 MB with the generator) go out as ~9 collectives whose ring time is bound
+by one xGMI link each (~7 ms for the lot), far below the ~100 ms backward they hide under.
+
+Overlap with the backward (VERDICT r2 #1d): a bucket's all-reduce is launched the moment its last gradient exists --
+  * from `register_post_accumulate_grad_hook` for parameters whose gradient autograd accumulates node by node (LocalMLPs,
+    generator), and
+  * from INSIDE the monolithic encoder backward (encoder_autograd.EncoderFn calls `notify_grad` per parameter as it walks the
+    24 units in reverse), so the encoder's buckets leave while the earlier units are still being differentiated.
+`arm()` before `loss.backward()`, `finish()` after it: finish() launches whatever has not fired (parameters without a gradient
+count as zeros), waits, divides by the world size and writes the averaged gradients back.  `average()` is the non-overlapped
+form (everything after backward); both give bit-identical results (same buffers, same collectives, same order)."""
 import torch
 import torch.distributed as dist
+
+_ACTIVE = None        # the armed averager; a plain global: autograd runs backward nodes on its own device thread
+
+
+def notify_grad(param, grad):
+    """Called by autograd Functions that produce FINAL parameter gradients inside one big backward node."""
+    a = _ACTIVE
+    if a is not None:
+        a.notify(param, grad)
 
 
 class GradAverager:
@@ -24,37 +43,101 @@ class GradAverager:
         if cur:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
+        self._where = {}
+        for i, bucket in enumerate(self.buckets):
+            o = 0
+            for p in bucket:
+                self._where[id(p)] = (i, o)
+                o += p.numel()
+        self._armed = False
+        self._sent, self._ready, self._works = set(), [0] * len(self.buckets), [None] * len(self.buckets)
+        self.fired_during_backward = 0                   # diagnostics: buckets launched before finish()
+        if self.world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._hook)
 
-    def average(self):
-        """grad <- mean over ranks of grad, for every parameter (a missing grad counts as zeros on that rank)."""
+    # ---- plumbing ---------------------------------------------------------------------------------------------------
+    def _buffer(self, i):
+        bucket = self.buckets[i]
+        dev = bucket[0].device
+        if self._flat[i] is None or self._flat[i].device != dev:
+            self._flat[i] = torch.empty(sum(p.numel() for p in bucket), device=dev, dtype=torch.float32)
+        return self._flat[i]
+
+    def _fire(self, i):
+        self._works[i] = dist.all_reduce(self._buffer(i), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _hook(self, p):
+        if self._armed and id(p) not in self._sent and p.grad is not None:
+            self.notify(p, p.grad)
+
+    def notify(self, p, grad):
+        """`grad` is the complete gradient of `p` for this backward: stage it, and launch the bucket when it is full."""
+        if not self._armed or self.world == 1:
+            return
+        key = id(p)
+        if key not in self._where:
+            return
+        if key in self._sent:
+            raise RuntimeError("GradAverager: a parameter's gradient was announced twice in one backward")
+        i, o = self._where[key]
+        with torch.no_grad():
+            self._buffer(i)[o:o + p.numel()].copy_(grad.detach().reshape(-1))
+        self._sent.add(key)
+        self._ready[i] += 1
+        if self._ready[i] == len(self.buckets[i]):
+            self._fire(i)
+            self.fired_during_backward += 1
+
+    # ---- API --------------------------------------------------------------------------------------------------------
+    def arm(self):
+        global _ACTIVE
         if self.world == 1:
             return
-        works = []
-        for i, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
-            dev = bucket[0].device
-            if self._flat[i] is None or self._flat[i].device != dev:
-                self._flat[i] = torch.empty(n, device=dev, dtype=torch.float32)
-            flat = self._flat[i]
-            o = 0
-            for p in bucket:
-                k = p.numel()
-                if p.grad is None:
-                    flat[o:o + k].zero_()
-                else:
-                    flat[o:o + k].copy_(p.grad.reshape(-1))
-                o += k
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for i, bucket in enumerate(self.buckets):
-            works[i].wait()
-            flat = self._flat[i]
-            flat.div_(self.world)
-            o = 0
-            for p in bucket:
-                k = p.numel()
-                g = flat[o:o + k].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                o += k
+        self._armed = True
+        self._sent, self._ready, self._works = set(), [0] * len(self.buckets), [None] * len(self.buckets)
+        self.fired_during_backward = 0
+        _ACTIVE = self
+
+    def finish(self):
+        """grad <- mean over ranks of grad, for every parameter (a missing grad counts as zeros on that rank)."""
+        global _ACTIVE
+        if self.world == 1:
+            return
+        if _ACTIVE is self:
+            _ACTIVE = None
+        self._armed = False
+        with torch.no_grad():
+            for i, bucket in enumerate(self.buckets):
+                if self._works[i] is not None:
+                    continue
+                flat = self._buffer(i)
+                for p in bucket:
+                    if id(p) in self._sent:
+                        continue
+                    _, o = self._where[id(p)]
+                    if p.grad is None:
+                        flat[o:o + p.numel()].zero_()
+                    else:
+                        flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
+                self._fire(i)
+            for i, bucket in enumerate(self.buckets):
+                self._works[i].wait()
+                flat = self._flat[i]
+                flat.div_(self.world)
+                for p in bucket:
+                    _, o = self._where[id(p)]
+                    g = flat[o:o + p.numel()].view_as(p)
+                    if p.grad is None:
+                        p.grad = g.clone()
+                    else:
+                        p.grad.copy_(g)
+        self._sent, self._works = set(), [None] * len(self.buckets)
+
+    def average(self):
+        """Non-overlapped form: everything after backward() has finished."""
+        if self.world == 1:
+            return
+        self._armed = False
+        self._sent, self._ready, self._works = set(), [0] * len(self.buckets), [None] * len(self.buckets)
+        self.finish()

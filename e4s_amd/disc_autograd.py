@@ -22,21 +22,43 @@ from torch.autograd import Function
 
 from . import kernels as K
 from .lib import call, fptr, stream
+from .packs import param_key
 
 
 # ---- conv family ------------------------------------------------------------------------------------------------
-def _pack(w):
-    return K.pack_taps(w.detach().float().contiguous())
+class _PackCache:
+    """Tap-packed / transposed / split-bf16 images of ONE ConvLayer weight, valid for one (storage, version) of the parameter
+    (packs.param_key).  While D is frozen (the generator step, 14 of 15 iterations) nothing is re-packed; while it trains, the
+    three or four uses inside one step (D(fake), D(real), their backward) share one pack."""
+    __slots__ = ("key", "packs")
+
+    def __init__(self):
+        self.key, self.packs = None, {}
+
+    def get(self, key, name, make):
+        if self.key != key:
+            self.key, self.packs = key, {}
+        if name not in self.packs:
+            self.packs[name] = make()
+        return self.packs[name]
 
 
-def _pack_t(w):
-    return K.pack_taps(w.detach().float().flip(2, 3).transpose(0, 1).contiguous())
+def _pack(w, cache=None):
+    make = lambda: K.pack_taps(w.detach().float().contiguous())
+    return cache[0].get(cache[1], "fwd", make) if cache is not None else make()
 
 
-def _conv_s1(x, wp, cout):
+def _pack_t(w, cache=None):
+    make = lambda: K.pack_taps(w.detach().float().flip(2, 3).transpose(0, 1).contiguous())
+    return cache[0].get(cache[1], "bwd", make) if cache is not None else make()
+
+
+def _conv_s1(x, wp, cout, cache=None, name=None):
     b, h, w, cx = x.shape
     if K.want_bf16x3(b, h, w, cx, cout):
-        return K.conv_mfma(x, wp, cout, w_split=K.split_bf16x2(wp))
+        make = lambda: K.split_bf16x2(wp)
+        ws = cache[0].get(cache[1], name + "_split", make) if cache is not None else make()
+        return K.conv_mfma(x, wp, cout, w_split=ws)
     return K.conv_mfma(x, wp, cout)
 
 
@@ -45,27 +67,27 @@ def _out_hw(kind, hw):
     return ((hw[0] - k) // 2 + 1, (hw[1] - k) // 2 + 1)
 
 
-def _conv_forward(x, w, kind):
+def _conv_forward(x, w, kind, cache=None):
     """x NHWC, w [Cout,Cin,k,k] (scale already applied).  kind: s1 = 3x3 stride 1 padding 1; s2k3 / s2k1 = 3x3 / 1x1 stride 2
     padding 0 (on the blurred map)."""
     x = x.contiguous()
     cout = w.shape[0]
     if kind == "s1":
-        return _conv_s1(x, _pack(w), cout)
+        return _conv_s1(x, _pack(w, cache), cout, cache, "fwd")
     anchors = _out_hw(kind, x.shape[1:3])
-    return K.conv_mfma(x, _pack(w), cout, istride=2, ntaps=9 if kind == "s2k3" else 1, anchors=anchors,
+    return K.conv_mfma(x, _pack(w, cache), cout, istride=2, ntaps=9 if kind == "s2k3" else 1, anchors=anchors,
                        tap_shift=1 if kind == "s2k3" else 0)
 
 
-def _conv_dgrad(gy, w, kind, x_shape):
+def _conv_dgrad(gy, w, kind, x_shape, cache=None):
     gy = gy.contiguous()
     cin = w.shape[1]
     if kind == "s1":
-        return _conv_s1(gy, _pack_t(w), cin)
+        return _conv_s1(gy, _pack_t(w, cache), cin, cache, "bwd")
     if kind == "s2k3":
         # y[o] = sum_k x[2o + k] w[k]  =>  dx = 'same' 3x3 conv of the grid holding gy[o] at (2o+1, 2o+1) with the flipped taps
-        return _conv_s1(K.strided_place(gy, 2, 1, 1, x_shape[1:3]), _pack_t(w), cin)
-    t = K.conv_mfma(gy, _pack_t(w), cin, ntaps=1, spatial=False)
+        return _conv_s1(K.strided_place(gy, 2, 1, 1, x_shape[1:3]), _pack_t(w, cache), cin, cache, "bwd")
+    t = K.conv_mfma(gy, _pack_t(w, cache), cin, ntaps=1, spatial=False)
     return K.strided_place(t, 2, 0, 0, x_shape[1:3])
 
 
@@ -80,33 +102,36 @@ def _conv_wgrad(gy, x, kind, w_shape):
 
 
 class Conv(Function):
+    """cache: (_PackCache, key) when `w` IS a ConvLayer's (scaled, padded) weight -- the packs are then shared between calls;
+    None for the second-order nodes, whose `w` operand is a gradient."""
+
     @staticmethod
-    def forward(ctx, x, w, kind):
-        ctx.kind = kind
+    def forward(ctx, x, w, kind, cache=None):
+        ctx.kind, ctx.cache = kind, cache
         ctx.save_for_backward(x, w)
-        return _conv_forward(x, w, kind)
+        return _conv_forward(x, w, kind, cache)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = ConvDgrad.apply(gy, w, ctx.kind, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+        gx = ConvDgrad.apply(gy, w, ctx.kind, tuple(x.shape), ctx.cache) if ctx.needs_input_grad[0] else None
         gw = ConvWgrad.apply(gy, x, ctx.kind, tuple(w.shape)) if ctx.needs_input_grad[1] else None
-        return gx, gw, None
+        return gx, gw, None, None
 
 
 class ConvDgrad(Function):
     @staticmethod
-    def forward(ctx, gy, w, kind, x_shape):
-        ctx.kind, ctx.x_shape = kind, x_shape
+    def forward(ctx, gy, w, kind, x_shape, cache=None):
+        ctx.kind, ctx.x_shape, ctx.cache = kind, x_shape, cache
         ctx.save_for_backward(gy, w)
-        return _conv_dgrad(gy, w, kind, x_shape)
+        return _conv_dgrad(gy, w, kind, x_shape, cache)
 
     @staticmethod
     def backward(ctx, ggx):
         gy, w = ctx.saved_tensors
-        d_gy = Conv.apply(ggx, w, ctx.kind) if ctx.needs_input_grad[0] else None
+        d_gy = Conv.apply(ggx, w, ctx.kind, ctx.cache) if ctx.needs_input_grad[0] else None
         d_w = ConvWgrad.apply(gy, ggx, ctx.kind, tuple(w.shape)) if ctx.needs_input_grad[1] else None
-        return d_gy, d_w, None, None
+        return d_gy, d_w, None, None, None
 
 
 class ConvWgrad(Function):
@@ -314,7 +339,10 @@ def _conv_layer(layer, x):
     kind = "s1" if conv.stride == 1 else ("s2k3" if k == 3 else "s2k1")
     if (kind == "s1" and (k != 3 or conv.padding != 1)) or (kind != "s1" and conv.padding != 0):
         raise NotImplementedError("ConvLayer geometry outside model.py:683-703")
-    y = Conv.apply(x, w, kind)
+    pc = getattr(conv, "_e4s_dpacks", None)
+    if pc is None:
+        pc = conv._e4s_dpacks = _PackCache()
+    y = Conv.apply(x, w, kind, (pc, param_key(conv.weight) + (cx,)))
     if isinstance(tail, FusedLeakyReLU):
         return BiasAct.apply(y, tail.bias, tail.negative_slope, tail.scale)
     if isinstance(tail, ScaledLeakyReLU):

@@ -8,15 +8,16 @@ same kernel schedule with a tape, the backward walks the 24 IR-SE units in rever
     conv 1x1 stride 2            dgrad: e4s_conv_mfma_f32 with the transposed weights + e4s_strided_scatter_f32
     PReLU                        e4s_prelu_bwd_f32
     IN(x)                        e4s_instnorm_bwd_f32
-    weight gradients             e4s_conv_wgrad_f32 (fp32 MFMA over the pixels, all 9 taps per block); the 3 -> 64 stem via
-                                 an im2col + one BLAS contraction
+    weight gradients             e4s_conv_wgrad_f32 (fp32 MFMA over the pixels, all 9 taps per block); the 3 -> 64 stem on the
+                                 same kernel with the image zero-padded to 32 channels
 
 The exact-zero SE input (the spatial mean of an instance-normalised map, helpers.py:64-66) makes dL/d(pooled) flow back
 only through rounding residue; that path (O(1e-8) of the gradient) is dropped."""
 import torch
-import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
 
 from . import kernels as K
+from .ddp import notify_grad
 from .encoders import _pack3x3, _conv3x3, _conv_strided
 
 
@@ -128,14 +129,21 @@ class EncoderFn(torch.autograd.Function):
         return codes
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dcodes):
         enc, tape = ctx.enc, ctx.tape
+        if tape is None or any(t is None for t in tape):
+            raise RuntimeError("EncoderFn: the activation tape was released by the first backward; run the forward again "
+                               "(retain_graph / double backward through this node are not supported)")
         grads = [None] * ctx.nparams
 
         def give(p, g):
             i = ctx.pidx.get(id(p))
             if i is not None:
-                grads[i] = g if grads[i] is None else grads[i] + g
+                if grads[i] is not None:
+                    raise RuntimeError("EncoderFn: every encoder parameter receives exactly one gradient contribution")
+                grads[i] = g
+                notify_grad(p, g)      # data-parallel runs: the bucket holding p may leave now, under the remaining units
         dcodes = dcodes.contiguous().to(torch.float32)
         dout = None
         for i in reversed(range(len(tape))):
@@ -153,10 +161,12 @@ class EncoderFn(torch.autograd.Function):
         give(prelu0.weight, dslope0)
         dc0, _ = K.instnorm_bwd(dn0, st["c0"], st["st0"])
         if id(conv0.weight) in ctx.pidx:
-            # 3-channel input: the [64 x P] x [P x 27] contraction over an im2col of the image (BLAS)
-            img = K.nhwc_to_nchw(st["x256"])
-            b = img.shape[0]
-            cols = F.unfold(img, 3, padding=1)                               # [B, 27, P]
-            dw0 = torch.einsum("bpc,bkp->ck", dc0.view(b, -1, dc0.shape[3]), cols)
-            give(conv0.weight, dw0.view_as(conv0.weight))
+            # 3-channel input: the same fp32-MFMA weight-gradient kernel as every other conv, on the image zero-padded to the
+            # kernel's 32-channel K step (8 MB per sample at 256^2; the padded channels' gradients are dropped)
+            x256 = st["x256"]
+            b, h, w, c = x256.shape
+            xpad = torch.zeros(b, h, w, 32, device=x256.device, dtype=torch.float32)
+            xpad[..., :c] = x256
+            dw0 = K.conv_wgrad(dc0, xpad, ntaps=9, istride=1)                 # [9, 64, 32]
+            give(conv0.weight, dw0[:, :, :c].permute(1, 2, 0).reshape(conv0.weight.shape).contiguous())
         return (None, None, None, None) + tuple(grads)

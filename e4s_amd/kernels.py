@@ -4,9 +4,11 @@ Each function allocates its outputs with torch (device memory + caching allocato
 plumbing PyTorch provides) and enqueues one native call on the current HIP stream.  No function
 here computes anything in torch; a missing library or a CPU tensor raises.
 """
+import contextlib
 import ctypes
 import math
 import os
+import threading
 
 import torch
 
@@ -174,8 +176,20 @@ def rgb_weights(w, s, scale):
 
 
 # ---- mask plan -------------------------------------------------------------------------------
-FLAG_SINK = None      # int32[1] device tensor: while set (HIP-graph capture), every mask_labels call ORs its not-one-hot flag
-                      # into it instead of a fresh tensor, so that a replayed graph can still be validated afterwards
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def flag_sink(flags):
+    """While active (HIP-graph capture), every mask_labels call OF THIS THREAD ORs its not-one-hot flag into `flags`
+    (int32[1] device tensor) instead of a fresh tensor, so that a replayed graph can still be validated afterwards.
+    Thread-local: another thread's strict-mask check keeps reading its own flag tensor."""
+    prev = getattr(_tls, "sink", None)
+    _tls.sink = flags
+    try:
+        yield flags
+    finally:
+        _tls.sink = prev
 
 
 def mask_labels(mask):
@@ -183,7 +197,8 @@ def mask_labels(mask):
     mask = _f32(mask)
     b, r, hm, wm = mask.shape
     labels = torch.empty(b, hm, wm, device=mask.device, dtype=torch.uint8)
-    flags = FLAG_SINK if FLAG_SINK is not None else torch.zeros(1, device=mask.device, dtype=torch.int32)
+    sink = getattr(_tls, "sink", None)
+    flags = sink if sink is not None else torch.zeros(1, device=mask.device, dtype=torch.int32)
     call("e4s_mask_labels", fptr(mask), ptr(labels), ptr(flags), b, r, hm, wm, stream())
     return labels, flags
 
@@ -539,6 +554,15 @@ def adam_step_dev(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step, adva
         raise RuntimeError("adam_step_dev: step must be a device int64 tensor")
     call("e4s_adam_step_dev_f32", fptr(p), fptr(_f32(grad)), fptr(m), fptr(v), p.numel(), float(lr), float(beta1),
          float(beta2), float(eps), float(weight_decay), ptr(step), 1 if advance else 0, stream())
+
+
+def ema_(dst, src, decay):
+    """dst <- dst * decay + src * (1 - decay) in place (torch_utils.accumulate, one launch per tensor)."""
+    if dst.dtype != torch.float32 or src.dtype != torch.float32 or dst.shape != src.shape or not dst.is_contiguous():
+        raise RuntimeError("ema_: contiguous fp32 tensors of one shape")
+    call("e4s_ema_f32", fptr(dst), fptr(src.contiguous()), dst.numel(), float(decay), stream())
+    torch.autograd.graph.increment_version(dst)          # raw-pointer write: keep (data_ptr, _version) pack keys honest
+    return dst
 
 
 def conv_wgrad(gz, x, *, ntaps=9, istride=1, anchors=None, ostride=1, phase=(0, 0), s=None, d=None, labels=None,

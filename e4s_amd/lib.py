@@ -90,6 +90,7 @@ SIGNATURES = {
     "e4s_grouped_outer_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "e4s_batch_sum_f32": [c_p, c_p, c_i, c_l, c_p],
     "e4s_adam_step_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_p],
+    "e4s_ema_f32": [c_p, c_p, c_l, c_d, c_p],
     "e4s_adam_step_dev_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_p, c_i, c_p],
     "e4s_torgb_bwd_x_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_shift_scale_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p],

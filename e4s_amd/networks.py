@@ -239,15 +239,12 @@ class GraphedFaceSwap:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            K.FLAG_SINK = self.flags
-            try:
-                # with a process group up (N > 1) other threads of this process (the RCCL watchdog) may touch the HIP
-                # runtime while the capture runs: only this thread's calls are policed then
-                mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+            # with a process group up (N > 1) other threads of this process (the RCCL watchdog) may touch the HIP
+            # runtime while the capture runs: only this thread's calls are policed then
+            mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+            with K.flag_sink(self.flags):
                 with torch.cuda.graph(self.graph, capture_error_mode=mode):
                     self.out = face_swap_core(self.net, *self.static, noise=self.noise)
-            finally:
-                K.FLAG_SINK = None
         self.graph.replay()
         return self.out
 

@@ -14,8 +14,8 @@ class FusedAdam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self.capturable = capturable
-        self._dev_step = None                                  # one device counter for the whole optimiser
+        self.capturable = capturable      # step counts live in state[p]["step"] as device int64[1] tensors (as torch's
+                                          # capturable Adam keeps them): per parameter, and part of state_dict()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -23,7 +23,6 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        advance = True
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -31,21 +30,28 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("FusedAdam handles contiguous fp32 parameters")
+                if p.grad.is_sparse or p.grad.device != p.device or p.grad.dtype != torch.float32:
+                    raise RuntimeError("FusedAdam needs a dense fp32 gradient on the parameter's device")
                 st = self.state[p]
                 if not st:
-                    st["step"] = 0
+                    st["step"] = torch.zeros(1, device=p.device, dtype=torch.int64) if self.capturable else 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 if self.capturable:
-                    if self._dev_step is None:
-                        self._dev_step = torch.zeros(1, device=p.device, dtype=torch.int64)
+                    if not torch.is_tensor(st["step"]):         # state loaded from a non-capturable optimiser
+                        st["step"] = torch.full((1,), int(st["step"]), device=p.device, dtype=torch.int64)
                     K.adam_step_dev(p, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
-                                    group["weight_decay"], self._dev_step, advance)
-                    advance = False
+                                    group["weight_decay"], st["step"], True)
+                    torch.autograd.graph.increment_version(p)
                     continue
+                if torch.is_tensor(st["step"]):                 # state loaded from a capturable optimiser (one sync, once)
+                    st["step"] = int(st["step"].item())
                 st["step"] += 1
                 K.adam_step(p, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
                             group["weight_decay"], st["step"])
+                # the kernel wrote through the raw pointer: advance the version counter like an in-place torch op would, or
+                # every weight pack keyed on (data_ptr, _version) (e4s_amd/packs.py) would keep serving the OLD weights
+                torch.autograd.graph.increment_version(p)
         return loss
 
 
@@ -72,15 +78,22 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         flags = torch.zeros(1, device=opt.param_groups[0]["params"][0].device, dtype=torch.int32)
         opt.zero_grad(set_to_none=True)
-        K.FLAG_SINK = flags                                     # mask checks accumulate here instead of syncing
-        try:
+        with K.flag_sink(flags):                                # this thread's mask checks accumulate here instead of syncing
             with torch.cuda.graph(self.graph):
                 self.loss = body()
-        finally:
-            K.FLAG_SINK = None
         self.flags = flags
 
     def step(self):
         self.graph.replay()
         self.steps_done += 1
         return self.loss
+
+    def validate(self):
+        """One host sync: raises if any replay since the last validate() saw a parsing mask that is not one-hot (the replayed
+        kernels use hard argmax regions; the eager path falls back to the reference's R-pass formulation) or a non-finite loss."""
+        bad = bool(self.flags.item())
+        self.flags.zero_()
+        if bad:
+            raise RuntimeError("GraphedStep was replayed with a parsing mask that is not one-hot")
+        if not bool(torch.isfinite(self.loss).all()):
+            raise RuntimeError("GraphedStep: non-finite loss")

@@ -641,8 +641,8 @@ def equal_linear_lrelu(lin, x):
 
 
 # ---- Discriminator (config 5): native forward on the MFMA conv kernels; under autograd the same kernels as closed families
-# of autograd Functions (disc_autograd.py) that can be differentiated twice (the R1 penalty).  CPU tensors take the module
-# tree's own torch forward (conv2d_gradfix -> ATen), which exists for state_dict / API parity with the reference ----
+# of autograd Functions (disc_autograd.py) that can be differentiated twice (the R1 penalty).  CPU tensors are refused (no CPU
+# path); the module tree (ConvLayer / ResBlock as nn.Modules) exists for state_dict / API parity with the reference ----
 class ConvLayer(nn.Sequential):
     """model.py:670-716"""
 
@@ -725,13 +725,5 @@ class Discriminator(nn.Module):
                 return self.forward_native(input)
             from .disc_autograd import discriminator_forward      # native graph, differentiable twice (R1, adv_loss.py:48-60)
             return discriminator_forward(self, input)
-        out = self.convs(input)
-        batch, channel, height, width = out.shape
-        group = min(batch, self.stddev_group)
-        stddev = out.view(group, -1, self.stddev_feat, channel // self.stddev_feat, height, width)
-        stddev = torch.sqrt(stddev.var(0, unbiased=False) + 1e-8)
-        stddev = stddev.mean([2, 3, 4], keepdims=True).squeeze(2)
-        stddev = stddev.repeat(group, 1, height, width)
-        out = torch.cat([out, stddev], 1)
-        out = self.final_conv(out)
-        return self.final_linear(out.view(batch, -1))
+        raise RuntimeError("Discriminator.forward needs a ROCm tensor: there is no CPU path (the module tree exists for "
+                           "state_dict / API parity; its layers run on the HIP ops)")

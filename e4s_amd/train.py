@@ -1,0 +1,161 @@
+"""One training iteration of the joint Net3 + Discriminator loop (BASELINE.json configs[4]) -- the body of Coach.train()
+(src/training/coach.py:280-398) as a host-side schedule over the native kernels:
+
+    D step   (coach.py:290-307, every `d_every`-th iteration)   net forward without a graph -> D(recon), D(img) on the native
+                                                               Discriminator graph -> AdvDLoss (adv_loss.py:18-29) -> backward
+                                                               through disc_autograd's closed Function families -> fused Adam
+    R1 step  (coach.py:309-319, adv_loss.py:33-45, when `d_reg_every` != -1 and the D step's batch index is a multiple of it)
+                                                               dD/d(img) with create_graph -> |grad|^2 penalty -> second-order
+                                                               backward through the same families (weight gradients only)
+    G step   (coach.py:324-357)                                 Net3.forward (encoder + LocalMLPs [+ G] trainable) -> AdvGLoss * g_adv_lambda
+                                                               + calc_loss (coach.py:403-453: parsing, ID, l2, LPIPS x3) -> backward through
+                                                               the loss networks, the generator, the LocalMLPs and the encoder -> [bucketed
+                                                               all-reduce overlapped with the encoder backward] -> fused Adam
+    EMA      (coach.py:396-398, torch_utils.py:189-194)         e4s_ema_f32 per tensor
+
+The scalar glue on [B,1] logits (softplus, means, the loss sum) stays in torch: a handful of one-element launches that
+autograd differentiates as is.  Nothing here touches the control plane of the Coach (data loading, logging, checkpoints)."""
+import torch
+import torch.nn.functional as F
+
+from . import kernels as K
+
+
+def requires_grad(model, flag=True):
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def accumulate(model1, model2, decay=0.999):
+    """torch_utils.accumulate (src/utils/torch_utils.py:189-194): EMA of model2's parameters into model1, one native launch per
+    tensor; version counters advance (kernels.ema_), so cached weight packs of model1 are rebuilt on next use."""
+    p2 = dict(model2.named_parameters())
+    with torch.no_grad():
+        for k, p in model1.named_parameters():
+            K.ema_(p, p2[k].detach(), decay)
+
+
+def adv_g_loss(fake_pred):
+    """AdvGLoss, adv_loss.py:8-16."""
+    return F.softplus(-fake_pred).mean()
+
+
+def adv_d_loss(real_pred, fake_pred):
+    """AdvDLoss, adv_loss.py:18-29."""
+    return F.softplus(-real_pred).mean() + F.softplus(fake_pred).mean()
+
+
+def d_r1_loss(real_pred, real_img):
+    """DR1Loss, adv_loss.py:33-45 (the reference's conv2d_gradfix.no_weight_gradients() is inert on every supported torch,
+    SURVEY.md 8(a) item 10; here the first-order weight-gradient nodes are simply never asked for)."""
+    grad_real, = torch.autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
+    return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
+
+
+class LossOpts:
+    """The loss weights of train_options.py:44-57 (defaults as shipped)."""
+
+    def __init__(self, face_parsing_lambda=0.1, id_lambda=0.1, l2_lambda=1.0, lpips_lambda=0.8, g_adv_lambda=0.01,
+                 r1_lambda=10.0, d_every=15, d_reg_every=-1, lpips_sizes=(1024, 512, 256)):
+        self.face_parsing_lambda, self.id_lambda, self.l2_lambda = face_parsing_lambda, id_lambda, l2_lambda
+        self.lpips_lambda, self.g_adv_lambda, self.r1_lambda = lpips_lambda, g_adv_lambda, r1_lambda
+        self.d_every, self.d_reg_every, self.lpips_sizes = d_every, d_reg_every, tuple(lpips_sizes)
+
+
+class TrainIteration:
+    """net: Net3 in train mode; disc: Discriminator or None (train_D False); crit: dict with optional 'lpips', 'id', 'parsing'
+    (e4s_amd.criteria modules); opt / opt_d: optimisers over net's / disc's trainable parameters; averager / averager_d:
+    ddp.GradAverager (N > 1) or None; net_ema: EMA copy of net or None."""
+
+    def __init__(self, net, disc, crit, opt, opt_d, lo=None, averager=None, averager_d=None, net_ema=None, ema_decay=0.999):
+        self.net, self.disc, self.crit, self.opt, self.opt_d = net, disc, crit, opt, opt_d
+        self.lo = lo or LossOpts()
+        self.averager, self.averager_d, self.net_ema, self.ema_decay = averager, averager_d, net_ema, ema_decay
+        self._net_trainable = [p for p in net.parameters() if p.requires_grad]
+        self.global_step = 0
+
+    # ---- coach.py:403-453 -------------------------------------------------------------------------------------------
+    def calc_loss(self, img, recon):
+        lo, loss, terms = self.lo, 0.0, {}
+        if lo.face_parsing_lambda > 0 and "parsing" in self.crit:
+            terms["parsing"] = self.crit["parsing"](recon, img)[0]
+            loss = loss + terms["parsing"] * lo.face_parsing_lambda
+        if lo.id_lambda > 0 and "id" in self.crit:
+            terms["id"] = self.crit["id"](recon, img)[0]
+            loss = loss + terms["id"] * lo.id_lambda
+        if lo.l2_lambda > 0:
+            terms["l2"] = F.mse_loss(recon, img)
+            loss = loss + terms["l2"] * lo.l2_lambda
+        if lo.lpips_lambda > 0 and "lpips" in self.crit:
+            # the three adaptive_avg_pool2d scales of coach.py:425-434, pooled inside the networks' first pass
+            terms["lpips"] = self.crit["lpips"].forward_pooled(recon, img, lo.lpips_sizes)
+            loss = loss + terms["lpips"] * lo.lpips_lambda
+        return loss, terms
+
+    def generator_loss(self, img, onehot, **fwd):
+        recon, _ = self.net(img, onehot, **fwd)
+        loss, terms = self.calc_loss(img, recon)
+        if self.disc is not None:
+            terms["g_adv"] = adv_g_loss(self.disc(recon))
+            loss = loss + self.lo.g_adv_lambda * terms["g_adv"]
+        return loss, terms, recon
+
+    # ---- coach.py:290-307 -------------------------------------------------------------------------------------------
+    def d_step(self, img, onehot, **fwd):
+        requires_grad(self.disc, True)
+        with torch.no_grad():                       # torch_utils.requires_grad(self.net, False): no graph through the net
+            recon, _ = self.net(img, onehot, **fwd)
+        d_loss = adv_d_loss(self.disc(img), self.disc(recon))
+        self.disc.zero_grad()
+        if self.averager_d is not None:
+            self.averager_d.arm()
+        d_loss.backward()
+        if self.averager_d is not None:
+            self.averager_d.finish()
+        self.opt_d.step()
+        return d_loss.detach()
+
+    # ---- coach.py:309-319 -------------------------------------------------------------------------------------------
+    def r1_step(self, img):
+        requires_grad(self.disc, True)
+        img = img.detach().requires_grad_(True)
+        real_pred = self.disc(img)
+        r1 = d_r1_loss(real_pred, img)
+        self.disc.zero_grad()
+        if self.averager_d is not None:
+            self.averager_d.arm()
+        (self.lo.r1_lambda / 2 * r1 * max(self.lo.d_reg_every, 1) + 0 * real_pred[0]).sum().backward()
+        if self.averager_d is not None:
+            self.averager_d.finish()
+        self.opt_d.step()
+        return r1.detach()
+
+    # ---- coach.py:324-357, 396-398 ----------------------------------------------------------------------------------
+    def g_step(self, img, onehot, **fwd):
+        if self.disc is not None:
+            requires_grad(self.disc, False)
+        for p in self._net_trainable:
+            p.requires_grad = True
+        self.net.zero_grad()
+        loss, terms, _ = self.generator_loss(img, onehot, **fwd)
+        if self.averager is not None:
+            self.averager.arm()                     # bucket all-reduces fire from gradient hooks, under the backward
+        loss.backward()
+        if self.averager is not None:
+            self.averager.finish()
+        self.opt.step()
+        if self.net_ema is not None:
+            accumulate(self.net_ema, self.net, self.ema_decay)
+        return loss.detach(), terms
+
+    def iteration(self, img, onehot, batch_idx=0, **fwd):
+        """One pass of the loop body at self.global_step (coach.py:281-398)."""
+        out = {}
+        lo = self.lo
+        if self.disc is not None and self.opt_d is not None and self.global_step % lo.d_every == 0:
+            out["d_loss"] = self.d_step(img, onehot, **fwd)
+            if lo.d_reg_every != -1 and batch_idx % lo.d_reg_every == 0:
+                out["r1_loss"] = self.r1_step(img)
+        out["loss"], out["terms"] = self.g_step(img, onehot, **fwd)
+        self.global_step += 1
+        return out

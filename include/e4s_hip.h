@@ -334,6 +334,9 @@ int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n
  * the first parameter's call) */
 int e4s_adam_step_dev_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                           double eps, double weight_decay, int64_t* step, int advance, void* stream);
+/* EMA of the weights, torch_utils.accumulate (src/utils/torch_utils.py:189-194; coach.py:396-398):
+ * dst[i] = dst[i] * decay + src[i] * (1 - decay), one launch per tensor */
+int e4s_ema_f32(float* dst, const float* src, int64_t n, double decay, void* stream);
 
 /* ---- device pre/post-processing of the face-swap pipeline ------------------------------- */
 /* labelMap2OneHot (src/utils/torch_utils.py:166-172): labels u8 [B,H,W] -> one-hot fp32 [B,R,H,W] */

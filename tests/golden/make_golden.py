@@ -30,6 +30,8 @@ What is pinned:
 import os
 import sys
 
+os.environ.setdefault("E4S_ALLOW_UNINITIALIZED_LOSS_NETS", "1")     # synthetic state dicts are loaded after construction
+
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -112,7 +112,15 @@ def test_capturable_adam_and_graphed_step_equal_eager():
         a.grad, b.grad = gr.to(DEV).clone(), gr.to(DEV).clone()
         oa.step()
         ob.step()
-    assert maxabs(a, b) < 2e-6 and int(oa._dev_step.item()) == 5
+    assert maxabs(a, b) < 2e-6 and int(oa.state[a]["step"].item()) == 5
+    # the step count is per parameter and travels with state_dict(): a reloaded optimiser continues at t = 6
+    a2 = a.detach().clone().requires_grad_(True)
+    oc = FusedAdam([a2], lr=1e-2, capturable=True)
+    oc.load_state_dict(oa.state_dict())
+    a.grad, a2.grad = grads[0].to(DEV).clone(), grads[0].to(DEV).clone()
+    oa.step()
+    oc.step()
+    assert torch.equal(a.detach(), a2.detach()) and int(oc.state[a2]["step"].item()) == 6
 
     net = Net3(make_opts(out_size=256))
     net.load_state_dict(synth.synth_state_dict(256, 13), strict=True)
@@ -147,7 +155,8 @@ def test_capturable_adam_and_graphed_step_equal_eager():
             gs = GraphedStep(opt, body, warmup=2)
             for _ in range(steps - 2):
                 losses.append(float(gs.step()))
-            assert gs.steps_done == steps and int(gs.flags.item()) == 0
+            assert gs.steps_done == steps
+            gs.validate()
         else:
             for _ in range(steps):
                 opt.zero_grad(set_to_none=True)
@@ -158,3 +167,51 @@ def test_capturable_adam_and_graphed_step_equal_eager():
     assert torch.equal(lat_e, lat_g)
     assert loss_g == loss_e[2:]
     assert loss_e[-1] < loss_e[0]
+
+
+def test_plan_path_replays_in_a_graph_with_other_masks_than_the_captured_one(monkeypatch):
+    """the row-plan statement of region-select (StyledConv.forward(use_plan=True), and the automatic
+    one-region plan of kernels.conv_mfma for per-sample scale rows on maps that are not a multiple of 128 rows) used to be
+    suspect under HIP-graph replay.  Its tables are now initialised by a kernel (plan.hip used to hold the library's only
+    hipMemsetAsync calls) and the consumer bound-checks what it reads.  Here: capture plan build + conv with mask A, replay
+    with masks B, C (different region populations => different tile tables) several times: every replay == eager == oracle."""
+    from e4s_amd import kernels as K
+    from e4s_amd.stylegan2 import StyledConv
+    monkeypatch.setattr(K, "PRECISION", "f32")
+    torch.manual_seed(0)
+    cin = cout = 512
+    res = 16
+    m = StyledConv(cin, cout, 3, 512, mask_op=True).to(DEV)
+    with torch.no_grad():
+        m.noise.weight.fill_(0.1)
+        m.activate.bias.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(3)
+    b = 2
+    x = torch.randn(b, cin, res, res, generator=g).to(DEV)
+    style = torch.randn(b, 12, 512, generator=g).to(DEV)
+    noise = torch.randn(b, 1, res, res, generator=g).to(DEV)
+    masks = [synth.onehot(synth.synth_labels_blocks(b, 512, cells, seed=sd)).to(DEV) for cells, sd in ((16, 7), (4, 8), (64, 9))]
+    static_mask = masks[0].clone()
+    with torch.no_grad():
+        eager = [m(x, style, mk, noise=noise, use_plan=True) for mk in masks]
+        sel = [m(x, style, mk, noise=noise, use_plan=False) for mk in masks]
+    for e, s_ in zip(eager, sel):
+        assert maxabs(e, s_) < 5e-5                                   # plan statement == in-GEMM region-select
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        m(x, style, static_mask, noise=noise, use_plan=True)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    flags = torch.zeros(1, device=DEV, dtype=torch.int32)
+    with K.flag_sink(flags), torch.no_grad():
+        with torch.cuda.graph(graph):
+            out = m(x, style, static_mask, noise=noise, use_plan=True)
+    for rep in range(4):
+        for mk, e in zip(masks[::-1] if rep % 2 else masks, eager[::-1] if rep % 2 else eager):
+            static_mask.copy_(mk)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, e), f"plan-path graph replay {rep} differs from the eager launch"
+    assert int(flags.item()) == 0

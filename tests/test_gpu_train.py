@@ -139,15 +139,47 @@ def test_fused_adam_train_loop_descends():
         for p in net.MLPs.parameters():
             p.add_(torch.randn_like(p) * 0.02)            # perturb; training must pull the output back
     opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
+    from e4s_amd.packs import param_key
+    conv = net.encoder.body[3].res_layer[1]
     losses = []
     for _ in range(4):
         opt.zero_grad()
         out, _ = net(img, mask, randomize_noise=False)
         loss = torch.nn.functional.mse_loss(out, target)
         loss.backward()
+        key, w_before = param_key(conv.weight), conv.weight.detach().clone()
         opt.step()
+        # the fused update writes through raw pointers; it must still advance the version counter, or the encoder's cached
+        # weight packs (keyed on data_ptr + _version) would keep serving the pre-step weights to every later forward
+        assert param_key(conv.weight) != key and not torch.equal(conv.weight.detach(), w_before)
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
+
+
+def test_encoder_forward_sees_the_optimizer_update():
+    """Train ONLY one encoder conv weight with a large step: the next forward must differ from the previous one (it runs
+    through the re-packed weight), and must equal a fresh module loaded with the updated state dict."""
+    from e4s_amd.optim import FusedAdam
+    net, _, _ = _net(256)
+    net.train()
+    for p in net.parameters():
+        p.requires_grad = False
+    w = net.encoder.body[5].res_layer[3].weight
+    w.requires_grad = True
+    img = synth.synth_image(1, 1024, tag="upd_img").to(DEV)
+    mask = synth.onehot(synth.synth_labels_face(1, 512, seed=5)).to(DEV)
+    opt = FusedAdam([w], lr=1e-2)
+    out0, _ = net(img, mask, randomize_noise=False)
+    out0.square().mean().backward()
+    opt.step()
+    with torch.no_grad():
+        out1, _ = net(img, mask, randomize_noise=False)
+    assert maxabs(out0, out1) > 1e-5
+    net2, _, _ = _net(256)
+    net2.load_state_dict(net.state_dict(), strict=True)
+    with torch.no_grad():
+        out2, _ = net2.eval()(img, mask, randomize_noise=False)
+    assert maxabs(out1, out2) < 1e-6
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,stride,ntaps", [(2, 16, 32, 64, 128, 1, 9), (1, 20, 12, 96, 32, 1, 9), (2, 16, 16, 128, 64, 2, 9),
@@ -169,3 +201,140 @@ def test_conv_wgrad_kernel_vs_fp64(b, h, w, cin, cout, stride, ntaps):
     assert maxabs(got, wt.grad) < 2e-5 * float(wt.grad.abs().max())
     dw2 = K.conv_wgrad(K.nchw_to_nhwc(gz.float().to(DEV)), K.nchw_to_nhwc(x.float().to(DEV)), ntaps=ntaps, istride=stride)
     assert torch.equal(dw, dw2)                                        # ordered split-K: bit-reproducible
+
+
+def _loss_modules(size):
+    """The generator step's loss networks + Discriminator on seeded synthetic weights (modules on the GPU, state dicts for the
+    oracle)."""
+    import types
+    from e4s_amd.criteria import FaceParsingLoss, IDLoss, LPIPS
+    from e4s_amd.stylegan2 import Discriminator
+    lp, idl, fpl = LPIPS(), IDLoss(types.SimpleNamespace(id_loss_multiscale=True)), FaceParsingLoss(types.SimpleNamespace())
+    sds = {}
+    for m, tag, key in ((lp, "lp.", "lpips"), (idl, "id.", "id"), (fpl, "fp.", "parsing")):
+        sds[key] = synth.synth_module_state_dict(m, 0, tag)
+        m.load_state_dict(sds[key])
+    disc = Discriminator(size)
+    sds["disc"] = synth.synth_disc_state_dict(size)
+    disc.load_state_dict(sds["disc"], strict=True)
+    crit = {"lpips": lp.to(DEV).eval(), "id": idl.to(DEV).eval(), "parsing": fpl.to(DEV).eval()}
+    return crit, disc.to(DEV).eval(), sds
+
+
+def test_net3_full_loss_generator_step_gradients_vs_oracle_f64():
+    """the loss config 5 is BENCHED with -- coach.py:403-453's default terms (parsing * 0.1 + ID * 0.1 + l2 +
+    LPIPS x3 * 0.8) + g_adv_lambda * AdvGLoss through the native Discriminator graph (adv_loss.py:8-16) -- as ONE chain:
+    loss networks' image gradients -> generator dgrad -> LocalMLP / encoder weight gradients.  out_size 256, batch 2; every
+    trainable Net3 parameter's gradient vs the oracle's fp64 autograd of the same objective (relative L2, the metric of
+    test_net3_train_step_gradients_vs_oracle_autograd); the SE fc gradients (rounding residue of an exactly-zero input) are
+    asserted to be ~0 on BOTH sides."""
+    import torch.nn.functional as F
+    from e4s_amd.train import LossOpts, TrainIteration
+    size, b = 256, 2
+    net, sd, lat = _net(size)
+    net.train()
+    crit, disc, sds = _loss_modules(size)
+    for p in disc.parameters():
+        p.requires_grad = False
+    img = synth.synth_image(b, size, tag="full_img")
+    mask = synth.onehot(synth.synth_labels_face(b, 512, seed=31))
+    noise = synth.synth_noise(size)
+    for i, nz in enumerate(noise):
+        getattr(net.G.noises, f"noise_{i}").copy_(nz.to(DEV))
+    lo = LossOpts(lpips_sizes=(256, 128, 64))            # coach.py:425-434 pools to 1024 / 512 / 256 of a 1024^2 output
+    it = TrainIteration(net, disc, crit, opt=None, opt_d=None, lo=lo)
+    loss, terms, recon = it.generator_loss(img.to(DEV), mask.to(DEV), randomize_noise=False)
+    loss.backward()
+
+    # ---- oracle, fp64 ----
+    d64 = lambda d_: {k: v.double() for k, v in d_.items()}
+    sd_r = {k: (v.double().requires_grad_(True) if (k.startswith("encoder.") or k.startswith("MLPs.")) else v.double())
+            for k, v in sd.items()}
+    x64, m64 = img.double(), mask.double()
+    # Net3.forward resizes the input to 1024 first only when resize=True; get_style_vectors takes the image as is
+    sv, _ = orc.get_style_vectors(sd_r, x64, m64)
+    codes = orc.cal_style_codes(sd_r, sv, lat.double(), 13)
+    out_r, _ = orc.gen_img(sd_r, codes, m64, [n.double() for n in noise], size, 13)
+    l_par, _ = orc.face_parsing_loss(d64(sds["parsing"]), out_r, x64)
+    l_id, _ = orc.id_loss(d64(sds["id"]), out_r, x64)
+    l_l2 = F.mse_loss(out_r, x64)
+    l_lp = orc.lpips_multiscale(d64(sds["lpips"]), out_r, x64, sizes=lo.lpips_sizes)
+    l_adv = F.softplus(-orc.discriminator_forward(d64(sds["disc"]), out_r, size)).mean()
+    loss_r = 0.1 * l_par + 0.1 * l_id + 1.0 * l_l2 + 0.8 * l_lp + 0.01 * l_adv
+    loss_r.backward()
+
+    assert maxabs(recon, out_r) < 1e-3
+    for name, got, ref in (("parsing", terms["parsing"], l_par), ("id", terms["id"], l_id), ("l2", terms["l2"], l_l2),
+                           ("lpips", terms["lpips"], l_lp), ("g_adv", terms["g_adv"], l_adv)):
+        assert abs(float(got) - float(ref)) < 2e-4 * max(1.0, abs(float(ref))), (name, float(got), float(ref))
+    assert abs(float(loss) - float(loss_r)) < 1e-4 * abs(float(loss_r))
+    worst_l2, worst_name, checked, se_checked = 0.0, "", 0, 0
+    gscale = max(float(sd_r[n].grad.abs().max()) for n, p in net.named_parameters() if p.requires_grad and ".fc" not in n)
+    for name, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        ref = sd_r[name].grad
+        if ".fc1." in name or ".fc2." in name:
+            # SE input = spatial mean of an instance-normalised map = rounding residue (helpers.py:64-66): ~0 on both sides
+            assert float(ref.abs().max()) < 1e-6 * gscale and float(p.grad.abs().max()) < 1e-3 * gscale, name
+            se_checked += 1
+            continue
+        d = p.grad.detach().cpu().double() - ref
+        l2 = float(d.norm() / ref.norm().clamp_min(1e-30))
+        if l2 > worst_l2:
+            worst_l2, worst_name = l2, name
+        checked += 1
+        assert l2 < 2e-3, (name, l2)
+    print(f"full-loss generator step: {checked} parameter tensors (+{se_checked} SE fc tensors ~0 on both sides) vs fp64 autograd: "
+          f"worst relative L2 gradient error {worst_l2:.3e} ({worst_name})")
+    assert checked > 100 and se_checked == 48
+
+
+def test_d_step_and_r1_step_vs_oracle_f64():
+    """coach.py:290-319 on the native Discriminator graph: AdvDLoss gradients and the R1 step's second-order gradients of every
+    Discriminator parameter vs the oracle's fp64 autograd; the fused Adam then moves every parameter."""
+    import torch.nn.functional as F
+    from e4s_amd.optim import FusedAdam
+    from e4s_amd.train import LossOpts, TrainIteration, adv_d_loss
+    size, b = 64, 4
+    from e4s_amd.stylegan2 import Discriminator
+    disc = Discriminator(size)
+    sdd = synth.synth_disc_state_dict(size)
+    disc.load_state_dict(sdd, strict=True)
+    disc = disc.to(DEV).train()
+    real = synth.synth_image(b, size, tag="d_real")
+    fake = synth.synth_image(b, size, tag="d_fake")
+
+    class _FakeNet(torch.nn.Module):                      # stands in for Net3.forward in the D step (no graph through it)
+        def forward(self, img, onehot, **kw):
+            return fake.to(DEV), None
+    opt_d = FusedAdam(disc.parameters(), lr=1e-3)
+    it = TrainIteration(_FakeNet(), disc, {}, opt=None, opt_d=opt_d, lo=LossOpts(d_reg_every=16))
+    before = {k: v.detach().clone() for k, v in disc.named_parameters()}
+    d_loss = it.d_step(real.to(DEV), None)
+    grads_d = {k: p.grad.detach().clone() for k, p in disc.named_parameters()}
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sdd.items()}
+    l64 = adv_d_loss(orc.discriminator_forward(sd64, real.double(), size), orc.discriminator_forward(sd64, fake.double(), size))
+    l64.backward()
+    assert abs(float(d_loss) - float(l64)) < 1e-4 * max(1.0, abs(float(l64)))
+    for k, g_ in grads_d.items():
+        ref = sd64[k].grad
+        assert float((g_.cpu().double() - ref).norm() / ref.norm().clamp_min(1e-30)) < 2e-3, k
+        assert not torch.equal(before[k], dict(disc.named_parameters())[k].detach()), k          # Adam moved it
+    # ---- R1 (second order) on the UPDATED weights ----
+    now = {k: v.detach().clone() for k, v in disc.named_parameters()}
+    r1 = it.r1_step(real.to(DEV))
+    sd64 = {k: v.cpu().double().requires_grad_(True) for k, v in now.items()}
+    x64 = real.double().requires_grad_(True)
+    pred = orc.discriminator_forward(sd64, x64, size)
+    gr, = torch.autograd.grad(pred.sum(), x64, create_graph=True)
+    pen = gr.pow(2).reshape(b, -1).sum(1).mean()
+    (10.0 / 2 * pen * 16 + 0 * pred[0]).sum().backward()
+    assert abs(float(r1) - float(pen)) < 2e-4 * max(1e-6, abs(float(pen)))
+    for k, p in disc.named_parameters():
+        ref = sd64[k].grad
+        if ref is None or float(ref.abs().max()) == 0.0:          # biases that only shift the logit: zero second-order gradient
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-6
+            continue
+        assert float((p.grad.cpu().double() - ref).norm() / ref.norm()) < 3e-3, k

@@ -272,3 +272,37 @@ def test_loss_network_parameter_folds_match_torch():
     bn.weight.data[3] = 0.0
     with pytest.raises(RuntimeError):
         C._bn_stats(bn, 3)
+
+
+def test_loss_networks_refuse_to_run_without_weights(monkeypatch):
+    """the reference always loads trained weights into IDLoss / LPIPS / FaceParsingLoss
+    (id_loss.py:15, lpips/utils.py:11-20, face_parsing_loss.py:29); the native classes must not silently stay random."""
+    import types
+    from e4s_amd import criteria as C
+    monkeypatch.setattr(C, "ALLOW_UNINITIALIZED", False)
+    monkeypatch.delenv("E4S_LPIPS_WEIGHTS", raising=False)
+    with pytest.raises(FileNotFoundError):
+        C.IDLoss(types.SimpleNamespace(ir_se50_path="/nonexistent/irse50.pth"))
+    with pytest.raises(FileNotFoundError):
+        C.IDLoss(types.SimpleNamespace())
+    with pytest.raises(FileNotFoundError):
+        C.FaceParsingLoss(types.SimpleNamespace())
+    with pytest.raises(FileNotFoundError):
+        C.LPIPS()
+    monkeypatch.setattr(C, "ALLOW_UNINITIALIZED", True)
+    C.LPIPS()                                                   # synthetic-weight runs opt in explicitly
+
+
+def test_target_feature_cache_holds_the_target_tensor():
+    """the cache entry keeps the target alive, so a freed target's address cannot be handed to a new
+    image that then hits the old entry; a different tensor object never hits, whatever its pointer/version."""
+    from e4s_amd import criteria as C
+    y1 = torch.zeros(1, 3, 8, 8)
+    k1 = C._target_key(y1)
+    entry = (k1, y1, "feats")
+    y2 = torch.zeros(1, 3, 8, 8)
+    assert entry[1] is not y2                                   # identity is part of the hit test (see _target_feats)
+    y1.add_(1.0)
+    assert C._target_key(y1) != k1                              # in-place edits miss as well
+    src = open(os.path.join(ROOT, "e4s_amd", "criteria.py")).read()
+    assert src.count("self._target[1] is not y") == 3           # all three loss classes use the guarded hit test

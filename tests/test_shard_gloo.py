@@ -214,3 +214,105 @@ def test_gloo_world2_gradient_averaging_equals_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+class _MonolithFn(torch.autograd.Function):
+    """Stand-in for encoder_autograd.EncoderFn: ONE backward node that produces the gradients of several parameters, last
+    layer first, and announces each as soon as it exists (ddp.notify_grad) -- long before autograd accumulates them."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3):
+        h1 = x @ w1.t()
+        h2 = torch.relu(h1) @ w2.t()
+        ctx.save_for_backward(x, w1, w2, w3, h1, h2)
+        return torch.relu(h2) @ w3.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        from e4s_amd.ddp import notify_grad
+        x, w1, w2, w3, h1, h2 = ctx.saved_tensors
+        fired = []
+        g3 = gy.t() @ torch.relu(h2)
+        notify_grad(ctx.params[2], g3)
+        fired.append(ctx.avg.fired_during_backward)
+        gh2 = (gy @ w3) * (h2 > 0)
+        g2 = gh2.t() @ torch.relu(h1)
+        notify_grad(ctx.params[1], g2)
+        fired.append(ctx.avg.fired_during_backward)
+        gh1 = (gh2 @ w2) * (h1 > 0)
+        g1 = gh1.t() @ x
+        notify_grad(ctx.params[0], g1)
+        fired.append(ctx.avg.fired_during_backward)
+        ctx.log.extend(fired)
+        return None, g1, g2, g3
+
+
+def _worker_ddp_overlap(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from e4s_amd.ddp import GradAverager
+    torch.manual_seed(0)
+    # "encoder" (monolithic node) followed by an ordinary torch head (hook-driven), as Net3 = EncoderFn -> LocalMLPs -> G
+    enc = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(64, 40) * 0.1), torch.nn.Parameter(torch.randn(64, 64) * 0.1),
+                                  torch.nn.Parameter(torch.randn(32, 64) * 0.1)])
+    head = torch.nn.Sequential(torch.nn.Linear(32, 300), torch.nn.ReLU(), torch.nn.Linear(300, 3))
+    params = list(enc) + list(head.parameters())
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 40, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    lo, hi = shard.shard_range(8, world, rank)
+    avg = GradAverager(params, bucket_mb=0.02)                  # tiny buckets: several collectives
+    log = []
+
+    def backward():
+        for p in params:
+            p.grad = None
+
+        class Fn(_MonolithFn):
+            pass
+        # the Function needs the parameter OBJECTS to announce them; ctx attributes are set through a thin subclass call
+        orig = _MonolithFn.forward
+
+        def fwd(ctx, xx, a, b, c):
+            ctx.params, ctx.avg, ctx.log = list(enc), avg, log
+            return orig(ctx, xx, a, b, c)
+        Fn.forward = staticmethod(fwd)
+        out = head(Fn.apply(x[lo:hi], *enc))
+        return torch.nn.functional.mse_loss(out, y[lo:hi])
+
+    # (a) overlapped: buckets fire from hooks / from inside the monolithic node
+    loss = backward()
+    avg.arm()
+    loss.backward()
+    fired = avg.fired_during_backward
+    avg.finish()
+    overl = [p.grad.clone() for p in params]
+    # (b) post-hoc: the same gradients averaged after backward
+    loss = backward()
+    loss.backward()
+    avg.average()
+    post = [p.grad.clone() for p in params]
+    ok = all(torch.equal(a, b) for a, b in zip(overl, post))
+    ok = ok and fired >= 2 and len(avg.buckets) >= 3
+    # head buckets had left before the monolithic node started, and more left while it was still running
+    ok = ok and log[0] >= 1 and log[-1] >= log[0]
+    q.put((rank, ok, fired, len(avg.buckets), log[:3]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_overlapped_bucket_allreduce_equals_post_hoc():
+    """bucket all-reduces launched from gradient hooks and from inside a monolithic backward node (the
+    encoder's) give bit-identical averages to the post-backward form, and really leave before backward() returns."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ddp_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
