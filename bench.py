@@ -214,6 +214,37 @@ def gpen_leg(dev, reps=10):
     return out
 
 
+def stitch_leg(net, inputs, reps=10):
+    """SURVEY.md 8(f) N4 on the device, after the swap (scripts/face_swap.py:253-310): head-mask swap of the parsing maps ->
+    (the generator output of the timed step) -> tensor2im -> foreground / create_masks -> default stitch (mask image, 11x11
+    erode, fixed-point Gaussian, PIL-style alpha composite) or --lap_bld (paste + 10-level Laplacian pyramid blend) -> uint8
+    HWC.  Batch of 8 at 1024^2; ms per batch, generator excluded (it is the timed step)."""
+    from e4s_amd import postproc as PP
+    driven, dm, target, tm, sm, noise = inputs
+    b = driven.shape[0]
+    src_lab = dm.argmax(1).to(torch.uint8).contiguous()
+    tgt_lab = tm.argmax(1).to(torch.uint8).contiguous()
+    tgt_u8 = PP.tensor2im(target)
+    with torch.no_grad():
+        img = face_swap_core(net, driven, dm, target, tm, sm, noise=noise)
+    out = {}
+    for name, lap in (("default_ms", False), ("lap_bld_ms", True)):
+        def run():
+            lab, hole = PP.swap_head_mask_revisit_considerGlass(src_lab, tgt_lab)
+            return PP.stitch(img, tgt_u8, lab, hole, lap_bld=lap)
+        for _ in range(2):
+            res = run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = run()
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+    out["batch"] = b
+    out["out"] = f"uint8 {list(res.shape)}"
+    return out
+
+
 def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3):
     """BASELINE.json configs[4] on ONE GPU -- the body of Coach.train() (coach.py:280-398) through e4s_amd.train.TrainIteration:
     G step = Net3.forward (encoder + LocalMLPs trainable, G frozen: SURVEY.md 8(d)'s opts) on a batch of 2
@@ -311,9 +342,12 @@ def build_parser():
     ap.add_argument("--train-only", action="store_true", help="run only the configs[4] train-step legs")
     ap.add_argument("--opt-modes", default="full,mse",
                     help="config-3 legs to run: full = l2 + LPIPS x3 + ID + parsing, mse = l2 only")
-    ap.add_argument("--opt-graph", action="store_true",
-                    help="replay each config-3 step as one HIP graph (e4s_amd.optim.GraphedStep): 11.6 vs 11.9 ms on the l2-only "
-                         "step, 20.4 vs ~25 ms with the LPIPS and identity terms")
+    ap.add_argument("--opt-eager", dest="opt_graph", action="store_false",
+                    help="enqueue the config-3 steps eagerly; the default replays each step -- generator forward, the four loss "
+                         "terms, backward, capturable Adam -- as ONE HIP graph (e4s_amd.optim.GraphedStep; bit-identical to the "
+                         "eager loop, tests/test_gpu_optim.py)")
+    ap.add_argument("--opt-graph", dest="opt_graph", action="store_true", help="(default) see --opt-eager")
+    ap.set_defaults(opt_graph=True)
     ap.add_argument("--opt-steps", type=int, default=200,
                     help="configs[2] leg: run this many W+ optimisation steps (scripts/optimization.py runs 200: "
                          "cal_style_codes + 1024^2 generator fwd + MSE + bwd + Adam each) and report the measured total")
@@ -526,6 +560,7 @@ def main():
             except Exception as e:      # noqa: BLE001
                 out[(key or "config3") + "_error"] = f"{type(e).__name__}: {e}"[:300]
         side("gpen512", lambda: gpen_leg(dev))
+        side("stitch_b8", lambda: stitch_leg(net, inputs))
         if args.train_steps > 0:
             side("config5_train_step_1gpu", lambda: train_leg(dev, lat, args.train_steps, losses="full"))
             side("config5_train_step_1gpu_mse_only", lambda: train_leg(dev, lat, args.train_steps, losses="mse"))

@@ -99,6 +99,36 @@ __global__ void batch_sum_kernel(const float* __restrict__ x, float* __restrict_
     out[i] = s;
 }
 
+// part[blk][c] = sum of rows [blk*rpb, (blk+1)*rpb) of x [rows][C] (C % 4 == 0, C <= 1024): thread = (float4 column, row lane);
+// every thread adds its rows in order, the row lanes are added in order -> with the ordered e4s_reduce_parts_f32 behind it the
+// column sum is bit-reproducible.  (Bias gradients of the Discriminator's FusedLeakyReLUs: rows = B * H * W up to 2 M at 1024^2;
+// e4s_batch_sum_f32's one-thread-per-output loop took seconds there.)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ part, int64_t rows, int C,
+                                                     int rpb) {
+    __shared__ f32x4 sm[256];
+    const int c4n = C >> 2, lanes = 256 / c4n;
+    const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = min(r0 + rpb, rows);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (rl < lanes)
+        for (int64_t r = r0 + rl; r < r1; r += lanes) acc += *reinterpret_cast<const f32x4*>(x + r * C + c4 * 4);
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        f32x4 s = sm[c4];
+        for (int l = 1; l < lanes; ++l) s += sm[l * c4n + c4];
+        *reinterpret_cast<f32x4*>(part + (int64_t)blockIdx.x * C + c4 * 4) = s;
+    }
+}
+
+inline int colsum_rpb(int64_t rows, int C) {
+    // ~2048 rows of work per block, but never more than 1024 blocks (e4s_reduce_parts_f32's two ordered levels)
+    int64_t rpb = 2048;
+    while ((rows + rpb - 1) / rpb > 1024) rpb *= 2;
+    (void)C;
+    return (int)rpb;
+}
+
 // torch.optim.Adam (no amsgrad, maximize=False), one fused pass: the arithmetic of its single-tensor path
 //   g += wd * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
@@ -223,6 +253,21 @@ extern "C" int e4s_batch_sum_f32(const float* x, float* out, int B, int64_t n, v
     hipLaunchKernelGGL(batch_sum_kernel, grid1(n), dim3(256), 0, as_stream(stream), x, out, B, n);
     E4S_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int64_t e4s_colsum_ws_floats(int64_t rows, int C) {
+    const int rpb = colsum_rpb(rows, C);
+    return e4s_reduce_parts_ws_floats((int)((rows + rpb - 1) / rpb), C);
+}
+
+extern "C" int e4s_colsum_f32(const float* x, float* out, float* ws, int64_t rows, int C, void* stream) {
+    if (C % 4 || C > 1024 || C <= 0 || !ws) return (int)hipErrorInvalidValue;
+    if (rows <= 0) return (int)hipErrorInvalidValue;
+    const int rpb = colsum_rpb(rows, C);
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), x, ws, rows, C, rpb);
+    E4S_CHECK_LAUNCH();
+    return e4s_reduce_parts_f32(ws, out, nblk, C, 1.f, stream);
 }
 
 extern "C" int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,

@@ -282,7 +282,7 @@ class ColSum(Function):
     @staticmethod
     def forward(ctx, x):
         ctx.shape = tuple(x.shape)
-        return K.batch_sum(x.contiguous().view(-1, x.shape[-1]))
+        return K.colsum(x.contiguous())
 
     @staticmethod
     def backward(ctx, g):

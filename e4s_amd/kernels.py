@@ -401,6 +401,51 @@ def upconv_mfma(x, w3, cout, k4, *, in_scale=None, out_scale=None, labels=None, 
     return y
 
 
+def subpixel_weights(w):
+    """w [Cout,Cin,3,3] -> [4 shifts, 4*Cout, Cin]: the sub-pixel GEMM operand of e4s_upconv_bf16x3_f32 (csrc/upconv_bf16x3.hip)."""
+    w = _f32(w)
+    cout, cin = w.shape[:2]
+    out = torch.empty(4, 4 * cout, cin, device=w.device, dtype=torch.float32)
+    call("e4s_subpixel_weights_f32", fptr(w), fptr(out), cout, cin, stream())
+    return out
+
+
+def upconv_bf16x3_eligible(cin, cout):
+    return cin % 32 == 0 and cout % 32 == 0
+
+
+def upconv_bf16x3(x, w_sub_split, cout, k4, *, in_scale=None, out_scale=None, noise=None, noise_w=None, bias=None, act=0,
+                  alpha=0.2, gain=LRELU_GAIN, out=None):
+    """Exact transposed conv + blur + noise + bias + act on the split-bf16 matrix-core path, one style per sample.
+    x NHWC [B,H,W,Cin]; w_sub_split = split_bf16x2(subpixel_weights(w)); k4 the 4x4 blur kernel (device) -> NHWC [B,2H,2W,Cout]."""
+    b, hi, wi, cin = x.shape
+    ho, wo = 2 * hi, 2 * wi
+    y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32) if out is None else out
+    p = ConvParams()
+    p.x, p.w, p.y = fptr(x), fptr(w_sub_split), fptr(y)
+    p.y_cstride = y.shape[3] if out is not None else 0
+    p.rows = p.tiles = p.meta = None
+    p.tiles_cap = 0
+    p.B, p.Ha, p.Wa = b, hi, wi
+    p.Hi, p.Wi, p.Ho, p.Wo, p.Cin, p.Cout = hi, wi, ho, wo, cin, cout
+    p.istride, p.ostride, p.ntaps, p.ncls = 1, 2, 9, 1
+    p.in_scale, p.out_scale = fptr(in_scale), fptr(out_scale)
+    p.groups_per_batch = 1
+    p.labels, p.Hm, p.Wm = None, 0, 0
+    if noise is not None:
+        p.noise, p.noise_w = fptr(noise), fptr(noise_w)
+        p.noise_bstride = ho * wo if noise.shape[0] > 1 else 0
+    else:
+        p.noise = p.noise_w = None
+        p.noise_bstride = 0
+    p.noise_per_channel = 0
+    p.bias, p.slope = fptr(bias), None
+    p.act, p.alpha, p.gain = act, alpha, gain
+    ws = torch.empty(lib.load().e4s_upconv_bf16x3_ws_floats(ctypes.byref(p)), device=x.device, dtype=torch.float32)
+    call("e4s_upconv_bf16x3_f32", ctypes.byref(p), fptr(_f32(k4)), fptr(ws), stream())
+    return y
+
+
 def torgb(x, ws, bias, skip, k4, labels, num_regions):
     """x NHWC [B,H,W,Cin]; ws [G,3,Cin]; skip NCHW [B,3,H/2,W/2] or None -> NCHW [B,3,H,W]."""
     b, h, w, cin = x.shape
@@ -539,6 +584,19 @@ def batch_sum(x):
     x = _f32(x)
     out = torch.empty(x.shape[1:], device=x.device, dtype=torch.float32)
     call("e4s_batch_sum_f32", fptr(x), fptr(out), x.shape[0], out.numel(), stream())
+    return out
+
+
+def colsum(x):
+    """[C] = sum over every dim but the last of a contiguous channels-last tensor (ordered two-level reduction)."""
+    x = _f32(x)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    if rows <= 64 or c % 4 or c > 1024:
+        return batch_sum(x.view(rows, c))
+    out = torch.empty(c, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.load().e4s_colsum_ws_floats(rows, c), device=x.device, dtype=torch.float32)
+    call("e4s_colsum_f32", fptr(x), fptr(out), fptr(ws), rows, c, stream())
     return out
 
 

@@ -37,6 +37,8 @@ from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix
 # pixel) or the polyphase form on the generic conv kernel (36).  Same function, different rounding order.
 UPCONV_EXACT = os.environ.get("E4S_UPCONV", "exact") != "polyphase"
 UPCONV_EXACT_MIN_RES = int(os.environ.get("E4S_UPCONV_MIN_RES", "256"))     # masked layers below this stay polyphase
+# unmasked up-convs under E4S_PRECISION=auto/bf16x3: exact sub-pixel GEMM (csrc/upconv_bf16x3.hip) unless "polyphase" is asked for
+UPCONV_BF16X3_EXACT = os.environ.get("E4S_UPCONV_BF16X3", "exact") != "polyphase"
 
 
 def make_kernel(k):
@@ -207,6 +209,14 @@ class ModulatedConv2d(nn.Module):
         self._pack = pack
         return pack
 
+    def subpixel_split_weights(self):
+        """Split-bf16 image of the sub-pixel GEMM operand of e4s_upconv_bf16x3_f32 (exact up-conv; cached with the pack)."""
+        pk = self.packed()
+        if "w_sub_split" not in pk:
+            with torch.no_grad():
+                pk["w_sub_split"] = K.split_bf16x2(K.subpixel_weights(self.weight.detach()[0].float().contiguous()))
+        return pk["w_sub_split"]
+
     def split_weights(self):
         """Split-bf16 image of packed()["w"] for e4s_conv_bf16x3_f32 (built on first use, cached with the pack)."""
         pk = self.packed()
@@ -297,6 +307,14 @@ class StyledConv(nn.Module):
                 raise NotImplementedError("backward with per-channel noise maps")
             rec.update(d=d, noise=nz)
         ncls = 4 if conv.upsample else 1
+        if (conv.upsample and labels is None and plan is None and not per_ch and UPCONV_BF16X3_EXACT
+                and K.upconv_bf16x3_eligible(conv.in_channel, conv.out_channel)
+                and K.want_bf16x3(b, h, w, conv.in_channel, conv.out_channel, ncls, masked=False)):
+            # unmasked up-conv: the exact transposed conv as a sub-pixel GEMM on the split-bf16 path (9 Cin Cout MACs per
+            # input pixel instead of the polyphase form's 36) + one FIR / noise / bias / activation pass
+            return K.upconv_bf16x3(x, conv.subpixel_split_weights(), conv.out_channel, conv.blur.kernel, in_scale=s,
+                                   out_scale=d, noise=nz, noise_w=self.noise.weight, bias=self.activate.bias, act=1,
+                                   alpha=self.activate.negative_slope, gain=self.activate.scale)
         if plan is None and not per_ch and K.want_bf16x3(b, h, w, conv.in_channel, conv.out_channel, ncls,
                                                          masked=labels is not None):
             # split-bf16 matrix-core path (polyphase form for up-convs: 4x the MACs of the exact kernel at > 3x its rate)

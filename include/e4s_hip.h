@@ -325,6 +325,10 @@ int64_t e4s_reduce_parts_ws_floats(int nparts, int64_t n);
 /* dw[r,o,k] = scale * sum_b g[b,r,o] * h[b,r,k] (LocalMLP weight gradients);  out[i] = sum_b x[b*n + i] (bias gradients) */
 int e4s_grouped_outer_f32(const float* g, const float* h, float* dw, int B, int R, int O, int K, float scale, void* stream);
 int e4s_batch_sum_f32(const float* x, float* out, int B, int64_t n, void* stream);
+/* out[c] = sum_r x[r*C + c] over a tall [rows][C] matrix (C % 4 == 0, C <= 1024): bias gradients of channels-last activations
+ * (rows = B*H*W); two ordered levels, bit-reproducible; ws: e4s_colsum_ws_floats(rows, C) floats */
+int e4s_colsum_f32(const float* x, float* out, float* ws, int64_t rows, int C, void* stream);
+int64_t e4s_colsum_ws_floats(int64_t rows, int C);
 /* torch.optim.Adam's update (no amsgrad) fused into one pass over p/grad/m/v [n]; `step` >= 1 is the step being taken;
  * bias corrections are evaluated in double on the host as torch does */
 int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
@@ -334,6 +338,37 @@ int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n
  * the first parameter's call) */
 int e4s_adam_step_dev_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                           double eps, double weight_decay, int64_t* step, int advance, void* stream);
+/* Exact up-sampling StyledConv on the split-bf16 matrix-core path (csrc/upconv_bf16x3.hip): conv_transpose2d(stride 2) +
+ * Blur (src/models/stylegan2/model.py:287-300, 206-213) + NoiseInjection + FusedLeakyReLU (:396-404) at 9 Cin Cout MACs per
+ * input pixel, one style per sample (unmasked layers, model.py:655-657).  e4s_subpixel_weights_f32: w [Cout,Cin,3,3] ->
+ * [4 shifts][4 Cout][Cin] (the caller then splits it with e4s_split_bf16x2_f32).  p: x / y NHWC, w = that split image,
+ * in_scale [B,Cin] | NULL, out_scale [B,Cout] | NULL, noise / bias / act / alpha / gain as e4s_conv_bf16x3_f32; k4: device
+ * pointer to the 4x4 blur taps; ws: e4s_upconv_bf16x3_ws_floats(p) floats (the (2H+2)x(2W+2) intermediate of one launch group). */
+int e4s_subpixel_weights_f32(const float* w, float* out, int Cout, int Cin, void* stream);
+int64_t e4s_upconv_bf16x3_ws_floats(const e4s_conv_params* p);
+int e4s_upconv_bf16x3_f32(const e4s_conv_params* p, const float* k4, float* ws, void* stream);
+
+/* ---- stitching the swapped face back onto the target on the device (csrc/stitch.hip) ----
+ * scripts/face_swap.py:81-97 smooth_face_boundry = e4s_erode_u8 (cv2.erode, flat (2r+1)^2, BORDER_CONSTANT) ->
+ * e4s_gaussian_blur_u8 (cv2.GaussianBlur on CV_8U: 8.8 fixed-point taps summing to 256, exact integer passes, one rounding;
+ * BORDER_REFLECT_101) -> e4s_alpha_composite_u8 (PIL Image.alpha_composite onto an opaque target, RGB of the result).
+ * e4s_mask_to_u8: 255 * uint8(bilinear resize of a [B,Hm,Wm] fp32 mask) (face_swap.py:291-294).
+ * src/utils/multi_band_blending.py:4-75: e4s_pyrdown_{u8,f32} / e4s_pyrup_f32 (cv2.pyrDown / pyrUp, HWC images),
+ * e4s_lap_level_f32 (one pyramid level of the blend, optionally + the up-sampled reconstruction), e4s_clip_u8.
+ * All images HWC; masks and alpha [B,H,W]. */
+int e4s_mask_to_u8(const float* mask, uint8_t* out, int B, int H, int W, int Hm, int Wm, void* stream);
+int e4s_erode_u8(const uint8_t* src, uint8_t* dst, int B, int H, int W, int radius, int border_value, void* stream);
+int e4s_gaussian_blur_u8(const uint8_t* src, uint8_t* dst, int B, int H, int W, int ksize, const int* taps_fixed8, void* stream);
+int e4s_alpha_composite_u8(const uint8_t* face, const uint8_t* target, const uint8_t* alpha, uint8_t* out, int B, int H, int W,
+                           void* stream);
+int e4s_pyrdown_u8(const uint8_t* src, uint8_t* dst, int B, int H, int W, int C, void* stream);
+int e4s_pyrdown_f32(const float* src, float* dst, int B, int H, int W, int C, void* stream);
+int e4s_pyrup_f32(const float* src, float* dst, int B, int h, int w, int C, void* stream);
+int e4s_u8_to_f32(const uint8_t* src, float* dst, int64_t n, void* stream);
+int e4s_lap_level_f32(const void* a, const float* ua, const void* b, const float* ub, const float* m, const float* acc,
+                      float* out, int64_t n, int a_is_u8, void* stream);
+int e4s_clip_u8(const float* src, uint8_t* dst, int64_t n, void* stream);
+
 /* EMA of the weights, torch_utils.accumulate (src/utils/torch_utils.py:189-194; coach.py:396-398):
  * dst[i] = dst[i] * decay + src[i] * (1 - decay), one launch per tensor */
 int e4s_ema_f32(float* dst, const float* src, int64_t n, double decay, void* stream);

@@ -453,6 +453,172 @@ def paste_u8(face_u8, target_u8, content_mask):
     return (face_u8.float() * m + target_u8.float() * (1 - m)).to(torch.uint8)
 
 
+# ---- stitching (scripts/face_swap.py:81-97, 276-310; src/utils/multi_band_blending.py) ---------------------------------------
+# OpenCV (opencv-python 4.7.0.72, e4s_env.yaml:96) is a third-party dependency that is NOT in this container: cv2.erode,
+# cv2.GaussianBlur (CV_8U fixed-point path), cv2.pyrDown and cv2.pyrUp are restated below from OpenCV 4.x's published
+# algorithms (imgproc/src/morph, smooth.dispatch.cpp, pyramids.cpp).  PARITY UNPINNED for these four: no cv2 here to
+# generate golden vectors.  PIL IS here: the alpha composite below calls the reference's own PIL code path.
+def cv2_erode_u8(mask, radius, border_value=255):
+    """cv2.erode(mask, np.ones((2r+1,2r+1)), borderType=BORDER_CONSTANT, borderValue): uint8 [B,H,W] tensor."""
+    x = F.pad(mask.float()[:, None], (radius,) * 4, value=float(border_value))
+    return (-F.max_pool2d(-x, 2 * radius + 1, stride=1))[:, 0].to(torch.uint8)
+
+
+def cv2_gaussian_taps_fixed8(ksize, sigma=0.0):
+    """getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED(fractionBits = 8) -> integer taps summing to 256."""
+    import math
+    small = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+             7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
+    if sigma <= 0 and ksize <= 7:
+        k = small[ksize]
+    else:
+        sg = sigma if sigma > 0 else 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+        k = [math.exp(-(i - (ksize - 1) / 2) ** 2 / (2 * sg * sg)) for i in range(ksize)]
+        k = [v / sum(k) for v in k]
+    taps, err = [0] * ksize, 0.0
+    for i in range(ksize // 2):
+        adj = k[i] * 256 + err
+        taps[i] = taps[-1 - i] = int(round(adj))
+        err = adj - taps[i]
+    taps[ksize // 2] = 256 - sum(taps)
+    return taps
+
+
+def cv2_gaussian_blur_u8(img, ksize, sigma=0.0):
+    """cv2.GaussianBlur(img, (k,k), sigma) for CV_8U [B,H,W]: exact integer row and column passes with the 8.8 taps,
+    BORDER_REFLECT_101, one rounding: (acc + 2^15) >> 16."""
+    import numpy as np
+    taps = np.array(cv2_gaussian_taps_fixed8(ksize, sigma), dtype=np.int64)
+    r = ksize // 2
+    x = np.pad(img.numpy().astype(np.int64), ((0, 0), (r, r), (r, r)), mode="reflect")
+    h, w = img.shape[1:]
+    rows = sum(taps[i] * x[:, :, i:i + w] for i in range(ksize))
+    acc = sum(taps[j] * rows[:, j:j + h, :] for j in range(ksize))
+    return torch.from_numpy(np.clip((acc + (1 << 15)) >> 16, 0, 255).astype(np.uint8))
+
+
+def smooth_face_boundry(image_u8, dst_u8, mask_u8, radius=0, sigma=0.0):
+    """scripts/face_swap.py:81-97 per sample, composite through PIL itself (as the reference does); uint8 HWC tensors in,
+    RGB uint8 [B,H,W,3] of the pasted RGBA image out."""
+    import numpy as np
+    from PIL import Image
+    out = []
+    for b in range(image_u8.shape[0]):
+        image_masked = Image.fromarray(image_u8[b].numpy()).convert("RGBA")
+        pasted = Image.fromarray(dst_u8[b].numpy()).convert("RGBA")
+        m = mask_u8[b:b + 1]
+        if radius != 0:
+            m = cv2_gaussian_blur_u8(cv2_erode_u8(m, radius, 255), 2 * radius + 1, sigma)
+        image_masked.putalpha(Image.fromarray(m[0].numpy()))
+        pasted.alpha_composite(image_masked)
+        out.append(torch.from_numpy(np.array(pasted)[:, :, :3].copy()))
+    return torch.stack(out)
+
+
+def mask_to_u8(mask, size):
+    """255 * F.interpolate(mask, size, 'bilinear')[b, 0].numpy().astype(np.uint8) (face_swap.py:291-294): [B,1,h,w] -> [B,H,W]."""
+    import numpy as np
+    m = F.interpolate(mask, size, mode="bilinear", align_corners=False)[:, 0].numpy()
+    return torch.from_numpy((255 * m.astype(np.uint8)).astype(np.uint8))
+
+
+def _reflect101(i, n):
+    if n == 1:
+        return 0
+    while i < 0 or i >= n:
+        i = -i if i < 0 else 2 * n - 2 - i
+    return i
+
+
+def cv2_pyrdown(x):
+    """cv2.pyrDown on a numpy HWC image: uint8 -> (sum + 128) >> 8 of the [1 4 6 4 1]^2 window; float32 -> row pass
+    src[2x]*6 + (src[2x-1] + src[2x+1])*4 + src[2x-2] + src[2x+2], column pass row2*6 + (row1 + row3)*4 + row0 + row4, * 1/256;
+    BORDER_REFLECT_101; output ((H+1)//2, (W+1)//2)."""
+    import numpy as np
+    h, w = x.shape[:2]
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    xs = [[_reflect101(2 * i + k - 2, w) for i in range(wo)] for k in range(5)]
+    ys = [[_reflect101(2 * j + k - 2, h) for j in range(ho)] for k in range(5)]
+    if x.dtype == np.uint8:
+        v = x.astype(np.int64)
+        row = v[:, xs[2]] * 6 + (v[:, xs[1]] + v[:, xs[3]]) * 4 + v[:, xs[0]] + v[:, xs[4]]
+        acc = row[ys[2]] * 6 + (row[ys[1]] + row[ys[3]]) * 4 + row[ys[0]] + row[ys[4]]
+        return ((acc + 128) >> 8).astype(np.uint8)
+    f = np.float32
+    v = x.astype(f)
+    row = (v[:, xs[2]] * f(6) + (v[:, xs[1]] + v[:, xs[3]]) * f(4)) + v[:, xs[0]] + v[:, xs[4]]
+    acc = (row[ys[2]] * f(6) + (row[ys[1]] + row[ys[3]]) * f(4)) + row[ys[0]] + row[ys[4]]
+    return (acc * f(1.0 / 256.0)).astype(f)
+
+
+def cv2_pyrup(x):
+    """cv2.pyrUp on a float32 numpy HWC image (pyramids.cpp): columns -- even: s[x-1] + s[x]*6 + s[x+1], odd: (s[x] + s[x+1])*4,
+    first column s0*6 + s1*2 / (s0 + s1)*4, last s[w-2] + s[w-1]*7 / s[w-1]*8; rows -- the generic form on rows (y-1, y, y+1) with
+    row -1 = row 1 and row h = row h-1; * 1/64."""
+    import numpy as np
+    f = np.float32
+    v = x.astype(f)
+    h, w = v.shape[:2]
+    row = np.empty((h, 2 * w) + v.shape[2:], dtype=f)
+    for xx in range(w):
+        if xx == 0:
+            s1 = v[:, 1 if w > 1 else 0]
+            row[:, 0] = v[:, 0] * f(6) + s1 * f(2)
+            row[:, 1] = (v[:, 0] + s1) * f(4)
+        elif xx == w - 1:
+            row[:, 2 * xx] = v[:, xx - 1] + v[:, xx] * f(7)
+            row[:, 2 * xx + 1] = v[:, xx] * f(8)
+        else:
+            row[:, 2 * xx] = (v[:, xx - 1] + v[:, xx] * f(6)) + v[:, xx + 1]
+            row[:, 2 * xx + 1] = (v[:, xx] + v[:, xx + 1]) * f(4)
+    out = np.empty((2 * h,) + row.shape[1:], dtype=f)
+    for yy in range(h):
+        ym, yp = (yy - 1 if yy > 0 else (1 if h > 1 else 0)), (yy + 1 if yy < h - 1 else h - 1)
+        out[2 * yy] = ((row[ym] + row[yy] * f(6)) + row[yp]) * f(1.0 / 64.0)
+        out[2 * yy + 1] = ((row[yy] + row[yp]) * f(4)) * f(1.0 / 64.0)
+    return out
+
+
+def laplacian_blend_u8(full_img, ori_img, mask, num_levels=10):
+    """multi_band_blending.py:4-75 (`blending` for 1024^2 inputs, whose cv2.resize calls are identities): numpy uint8 HWC
+    full_img / ori_img, float32 HWC mask -> uint8 HWC."""
+    import numpy as np
+    GA, GB, GM = full_img.copy(), ori_img.copy(), np.float32(mask)
+    gpA, gpB, gpM = [GA], [GB], [GM]
+    for _ in range(num_levels):
+        GA, GB, GM = cv2_pyrdown(GA), cv2_pyrdown(GB), cv2_pyrdown(GM)
+        gpA.append(np.float32(GA)); gpB.append(np.float32(GB)); gpM.append(np.float32(GM))
+    lpA, lpB, gpMr = [gpA[num_levels - 1]], [gpB[num_levels - 1]], [gpM[num_levels - 1]]
+    for i in range(num_levels - 1, 0, -1):
+        lpA.append(np.subtract(gpA[i - 1], cv2_pyrup(gpA[i])))
+        lpB.append(np.subtract(gpB[i - 1], cv2_pyrup(gpB[i])))
+        gpMr.append(gpM[i - 1])
+    LS = [la * gm + lb * (np.float32(1.0) - gm) for la, lb, gm in zip(lpA, lpB, gpMr)]
+    ls_ = LS[0]
+    for i in range(1, num_levels):
+        ls_ = cv2_pyrup(ls_) + LS[i]
+    return np.uint8(np.clip(ls_, 0, 255))
+
+
+def stitch(swapped_face, target_u8, swapped_labels, hole, lap_bld=False, outer_dilation=5):
+    """scripts/face_swap.py:276-310 for a batch (tensors in, uint8 [B,H,W,3] out); swapped_labels / hole uint8 [B,512,512]."""
+    import numpy as np
+    b, _, h, w = swapped_face.shape
+    face = tensor2im_u8(swapped_face)
+    lab = swapped_labels.long()
+    bg = (lab == 0) | (lab == 11) | (lab == 4)
+    fg = (~bg) | (hole == 255)
+    fg = fg.float()[:, None]
+    content, border, full = create_masks(fg, outer_dilation, "expansion" if lap_bld else "dilation")
+    if lap_bld:
+        pasted = paste_u8(face, target_u8, content)
+        bm = F.interpolate(border, (h, w), mode="bilinear", align_corners=False)[:, 0, :, :, None].numpy()
+        bm = np.repeat(bm, 3, axis=-1)
+        return torch.stack([torch.from_numpy(laplacian_blend_u8(target_u8[i].numpy(), pasted[i].numpy(), bm[i])) for i in range(b)])
+    mask_img = mask_to_u8(content if outer_dilation == 0 else full, (h, w))
+    return smooth_face_boundry(face, target_u8, mask_img, radius=outer_dilation)
+
+
 # --------------------------------------------------------------------------
 # N3: loss networks of the optimisation loop (scripts/optimization.py:88-122)
 # --------------------------------------------------------------------------

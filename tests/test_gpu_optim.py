@@ -116,15 +116,28 @@ def test_capturable_adam_and_graphed_step_equal_eager():
     # the step count is per parameter and travels with state_dict(): a reloaded optimiser continues at t = 6
     a2 = a.detach().clone().requires_grad_(True)
     oc = FusedAdam([a2], lr=1e-2, capturable=True)
-    oc.load_state_dict(oa.state_dict())
+    import copy
+    oc.load_state_dict(copy.deepcopy(oa.state_dict()))     # (load_state_dict aliases same-device tensors of a live state dict)
     a.grad, a2.grad = grads[0].to(DEV).clone(), grads[0].to(DEV).clone()
     oa.step()
     oc.step()
     assert torch.equal(a.detach(), a2.detach()) and int(oc.state[a2]["step"].item()) == 6
 
-    net = Net3(make_opts(out_size=256))
-    net.load_state_dict(synth.synth_state_dict(256, 13), strict=True)
-    net.latent_avg = synth.synth_latent_avg(256).to(DEV)
+    _graphed_equals_eager(256, (256, 128), steps=5)
+
+
+def _graphed_equals_eager(size, lpips_sizes, steps):
+    """The script's default objective (optimization.py:88-122: l2 + 0.8 LPIPS x scales + 0.1 ID + 0.1 parsing) as ONE replayed
+    HIP graph == the eager loop, bit for bit."""
+    import types
+    from e4s_amd.criteria import FaceParsingLoss, IDLoss, LPIPS
+    from e4s_amd.networks import Net3
+    from e4s_amd.optim import FusedAdam, GraphedStep
+    from e4s_amd.options import make_opts
+    g = torch.Generator().manual_seed(6)
+    net = Net3(make_opts(out_size=size))
+    net.load_state_dict(synth.synth_state_dict(size, 13), strict=True)
+    net.latent_avg = synth.synth_latent_avg(size).to(DEV)
     net = net.to(DEV).eval()
     for p in net.parameters():
         p.requires_grad = False
@@ -132,21 +145,23 @@ def test_capturable_adam_and_graphed_step_equal_eager():
     lp.load_state_dict(synth.synth_module_state_dict(lp, 0, "lp."))
     idl = IDLoss(types.SimpleNamespace(id_loss_multiscale=True))
     idl.load_state_dict(synth.synth_module_state_dict(idl, 0, "id."))
-    lp, idl = lp.to(DEV).eval(), idl.to(DEV).eval()
-    _, target = synth.synth_image_pair(1, 256, seed=12)
+    fpl = FaceParsingLoss(types.SimpleNamespace())
+    fpl.load_state_dict(synth.synth_module_state_dict(fpl, 0, "fp."))
+    lp, idl, fpl = lp.to(DEV).eval(), idl.to(DEV).eval(), fpl.to(DEV).eval()
+    _, target = synth.synth_image_pair(1, size, seed=12)
     target = target.to(DEV)
     mask = synth.onehot(synth.synth_labels_face(1, 512, seed=6)).to(DEV)
-    noise = [n.to(DEV) for n in synth.synth_noise(256)]
+    noise = [n.to(DEV) for n in synth.synth_noise(size)]
     sv = (torch.randn(1, 12, 1280, generator=g) * 0.1).to(DEV)
 
-    def run(graphed, steps=5):
+    def run(graphed):
         latent = sv.clone().requires_grad_(True)
         opt = FusedAdam([latent], lr=1e-2, capturable=True)
 
         def body():
             img, _, _ = net.gen_img(None, net.cal_style_codes(latent), mask, noise=noise)
-            loss = torch.nn.functional.mse_loss(img, target) + 0.8 * lp.forward_pooled(img, target, (256, 128)) \
-                + 0.1 * idl(img, target)[0]
+            loss = torch.nn.functional.mse_loss(img, target) + 0.8 * lp.forward_pooled(img, target, lpips_sizes) \
+                + 0.1 * idl(img, target)[0] + 0.1 * fpl(img, target)[0]
             loss.backward()
             opt.step()
             return loss.detach()
@@ -167,6 +182,12 @@ def test_capturable_adam_and_graphed_step_equal_eager():
     assert torch.equal(lat_e, lat_g)
     assert loss_g == loss_e[2:]
     assert loss_e[-1] < loss_e[0]
+
+
+def test_graphed_four_term_step_equals_eager_at_1024():
+    """the config-3 step bench.py times by default -- l2 + LPIPS(1024, 512, 256) + ID + parsing at 1024^2,
+    captured -- against the eager loop, bitwise."""
+    _graphed_equals_eager(1024, (1024, 512, 256), steps=4)
 
 
 def test_plan_path_replays_in_a_graph_with_other_masks_than_the_captured_one(monkeypatch):

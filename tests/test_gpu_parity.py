@@ -304,8 +304,10 @@ def test_unmasked_polyphase_upconv_bf16x3_vs_oracle(cin, cout, res, monkeypatch)
     """Unmasked up-sampling StyledConv (the 512^2 / 1024^2 layers, model.py:655-657) on the plain split-bf16 kernel in
     polyphase form (ncls = 4) with 128- / 64- / 32-wide column tiles, against the oracle's conv_transpose2d + blur."""
     from e4s_amd import kernels as K
+    from e4s_amd import stylegan2
     from e4s_amd.stylegan2 import StyledConv
     monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    monkeypatch.setattr(stylegan2, "UPCONV_BF16X3_EXACT", False)       # the polyphase statement (E4S_UPCONV_BF16X3=polyphase)
     sd = _styled_sd(cin, cout, True, 14)
     m = StyledConv(cin, cout, 3, 512, upsample=True, mask_op=False)
     m.load_state_dict(sd)
@@ -320,6 +322,39 @@ def test_unmasked_polyphase_upconv_bf16x3_vs_oracle(cin, cout, res, monkeypatch)
     got32 = m(x.to(DEV), style.to(DEV), None, noise=noise.to(DEV))
     assert 0.0 < maxabs(got, got32)
     assert maxabs(got, want) < 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 128, 64, 32, 32), (3, 64, 32, 24, 40), (2, 256, 128, 16, 16), (1, 32, 32, 15, 33),
+                                            (1, 128, 64, 256, 256), (1, 64, 32, 512, 512)])
+def test_unmasked_exact_upconv_bf16x3_vs_oracle(b, cin, cout, h, w, monkeypatch):
+    """the unmasked up-sampling StyledConvs (model.py:287-300 + Blur :206-213; the 128 -> 64 -> 512^2 and
+    64 -> 32 -> 1024^2 layers of a face swap, run here at their FULL sizes too) on the exact split-bf16 sub-pixel GEMM
+    (e4s_upconv_bf16x3_f32: 9 Cin Cout MACs per input pixel) + FIR epilogue, against the oracle's conv_transpose2d + blur;
+    odd, non-square and partial-tile geometries; per-sample and shared noise maps; <= 5e-5 of the output scale."""
+    from e4s_amd import kernels as K
+    from e4s_amd import stylegan2
+    from e4s_amd.stylegan2 import StyledConv
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    assert stylegan2.UPCONV_BF16X3_EXACT
+    sd = _styled_sd(cin, cout, True, 15)
+    m = StyledConv(cin, cout, 3, 512, upsample=True, mask_op=False)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(b, cin, h, w, generator=g)
+    style = torch.randn(b, 512, generator=g)
+    noise = torch.randn(b if b > 1 else 1, 1, 2 * h, 2 * w, generator=g)
+    want = orc.styled_conv(sd, "", x, style, None, noise, True, False)
+    calls = []
+    real = K.upconv_bf16x3
+    monkeypatch.setattr(K, "upconv_bf16x3", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    got = m(x.to(DEV), style.to(DEV), None, noise=noise.to(DEV))
+    assert calls, "the exact split-bf16 up-conv kernel was not the one that ran"
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    assert maxabs(got, want) < 5e-5 * scale, (maxabs(got, want), scale)
+    got2 = m(x.to(DEV), style.to(DEV), None, noise=noise.to(DEV))
+    assert torch.equal(got, got2)                                  # no atomics anywhere: bit-reproducible
 
 
 # ---------------------------------------------------------------------------------------------

@@ -101,3 +101,78 @@ def test_swap_image_to_uint8_vs_reference_tensor2im(golden):
     diff = (u8[y0:y0 + 128, x0:x0 + 128].int() - want.int()).abs()
     assert int(diff.max()) <= 1 and float((diff == 0).float().mean()) > 0.995
     assert abs(int(u8.long().sum()) - g["img_u8_sum"]) < 3e-5 * g["img_u8_sum"]
+
+
+# ---- stitching: the default smooth_face_boundry path and the Laplacian blend ---------------------------------
+def _blob_mask(b, h, w, seed):
+    """binary {0,255} mask: a few random ellipses (face-like blobs touching the border in some samples)"""
+    g = torch.Generator().manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    out = torch.zeros(b, h, w, dtype=torch.uint8)
+    for i in range(b):
+        for _ in range(3):
+            cy, cx = float(torch.rand(1, generator=g)) * h, float(torch.rand(1, generator=g)) * w
+            ry, rx = (0.1 + 0.3 * float(torch.rand(1, generator=g))) * h, (0.1 + 0.3 * float(torch.rand(1, generator=g))) * w
+            out[i][((ys - cy) / ry) ** 2 + ((xs - cx) / rx) ** 2 < 1] = 255
+    return out
+
+
+@pytest.mark.parametrize("b,h,w,r", [(2, 64, 96, 5), (1, 37, 23, 5), (1, 16, 16, 2), (1, 1024, 1024, 5)])
+def test_erode_gaussian_and_composite_bit_exact_vs_oracle(b, h, w, r):
+    """cv2.erode / cv2.GaussianBlur (CV_8U fixed point) restated in the oracle, PIL's own alpha_composite: bit-exact."""
+    from e4s_amd import postproc as PP
+    m = _blob_mask(b, h, w, 5)
+    g = torch.Generator().manual_seed(9)
+    grey = torch.randint(0, 256, (b, h, w), generator=g, dtype=torch.uint8)                 # any uint8 image, not just masks
+    er = PP.erode_u8(m.to(DEV), r, 255)
+    assert torch.equal(er.cpu(), orc.cv2_erode_u8(m, r, 255))
+    assert torch.equal(PP.erode_u8(grey.to(DEV), r, 0).cpu(), orc.cv2_erode_u8(grey, r, 0))
+    for src in (er.cpu(), grey):
+        assert torch.equal(PP.gaussian_blur_u8(src.to(DEV), 2 * r + 1).cpu(), orc.cv2_gaussian_blur_u8(src, 2 * r + 1))
+    face = torch.randint(0, 256, (b, h, w, 3), generator=g, dtype=torch.uint8)
+    tgt = torch.randint(0, 256, (b, h, w, 3), generator=g, dtype=torch.uint8)
+    got = PP.smooth_face_boundry(face.to(DEV), tgt.to(DEV), m.to(DEV), radius=r)
+    assert torch.equal(got.cpu(), orc.smooth_face_boundry(face, tgt, m, radius=r))            # PIL does the composite there
+    got0 = PP.smooth_face_boundry(face.to(DEV), tgt.to(DEV), grey.to(DEV), radius=0)          # every alpha value 0..255
+    assert torch.equal(got0.cpu(), orc.smooth_face_boundry(face, tgt, grey, radius=0))
+
+
+def test_pyramids_vs_oracle():
+    """cv2.pyrDown (uint8 and fp32) / cv2.pyrUp (fp32) restatements: same operation order -> bit-exact; odd sizes, 2x2."""
+    from e4s_amd import postproc as PP
+    g = torch.Generator().manual_seed(4)
+    for (h, w) in ((32, 48), (17, 9), (2, 2), (4, 2)):
+        u = torch.randint(0, 256, (2, h, w, 3), generator=g, dtype=torch.uint8)
+        f = torch.rand(2, h, w, 3, generator=g) * 255
+        du = PP.pyr_down(u.to(DEV)).cpu()
+        df = PP.pyr_down(f.to(DEV)).cpu()
+        upf = PP.pyr_up(f.to(DEV)).cpu()
+        for i in range(2):
+            assert torch.equal(du[i], torch.from_numpy(orc.cv2_pyrdown(u[i].numpy()))), (h, w)
+            assert torch.equal(df[i], torch.from_numpy(orc.cv2_pyrdown(f[i].numpy()))), (h, w)
+            assert torch.equal(upf[i], torch.from_numpy(orc.cv2_pyrup(f[i].numpy()))), (h, w)
+    const = torch.full((1, 8, 8, 3), 100, dtype=torch.uint8)
+    assert bool((PP.pyr_up(PP.pyr_down(const.to(DEV)).float()) == 100).all())
+
+
+def test_stitch_pipeline_both_modes_vs_oracle(golden):
+    """scripts/face_swap.py:276-310 end to end on the reference's example parsing maps: foreground -> create_masks -> (default)
+    mask image -> erode -> Gaussian -> alpha composite, bit-exact; (--lap_bld) paste -> 10-level Laplacian blend, +-1 LSB."""
+    from e4s_amd import postproc as PP
+    gold = golden("realmask.pt")
+    swapped, hole = unz(gold["swapped_mask"]), unz(gold["hole_map"]) * 255
+    b = 2
+    lab = torch.stack([swapped, swapped.flip(-1)]).contiguous()
+    hol = torch.stack([hole, hole.flip(-1)]).contiguous()
+    face = synth.synth_image(b, 1024, tag="stitch_face")
+    g = torch.Generator().manual_seed(12)
+    tgt = torch.randint(0, 256, (b, 1024, 1024, 3), generator=g, dtype=torch.uint8)
+    want = orc.stitch(face, tgt, lab, hol, lap_bld=False)
+    got = PP.stitch(face.to(DEV), tgt.to(DEV), lab.to(DEV), hol.to(DEV), lap_bld=False)
+    assert torch.equal(got.cpu(), want)
+    changed = float((want != tgt).float().mean())
+    assert 0.05 < changed < 0.95                                       # the face really was pasted, the background really kept
+    want_l = orc.stitch(face[:1], tgt[:1], lab[:1], hol[:1], lap_bld=True)
+    got_l = PP.stitch(face[:1].to(DEV), tgt[:1].to(DEV), lab[:1].to(DEV), hol[:1].to(DEV), lap_bld=True)
+    diff = (got_l.cpu().int() - want_l.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3, (int(diff.max()), float((diff > 0).float().mean()))

@@ -211,11 +211,13 @@ def _load_bench():
 
 def test_bench_parser_defaults_follow_the_driver_contract():
     """`python bench.py` with no flags (the driver's N = 1 run): one GPU, a K / W that finish within minutes, the uint8
-    gather and the overlapped collective as the N > 1 defaults, the eager config-3 loop; the driver's own flags parse."""
+    gather and the overlapped collective as the N > 1 defaults, the graphed config-3 step (--opt-eager opts out), >= 10 timed
+    config-5 steps; the driver's own flags parse."""
     bench = _load_bench()
     a = bench.build_parser().parse_args([])
     assert a.gpus == 1 and 1 <= a.steps <= 50 and 0 <= a.warmup <= 10 and a.batch == 8
-    assert not a.gather_fp32 and not a.sync_gather and not a.no_graph and not a.opt_graph
+    assert not a.gather_fp32 and not a.sync_gather and not a.no_graph and a.opt_graph and not a.stub_swap
+    assert not bench.build_parser().parse_args(["--opt-eager"]).opt_graph and a.train_steps >= 10
     assert a.opt_steps == 200 and set(a.opt_modes.split(",")) == {"full", "mse"}
     d = bench.build_parser().parse_args(["--gpus", "8", "--steps", "20", "--warmup", "3"])
     assert (d.gpus, d.steps, d.warmup) == (8, 20, 3)
@@ -306,3 +308,40 @@ def test_target_feature_cache_holds_the_target_tensor():
     assert C._target_key(y1) != k1                              # in-place edits miss as well
     src = open(os.path.join(ROOT, "e4s_amd", "criteria.py")).read()
     assert src.count("self._target[1] is not y") == 3           # all three loss classes use the guarded hit test
+
+
+def test_stitch_host_side_restatements():
+    """N4 stitching, CPU side: (1) the integer alpha-composite formula the device kernel implements (libImaging/AlphaComposite.c,
+    PRECISION_BITS 7, opaque destination) against PIL itself for every alpha; (2) the 8.8 fixed-point Gaussian taps, product
+    and oracle statements agree and sum to 256; (3) pyramid restatements preserve constants and sizes."""
+    import numpy as np
+    from PIL import Image
+    from e4s_amd import postproc as PP
+    rs = np.random.RandomState(0)
+    face = rs.randint(0, 256, (256, 64, 3)).astype(np.uint8)
+    tgt = rs.randint(0, 256, (256, 64, 3)).astype(np.uint8)
+    alpha = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 64, 1)
+    src = Image.fromarray(face).convert("RGBA")
+    src.putalpha(Image.fromarray(alpha))
+    dst = Image.fromarray(tgt).convert("RGBA")
+    dst.alpha_composite(src)
+    ref = np.array(dst)
+    a = alpha.astype(np.uint64)[..., None]
+    outa255 = a * 255 + 255 * (255 - a)
+    coef1 = a * 255 * 255 * 128 // np.maximum(outa255, 1)
+    coef2 = 255 * 128 - coef1
+    t = face.astype(np.uint64) * coef1 + tgt.astype(np.uint64) * coef2 + (0x80 << 7)
+    mine = ((((t >> 8) + t) >> 8) >> 7).astype(np.uint8)
+    mine = np.where(a == 0, tgt, mine)
+    assert np.array_equal(mine, ref[:, :, :3]) and bool((ref[:, :, 3] == 255).all())
+    for k, s in ((11, 0.0), (5, 0.0), (7, 0.0), (3, 0.0), (9, 1.5), (11, 3.0)):
+        taps = PP.gaussian_kernel_fixed8(k, s)
+        assert taps == orc.cv2_gaussian_taps_fixed8(k, s) and sum(taps) == 256 and taps == taps[::-1]
+    assert PP.gaussian_kernel_fixed8(11, 0.0) == [2, 7, 17, 31, 45, 52, 45, 31, 17, 7, 2]
+    c = np.full((12, 10, 3), 77, dtype=np.uint8)
+    d = orc.cv2_pyrdown(c)
+    assert d.shape == (6, 5, 3) and bool((d == 77).all())
+    u = orc.cv2_pyrup(d.astype(np.float32))
+    assert u.shape == (12, 10, 3) and bool((u == 77).all())
+    one = orc.laplacian_blend_u8(c, c, np.random.RandomState(1).rand(12, 10, 3).astype(np.float32), num_levels=2)
+    assert bool((one == 77).all())
