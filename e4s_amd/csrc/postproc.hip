@@ -12,6 +12,9 @@
 // in ATen itself: there a uint8 result may differ by one step where the mask is fractional.
 #include "common.h"
 
+// numpy-order fp32 arithmetic (one rounding per operation): no FMA contraction in this file (see stitch.hip)
+#pragma clang fp contract(off)
+
 namespace {
 
 __global__ void onehot_kernel(const uint8_t* __restrict__ labels, float* __restrict__ out, int R, int64_t hw, int64_t n) {

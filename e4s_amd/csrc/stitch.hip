@@ -13,6 +13,11 @@
 // the composite in the CPU tests.  The OpenCV restatements are "parity unpinned" (oracle/e4s_oracle.py says the same).
 #include "common.h"
 
+// Every fp32 expression in this file restates an operation ORDER of OpenCV / numpy (one rounding per operation).  hipcc's default
+// -ffp-contract=fast may fuse a*b+c into one FMA, and __fmul_rn / __fadd_rn are plain operators in this ROCm's headers
+// (__clang_hip_math.h:271), so contraction is switched off for the whole translation unit.
+#pragma clang fp contract(off)
+
 namespace {
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
