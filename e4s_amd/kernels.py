@@ -402,27 +402,29 @@ def upconv_mfma(x, w3, cout, k4, *, in_scale=None, out_scale=None, labels=None, 
 
 
 def subpixel_weights(w):
-    """w [Cout,Cin,3,3] -> [4 shifts, 4*Cout, Cin]: the sub-pixel GEMM operand of e4s_upconv_bf16x3_f32 (csrc/upconv_bf16x3.hip)."""
+    """w [Cout,Cin,3,3] -> the packed, hi/lo-split sub-pixel GEMM operand of e4s_upconv_bf16x3_f32 (csrc/upconv_bf16x3.hip):
+    [Cin/32, Cout/32, 9 blocks, 32 co, 32 hi | 32 lo bf16], returned as an opaque fp32-typed tensor of the same byte size."""
     w = _f32(w)
     cout, cin = w.shape[:2]
-    out = torch.empty(4, 4 * cout, cin, device=w.device, dtype=torch.float32)
-    call("e4s_subpixel_weights_f32", fptr(w), fptr(out), cout, cin, stream())
+    out = torch.empty(cin // 32, cout // 32, 9, 32, 32, device=w.device, dtype=torch.float32)
+    call("e4s_subpixel_weights_f32", fptr(w), ptr(out), cout, cin, stream())
     return out
 
 
 def upconv_bf16x3_eligible(cin, cout):
-    return cin % 32 == 0 and cout % 32 == 0
+    """e4s_upconv_bf16x3_f32: 32-channel output tiles; its stage pipeline is unrolled by two 32-channel input chunks."""
+    return cin % 64 == 0 and cout % 32 == 0
 
 
-def upconv_bf16x3(x, w_sub_split, cout, k4, *, in_scale=None, out_scale=None, noise=None, noise_w=None, bias=None, act=0,
+def upconv_bf16x3(x, w_sub, cout, k4, *, in_scale=None, out_scale=None, noise=None, noise_w=None, bias=None, act=0,
                   alpha=0.2, gain=LRELU_GAIN, out=None):
     """Exact transposed conv + blur + noise + bias + act on the split-bf16 matrix-core path, one style per sample.
-    x NHWC [B,H,W,Cin]; w_sub_split = split_bf16x2(subpixel_weights(w)); k4 the 4x4 blur kernel (device) -> NHWC [B,2H,2W,Cout]."""
+    x NHWC [B,H,W,Cin]; w_sub = subpixel_weights(w); k4 the 4x4 blur kernel (device tensor) -> NHWC [B,2H,2W,Cout]."""
     b, hi, wi, cin = x.shape
     ho, wo = 2 * hi, 2 * wi
     y = torch.empty(b, ho, wo, cout, device=x.device, dtype=torch.float32) if out is None else out
     p = ConvParams()
-    p.x, p.w, p.y = fptr(x), fptr(w_sub_split), fptr(y)
+    p.x, p.w, p.y = fptr(x), fptr(w_sub), fptr(y)
     p.y_cstride = y.shape[3] if out is not None else 0
     p.rows = p.tiles = p.meta = None
     p.tiles_cap = 0
@@ -441,9 +443,55 @@ def upconv_bf16x3(x, w_sub_split, cout, k4, *, in_scale=None, out_scale=None, no
     p.noise_per_channel = 0
     p.bias, p.slope = fptr(bias), None
     p.act, p.alpha, p.gain = act, alpha, gain
-    ws = torch.empty(lib.load().e4s_upconv_bf16x3_ws_floats(ctypes.byref(p)), device=x.device, dtype=torch.float32)
-    call("e4s_upconv_bf16x3_f32", ctypes.byref(p), fptr(_f32(k4)), fptr(ws), stream())
+    call("e4s_upconv_bf16x3_f32", ctypes.byref(p), fptr(_f32(k4)), stream())
     return y
+
+
+def conv_c32(x, w_split, cout, *, in_scale=None, out_scale=None, noise=None, noise_w=None, bias=None, act=0, alpha=0.2,
+             gain=LRELU_GAIN, rgb_ws=None):
+    """3x3 stride-1 conv with 32 input channels on e4s_conv_c32_bf16x3_f32 (weights resident in LDS).  x NHWC [B,H,W,32];
+    w_split = split_bf16x2(pack_taps(w)); rgb_ws [B,3,32]: also return the ToRGB partial [B,3,H,W] of the OUTPUT (Cout == 32).
+    Returns y NHWC [B,H,W,Cout] or (y, rgb_partial)."""
+    b, h, w, cin = x.shape
+    if cin != 32 or cout % 32:
+        raise RuntimeError("conv_c32: Cin == 32 and Cout % 32 == 0")
+    y = torch.empty(b, h, w, cout, device=x.device, dtype=torch.float32)
+    p = ConvParams()
+    p.x, p.w, p.y = fptr(x), fptr(w_split), fptr(y)
+    p.y_cstride = 0
+    p.rows = p.tiles = p.meta = None
+    p.tiles_cap = 0
+    p.B, p.Ha, p.Wa = b, h, w
+    p.Hi, p.Wi, p.Ho, p.Wo, p.Cin, p.Cout = h, w, h, w, cin, cout
+    p.istride, p.ostride, p.ntaps, p.ncls = 1, 1, 9, 1
+    p.in_scale, p.out_scale = fptr(in_scale), fptr(out_scale)
+    p.groups_per_batch = 1
+    p.labels, p.Hm, p.Wm = None, 0, 0
+    if noise is not None:
+        p.noise, p.noise_w = fptr(noise), fptr(noise_w)
+        p.noise_bstride = h * w if noise.shape[0] > 1 else 0
+    else:
+        p.noise = p.noise_w = None
+        p.noise_bstride = 0
+    p.noise_per_channel = 0
+    p.bias, p.slope = fptr(bias), None
+    p.act, p.alpha, p.gain = act, alpha, gain
+    partial = None
+    if rgb_ws is not None:
+        if cout != 32 or tuple(rgb_ws.shape) != (b, 3, 32):
+            raise RuntimeError("conv_c32: the fused ToRGB partial needs Cout == 32 and rgb_ws [B,3,32]")
+        partial = torch.empty(b, 3, h, w, device=x.device, dtype=torch.float32)
+    call("e4s_conv_c32_bf16x3_f32", ctypes.byref(p), fptr(rgb_ws), fptr(partial), stream())
+    return y if partial is None else (y, partial)
+
+
+def torgb_finish(partial, bias, skip, k4):
+    """partial [B,3,H,W] (the fused ToRGB contraction) + bias + FIR-upsampled skip [B,3,H/2,W/2] -> [B,3,H,W]."""
+    b, _, h, w = partial.shape
+    out = torch.empty_like(partial)
+    call("e4s_torgb_finish_f32", fptr(partial), fptr(_f32(bias)), fptr(skip), fptr(_f32(k4)) if skip is not None else None,
+         fptr(out), b, h, w, stream())
+    return out
 
 
 def torgb(x, ws, bias, skip, k4, labels, num_regions):

@@ -91,10 +91,9 @@ SIGNATURES = {
     "e4s_batch_sum_f32": [c_p, c_p, c_i, c_l, c_p],
     "e4s_adam_step_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_p],
     "e4s_subpixel_weights_f32": [c_p, c_p, c_i, c_i, c_p],
-    "e4s_upconv_bf16x3_f32": [c_p, c_p, c_p, c_p],
+    "e4s_upconv_bf16x3_f32": [c_p, c_p, c_p],
     "e4s_colsum_f32": [c_p, c_p, c_p, c_l, c_i, c_p],
     "e4s_colsum_ws_floats": [c_l, c_i],
-    "e4s_upconv_bf16x3_ws_floats": [ctypes.POINTER(ConvParams)],
     "e4s_mask_to_u8": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_erode_u8": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_gaussian_blur_u8": [c_p, c_p, c_i, c_i, c_i, c_i, ctypes.POINTER(c_i), c_p],
@@ -105,6 +104,8 @@ SIGNATURES = {
     "e4s_u8_to_f32": [c_p, c_p, c_l, c_p],
     "e4s_lap_level_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p],
     "e4s_clip_u8": [c_p, c_p, c_l, c_p],
+    "e4s_conv_c32_bf16x3_f32": [c_p, c_p, c_p, c_p],
+    "e4s_torgb_finish_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_ema_f32": [c_p, c_p, c_l, c_d, c_p],
     "e4s_adam_step_dev_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_p, c_i, c_p],
     "e4s_torgb_bwd_x_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
@@ -166,7 +167,7 @@ SIGNATURES = {
 }
 
 INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats", "e4s_lpips_layer_ws_doubles", "e4s_conv_mfma_ws_floats",
-                "e4s_cosine_ws_doubles", "e4s_colsum_ws_floats", "e4s_upconv_bf16x3_ws_floats"}       # size queries: return a count, not an error code
+                "e4s_cosine_ws_doubles", "e4s_colsum_ws_floats"}       # size queries: return a count, not an error code
 
 _lib = None
 

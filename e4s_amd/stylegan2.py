@@ -39,6 +39,8 @@ UPCONV_EXACT = os.environ.get("E4S_UPCONV", "exact") != "polyphase"
 UPCONV_EXACT_MIN_RES = int(os.environ.get("E4S_UPCONV_MIN_RES", "256"))     # masked layers below this stay polyphase
 # unmasked up-convs under E4S_PRECISION=auto/bf16x3: exact sub-pixel GEMM (csrc/upconv_bf16x3.hip) unless "polyphase" is asked for
 UPCONV_BF16X3_EXACT = os.environ.get("E4S_UPCONV_BF16X3", "exact") != "polyphase"
+# the Cin == 32 StyledConv (32 -> 32 at 1024^2) on the resident-weights kernel with the ToRGB contraction in its epilogue
+CONV_C32 = os.environ.get("E4S_CONV_C32", "1") != "0"
 
 
 def make_kernel(k):
@@ -214,7 +216,7 @@ class ModulatedConv2d(nn.Module):
         pk = self.packed()
         if "w_sub_split" not in pk:
             with torch.no_grad():
-                pk["w_sub_split"] = K.split_bf16x2(K.subpixel_weights(self.weight.detach()[0].float().contiguous()))
+                pk["w_sub_split"] = K.subpixel_weights(self.weight.detach()[0].float().contiguous())
         return pk["w_sub_split"]
 
     def split_weights(self):
@@ -292,10 +294,17 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
         self.mask_op = mask_op
 
-    def run_nhwc(self, x, s, noise, labels=None, num_regions=1, plan=None, rec=None):
+    def c32_eligible(self, b, h, w, labels=None, plan=None):
+        """The Cin == 32 resident-weights kernel (e4s_conv_c32_bf16x3_f32) applies: unmasked 32 -> 32k, stride 1, split-bf16 on."""
+        conv = self.conv
+        return (CONV_C32 and not conv.upsample and labels is None and plan is None and conv.in_channel == 32
+                and conv.out_channel % 32 == 0 and K.want_bf16x3(b, h, w, 32, conv.out_channel))
+
+    def run_nhwc(self, x, s, noise, labels=None, num_regions=1, plan=None, rec=None, rgb_ws=None):
         """x NHWC, s [G,Cin] modulation (G = B*R when masked).  Masked layers pass the label map
         (region-select inside the GEMM) or, alternatively, a gathered RowPlan.  Returns NHWC output
-        after noise + bias + leaky-ReLU*sqrt(2)."""
+        after noise + bias + leaky-ReLU*sqrt(2).  rgb_ws [B,3,32] (only where c32_eligible and Cout == 32): also return the
+        ToRGB partial of the output, (y, partial [B,3,H,W])."""
         conv = self.conv
         pk = conv.packed()
         b, h, w, _ = x.shape
@@ -307,6 +316,12 @@ class StyledConv(nn.Module):
                 raise NotImplementedError("backward with per-channel noise maps")
             rec.update(d=d, noise=nz)
         ncls = 4 if conv.upsample else 1
+        if not per_ch and self.c32_eligible(b, h, w, labels, plan):
+            return K.conv_c32(x, conv.split_weights(), conv.out_channel, in_scale=s, out_scale=d, noise=nz,
+                              noise_w=self.noise.weight, bias=self.activate.bias, act=1, alpha=self.activate.negative_slope,
+                              gain=self.activate.scale, rgb_ws=rgb_ws)
+        if rgb_ws is not None:
+            raise RuntimeError("the fused ToRGB partial exists only on the Cin == 32 kernel")
         if (conv.upsample and labels is None and plan is None and not per_ch and UPCONV_BF16X3_EXACT
                 and K.upconv_bf16x3_eligible(conv.in_channel, conv.out_channel)
                 and K.want_bf16x3(b, h, w, conv.in_channel, conv.out_channel, ncls, masked=False)):
@@ -536,18 +551,34 @@ class Generator(nn.Module):
         if soft and tape is not None:
             raise NotImplementedError("backward with soft (non one-hot) masks")
 
-        def styled(layer, x, idx, nz):
+        def styled(layer, x, idx, nz, rgb_ws=None):
             mod = layer.conv.modulation
             s = K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
             if soft and layer.mask_op:
                 return layer.run_nhwc_soft(x, s, nz, mask)
             rec = {} if tape is not None else None
-            y = layer.run_nhwc(x, s, nz, labels if layer.mask_op else None, r, rec=rec)
+            y = layer.run_nhwc(x, s, nz, labels if layer.mask_op else None, r, rec=rec, rgb_ws=rgb_ws)
+            partial = None
+            if rgb_ws is not None:
+                y, partial = y
             if tape is not None:
                 rec.update(kind="conv", layer=layer, idx=idx, masked=layer.mask_op, x=x, y=y, s=s,
                            labels=labels if layer.mask_op else None)
                 tape.append(rec)
-            return y
+            return y if rgb_ws is None else (y, partial)
+
+        def styled_then_rgb(conv2, to_rgb, x, idx, nz, skip):
+            """conv2 (Cin == Cout == 32, unmasked) with the ToRGB 1x1 modulated conv of ITS OUTPUT in the epilogue
+            (model.py:422-440), then bias + FIR-upsampled skip (model.py:441-446): the 1024^2 activation is not read again."""
+            mod = to_rgb.conv.modulation
+            s_rgb = K.modulate(lat, idx + 1, False, mod.weight, mod.bias)
+            ws = K.rgb_weights(to_rgb.conv.packed()["w"].view(3, -1), s_rgb, to_rgb.conv.scale)
+            y, partial = styled(conv2, x, idx, nz, rgb_ws=ws)
+            out = K.torgb_finish(partial, to_rgb.bias, skip, to_rgb.upsample.kernel if skip is not None else None)
+            if tape is not None:
+                tape.append(dict(kind="rgb", layer=to_rgb, idx=idx + 1, masked=False, x=y, s=s_rgb, ws=ws,
+                                 has_skip=skip is not None, out=out, labels=None))
+            return y, out
 
         def rgb(layer, x, idx, skip):
             mod = layer.conv.modulation
@@ -573,8 +604,13 @@ class Generator(nn.Module):
                 feats = K.nhwc_to_nchw(x)                                          # model.py:642-647
                 if tape is not None:
                     tape[-1]["is_feats"] = True
-            x = styled(conv2, x, i + 1, noise[i + 1])
-            skip = rgb(to_rgb, x, i + 2, skip)
+            nz2 = noise[i + 1]
+            if (not soft and not conv2.mask_op and not to_rgb.mask_op and conv2.conv.out_channel == 32
+                    and (nz2 is None or nz2.shape[1] == 1) and conv2.c32_eligible(b, x.shape[1], x.shape[2])):
+                x, skip = styled_then_rgb(conv2, to_rgb, x, i + 1, nz2, skip)
+            else:
+                x = styled(conv2, x, i + 1, nz2)
+                skip = rgb(to_rgb, x, i + 2, skip)
             i += 2
         return skip, feats
 

@@ -339,14 +339,22 @@ int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n
 int e4s_adam_step_dev_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                           double eps, double weight_decay, int64_t* step, int advance, void* stream);
 /* Exact up-sampling StyledConv on the split-bf16 matrix-core path (csrc/upconv_bf16x3.hip): conv_transpose2d(stride 2) +
- * Blur (src/models/stylegan2/model.py:287-300, 206-213) + NoiseInjection + FusedLeakyReLU (:396-404) at 9 Cin Cout MACs per
- * input pixel, one style per sample (unmasked layers, model.py:655-657).  e4s_subpixel_weights_f32: w [Cout,Cin,3,3] ->
- * [4 shifts][4 Cout][Cin] (the caller then splits it with e4s_split_bf16x2_f32).  p: x / y NHWC, w = that split image,
- * in_scale [B,Cin] | NULL, out_scale [B,Cout] | NULL, noise / bias / act / alpha / gain as e4s_conv_bf16x3_f32; k4: device
- * pointer to the 4x4 blur taps; ws: e4s_upconv_bf16x3_ws_floats(p) floats (the (2H+2)x(2W+2) intermediate of one launch group). */
-int e4s_subpixel_weights_f32(const float* w, float* out, int Cout, int Cin, void* stream);
-int64_t e4s_upconv_bf16x3_ws_floats(const e4s_conv_params* p);
-int e4s_upconv_bf16x3_f32(const e4s_conv_params* p, const float* k4, float* ws, void* stream);
+ * Blur (src/models/stylegan2/model.py:287-300, 206-213) + NoiseInjection + FusedLeakyReLU (:396-404) in one kernel, one style
+ * per sample (unmasked layers, model.py:655-657); Cin % 32 == 0, Cout % 32 == 0.
+ * e4s_subpixel_weights_f32: w [Cout,Cin,3,3] -> the kernel's packed, hi/lo-split operand (9 * Cout * Cin * 4 bytes, opaque).
+ * p: x / y NHWC, w = that buffer, in_scale [B,Cin] | NULL, out_scale [B,Cout] | NULL, noise / bias / act / alpha / gain as
+ * e4s_conv_bf16x3_f32; k4: DEVICE pointer to the 4x4 blur taps. */
+int e4s_subpixel_weights_f32(const float* w, void* out, int Cout, int Cin, void* stream);
+int e4s_upconv_bf16x3_f32(const e4s_conv_params* p, const float* k4, void* stream);
+
+/* 3x3 stride-1 conv with Cin == 32 on the split-bf16 path, weights resident in LDS, halos fetched two tiles ahead
+ * (csrc/conv_c32.hip): the generator's 32 -> 32 StyledConv at 1024^2 (model.py:537-549).  p as e4s_conv_bf16x3_f32 (no
+ * labels / stats / split-K); w = split image of the tap-packed weights.  rgb_ws [B][3][32] and rgb_partial [B][3][H][W], both
+ * or neither (Cout == 32): the ToRGB 1x1 modulated conv (model.py:422-440) of the layer's output leaves the same pass;
+ * e4s_torgb_finish_f32 then adds bias + the FIR-upsampled skip (model.py:441-446) -> out NCHW [B,3,H,W]. */
+int e4s_conv_c32_bf16x3_f32(const e4s_conv_params* p, const float* rgb_ws, float* rgb_partial, void* stream);
+int e4s_torgb_finish_f32(const float* partial, const float* bias, const float* skip, const float* k4, float* out, int B, int H,
+                         int W, void* stream);
 
 /* ---- stitching the swapped face back onto the target on the device (csrc/stitch.hip) ----
  * scripts/face_swap.py:81-97 smooth_face_boundry = e4s_erode_u8 (cv2.erode, flat (2r+1)^2, BORDER_CONSTANT) ->

@@ -324,7 +324,7 @@ def test_unmasked_polyphase_upconv_bf16x3_vs_oracle(cin, cout, res, monkeypatch)
     assert maxabs(got, want) < 1e-4 * float(want.abs().max())
 
 
-@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 128, 64, 32, 32), (3, 64, 32, 24, 40), (2, 256, 128, 16, 16), (1, 32, 32, 15, 33),
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 128, 64, 32, 32), (3, 64, 32, 24, 40), (2, 256, 128, 16, 16), (1, 64, 32, 15, 33), (2, 192, 96, 9, 20),
                                             (1, 128, 64, 256, 256), (1, 64, 32, 512, 512)])
 def test_unmasked_exact_upconv_bf16x3_vs_oracle(b, cin, cout, h, w, monkeypatch):
     """the unmasked up-sampling StyledConvs (model.py:287-300 + Blur :206-213; the 128 -> 64 -> 512^2 and
@@ -355,6 +355,64 @@ def test_unmasked_exact_upconv_bf16x3_vs_oracle(b, cin, cout, h, w, monkeypatch)
     assert maxabs(got, want) < 5e-5 * scale, (maxabs(got, want), scale)
     got2 = m(x.to(DEV), style.to(DEV), None, noise=noise.to(DEV))
     assert torch.equal(got, got2)                                  # no atomics anywhere: bit-reproducible
+
+
+@pytest.mark.parametrize("b,cout,h,w", [(2, 32, 48, 48), (1, 32, 37, 70), (3, 64, 16, 33), (1, 32, 256, 256)])
+def test_conv_c32_resident_weights_and_fused_torgb_vs_oracle(b, cout, h, w, monkeypatch):
+    """the Cin == 32 StyledConv (the generator's 32 -> 32 layer at 1024^2) on e4s_conv_c32_bf16x3_f32 -- weights
+    resident in LDS, halos fetched two tiles ahead, partial edge tiles -- against the oracle's modulated conv + noise + bias +
+    activation (<= 5e-5 of the output scale); and the ToRGB contraction fused into its epilogue + e4s_torgb_finish_f32 against
+    the standalone e4s_torgb_f32 pass over the same activation (model.py:422-448) and against the oracle."""
+    from e4s_amd import kernels as K
+    from e4s_amd import stylegan2
+    from e4s_amd.stylegan2 import StyledConv, ToRGB
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    assert stylegan2.CONV_C32
+    sd = _styled_sd(32, cout, False, 16)
+    m = StyledConv(32, cout, 3, 512, upsample=False, mask_op=False)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(b, 32, h, w, generator=g)
+    style = torch.randn(b, 512, generator=g)
+    noise = torch.randn(b if b > 1 else 1, 1, h, w, generator=g)
+    want = orc.styled_conv(sd, "", x, style, None, noise, False, False)
+    calls = []
+    real = K.conv_c32
+    monkeypatch.setattr(K, "conv_c32", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    got = m(x.to(DEV), style.to(DEV), None, noise=noise.to(DEV))
+    assert calls, "the Cin == 32 kernel was not the one that ran"
+    scale = float(want.abs().max())
+    assert maxabs(got, want) < 5e-5 * scale, (maxabs(got, want), scale)
+    assert torch.equal(got, m(x.to(DEV), style.to(DEV), None, noise=noise.to(DEV)))
+    if cout != 32:
+        return
+    # ---- fused ToRGB ----
+    rgb_sd = {"conv.weight": synth.synth_tensor("rgb.w", (1, 3, 32, 1, 1), "randn", 3),
+              "conv.modulation.weight": synth.synth_tensor("rgb.mw", (32, 512), "randn", 3),
+              "conv.modulation.bias": synth.synth_tensor("rgb.mb", (32,), "modbias", 3),
+              "bias": synth.synth_tensor("rgb.b", (1, 3, 1, 1), "bias", 3), "upsample.kernel": orc.make_blur_kernel() * 4}
+    t = ToRGB(32, 512, mask_op=False)
+    t.load_state_dict(rgb_sd)
+    t = t.to(DEV)
+    style_rgb = torch.randn(b, 512, generator=g)
+    skip = torch.randn(b, 3, h // 2, w // 2, generator=g) if (h % 2 == 0 and w % 2 == 0) else None
+    s_c = K.modulate_vec(style.to(DEV), m.conv.modulation.weight, m.conv.modulation.bias)
+    d = K.demod_coefs(s_c, m.conv.packed()["wsq"], m.conv.scale)
+    s_r = K.modulate_vec(style_rgb.to(DEV), t.conv.modulation.weight, t.conv.modulation.bias)
+    ws = K.rgb_weights(t.conv.packed()["w"].view(3, -1), s_r, t.conv.scale)
+    xn = K.nchw_to_nhwc(x.to(DEV))
+    nzd = noise.to(DEV)
+    y, partial = K.conv_c32(xn, m.conv.split_weights(), 32, in_scale=s_c, out_scale=d, noise=nzd, noise_w=m.noise.weight,
+                            bias=m.activate.bias, act=1, alpha=m.activate.negative_slope, gain=m.activate.scale, rgb_ws=ws)
+    assert torch.equal(K.nhwc_to_nchw(y), got)                         # the rgb epilogue does not disturb y
+    skd = skip.to(DEV) if skip is not None else None
+    fused = K.torgb_finish(partial, t.bias, skd, t.upsample.kernel if skd is not None else None)
+    separate = K.torgb(y, ws, t.bias, skd, t.upsample.kernel if skd is not None else None, None, 1)
+    rscale = float(separate.abs().max())
+    assert maxabs(fused, separate) < 2e-6 * rscale
+    want_rgb = orc.to_rgb(rgb_sd, "", want, style_rgb, None, skip, False)
+    assert maxabs(fused, want_rgb) < 1e-4 * float(want_rgb.abs().max())
 
 
 # ---------------------------------------------------------------------------------------------

@@ -120,14 +120,19 @@ for tag, b, res, cin, cout, kind in CASES:
         if kind == "same":
             row["f32_ms"] = timeit(lambda: K.conv_mfma(x, w, cout, **kw))
             row["bf16x3_ms"] = timeit(lambda: K.conv_mfma(x, w, cout, w_split=ws, **kw))
+            if cin == 32:
+                row["bf16x3_generic_ms"] = row["bf16x3_ms"]
+                row["bf16x3_ms"] = timeit(lambda: K.conv_c32(x, ws, cout, **kw))             # resident weights
+                wrgb = torch.randn(b, 3, 32, device=dev)
+                row["bf16x3_with_torgb_ms"] = timeit(lambda: K.conv_c32(x, ws, cout, rgb_ws=wrgb, **kw))
         else:
             w3 = torch.randn(1, 9, cout, cin, device=dev) / (3 * cin ** 0.5)
             row["f32_ms"] = timeit(lambda: K.upconv_mfma(x, w3, cout, k4, **kw))
             row["f32_poly_ms"] = timeit(lambda: K.conv_mfma(x, w, cout, ncls=4, ostride=2, **kw))
             row["bf16x3_poly_ms"] = timeit(lambda: K.conv_mfma(x, w, cout, ncls=4, ostride=2, w_split=ws, **kw))
             wraw = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
-            wsub = K.split_bf16x2(K.subpixel_weights(wraw))
-            row["bf16x3_ms"] = timeit(lambda: K.upconv_bf16x3(x, wsub, cout, k4, **kw))     # exact sub-pixel GEMM + FIR pass
+            wsub = K.subpixel_weights(wraw)
+            row["bf16x3_ms"] = timeit(lambda: K.upconv_bf16x3(x, wsub, cout, k4, **kw))     # exact: fused sub-pixel GEMM + FIR epilogue
     row = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items()}
     row["bf16x3_tflops_alg"] = round(row["gflop_alg"] / row["bf16x3_ms"], 1)
     rows.append(row)
