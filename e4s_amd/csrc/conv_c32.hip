@@ -2,18 +2,25 @@
 // ToRGB partial fused into the epilogue -- the generator's last StyledConv (32 -> 32 at 1024^2, model.py:537-549, 655-657) and the
 // ToRGB behind it (model.py:422-448).
 //
+// (Round-3 measurements, 8 images at 1024^2, ms: generic kernel 0.97; this kernel as ONE 512-thread block per CU with dword stores
+// from the accumulators 0.86; stores transposed through LDS 0.70; ablations of that version -- no MFMA loop 0.51, no halo loads
+// 0.58, no stores 0.61, no epilogue 0.54: no single phase is the bound, the phases of the one resident block add up.  256-thread
+// blocks, two per CU, on 8x16 tiles were SLOWER (0.75: 40 % halo overhead, twice the barriers); what is left is wave
+// specialisation (loader / MFMA / store waves) -- not done.)
 // That layer is HBM-bound (8 images: 1.07 GB in + 1.07 GB out, 0.36 ms at 6 TB/s; its 155 GFLOP are 0.15 ms of MFMA time), but
 // ran at 0.97 ms on the generic kernel: with K = 288 a 256-pixel tile is only 54 MFMAs per wave, and the generic
 // pipeline re-stages the weights every 3 taps (3 barriers per tile) and re-reads each A fragment per 32 columns.  Here:
 //   * the 9 x 32 x 32 weights (split hi/lo bf16, 41 KB) are staged ONCE per block and stay in LDS;
 //   * one stage = one 16x16-pixel tile: its 18x18 halo (32 channels, split once while staged) sits in a single LDS buffer and
 //     is fetched into registers TWO tiles ahead (two register sets, even / odd tiles), so an HBM round trip has two whole tiles
-//     to complete; 2 barriers per tile;
-//   * the epilogue (demodulation, noise, bias, activation) stores y and, when asked, drops the tile into LDS so that
+//     to complete; 2 barriers per tile (3 with the ToRGB partial);
+//   * the epilogue (demodulation, noise, bias, activation) leaves through an LDS staging tile (16-byte stores, one 128-byte
+//     line per pixel: dword stores straight from the accumulators are store-issue bound) from which, when asked,
 //     rgb_partial[b, c, p] = sum_co y[b, p, co] * ws[b, c, co] (the ToRGB 1x1 modulated conv) comes out of the same pass: the
 //     134 MB activation per image is not read again; e4s_torgb_finish_f32 adds bias + FIR-upsampled skip.
 // Arithmetic as conv_bf16x3.hip: three v_mfma_f32_32x32x16_bf16 per product on hi/lo-split fp32 operands, fp32 accumulate.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -21,12 +28,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KC = 32, ROWB = 144, LO = 64;
-constexpr int TW = 16, TH = 16, HALO_W = TW + 2, HALO = (TH + 2) * HALO_W;      // 324
-constexpr int BM = 256, BN = 32, NTHR = 512;
+constexpr int TW = 16, TH = 16, HALO_W = TW + 2, HALO = (TH + 2) * HALO_W;      // 16 x 16-pixel tiles, 324 halo pixels
+constexpr int BM = TH * TW, BN = 32, NTHR = 512;                                // 8 waves x (32 pixels x 32 channels)
 constexpr int ITEMS = HALO * 4, AJ = (ITEMS + NTHR - 1) / NTHR;                 // 1296 items, 3 per thread
 constexpr int BPIECES = 9 * BN * 8, BJ = (BPIECES + NTHR - 1) / NTHR;           // 2304 16-byte pieces, 5 per thread (once)
 constexpr int A_BYTES = HALO * ROWB, B_BYTES = 9 * BN * ROWB;
-constexpr int YLD = 36;                                                         // floats per pixel row of the rgb staging tile
+constexpr int YLD = 36;                                                         // floats per pixel row of the output staging tile
 constexpr int SMEM = B_BYTES + A_BYTES + BM * 8 + BM * YLD * 4 + 3 * BN * 4;
 static_assert(SMEM <= 160 * 1024, "LDS budget");
 
@@ -50,13 +57,15 @@ struct TileId { int tb, tyb, txb, nt; };
 template <int XF, int RGB>
 __global__ __launch_bounds__(NTHR) void conv_c32_kernel(const e4s_conv_params p, const float* __restrict__ rgb_ws,
                                                         float* __restrict__ rgb_partial, const int ntn, const int tx_n,
-                                                        const int per_img, const int ntiles) {
+                                                        const int per_img, const int ntiles, const int abl) {
+    // abl (profiling builds only, -DE4S_ABLATIONS + env E4S_C32_ABL; results WRONG): 1 no MFMA loop, 2 no halo loads, 3 no output
+    // stores, 4 no halo staging (split + LDS write), 5 no epilogue at all
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sB = smem;                                   // [9][32][ROWB]  resident weights of this block's n-tile
     unsigned char* sA = smem + B_BYTES;                         // [HALO][ROWB]
     int* s_out = reinterpret_cast<int*>(sA + A_BYTES);          // [BM] output pixel index or -1
     float* s_nz = reinterpret_cast<float*>(s_out + BM);         // [BM]
-    float* sY = s_nz + BM;                                      // [BM][YLD]  (RGB)
+    float* sY = s_nz + BM;                                      // [BM][YLD]  output staging tile
     float* sWS = sY + BM * YLD;                                 // [3][32]    (RGB)
 
     const int tid = threadIdx.x;
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(NTHR) void conv_c32_kernel(const e4s_conv_params p,
         for (int j = 0; j < AJ; ++j) {
             const int item = tid + NTHR * j;
             const size_t off = item_src(id, item, R.ok[j]);
-            R.a[j] = load8(xb + off);
+            if (abl != 2) R.a[j] = load8(xb + off);
         }
         if (XF) R.sc = load8(p.in_scale + (real ? (size_t)id.tb * KC : 0) + (tid & 3) * 8);
     };
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(NTHR) void conv_c32_kernel(const e4s_conv_params p,
     auto process = [&](AReg& R) {
         __syncthreads();                                        // every reader of sA / sY of the previous tile is done
         if (cur.nt != res_nt) { res_nt = cur.nt; load_weights(res_nt); }
-        store_a(R);
+        if (abl != 4) store_a(R);
         {
             const int t2 = t_cur + 2 * G;
             fetch_a(R, decode(t2 < ntiles ? t2 : t_cur), t2 < ntiles);
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(NTHR) void conv_c32_kernel(const e4s_conv_params p,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < (abl == 1 ? 0 : 9); ++tap) {
             const unsigned char* At = sA + ((tap / 3) * HALO_W + (tap % 3)) * ROWB + arow;
             const unsigned char* Bt = sB + tap * (BN * ROWB) + brow;
 #pragma unroll
@@ -183,6 +192,7 @@ __global__ __launch_bounds__(NTHR) void conv_c32_kernel(const e4s_conv_params p,
             }
         }
         // ---- epilogue ----
+        if (abl == 5) { asm volatile("" :: "v"(acc[0]), "v"(acc[5])); return; }
         const int co = cur.nt * BN + li;
         const float osc = p.out_scale ? p.out_scale[(size_t)cur.tb * p.Cout + co] : 1.f;
         const float bsv = p.bias ? p.bias[co] : 0.f;
@@ -191,14 +201,26 @@ __global__ __launch_bounds__(NTHR) void conv_c32_kernel(const e4s_conv_params p,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int off = s_out[row];
             float v = acc[r] * osc + s_nz[row] + bsv;
             if (p.act) v = (v > 0.f ? v : v * p.alpha) * gain;
-            if (off >= 0) p.y[(size_t)off * ycs + co] = v;
-            if (RGB) sY[row * YLD + li] = v;
+            sY[row * YLD + li] = v;
+        }
+        __syncthreads();
+        // the tile leaves through LDS: 16 dword stores per lane straight from the accumulators (128 store instructions per
+        // tile) are store-ISSUE bound on this chip (~70 cycles each: 9-10k cycles per tile against 3.5k of MFMA time);
+        // transposed, a thread stores 4 x 16 bytes and 8 lanes cover one pixel's 128-byte line
+        {
+            const int c4 = tid & 7;
+#pragma unroll
+            for (int ps = 0; ps < BM / (NTHR / 8); ++ps) {
+                const int px = ps * (NTHR / 8) + (tid >> 3);
+                const int off = s_out[px];
+                if (off >= 0 && abl != 3)
+                    *reinterpret_cast<f32x4*>(p.y + (size_t)off * ycs + cur.nt * BN + c4 * 4) =
+                        *reinterpret_cast<const f32x4*>(sY + px * YLD + c4 * 4);
+            }
         }
         if (RGB) {
-            __syncthreads();
             // thread = (pixel, half of the 32 channels): 3 dot products of 16, combined across the lane pair
             const int px = tid >> 1, hf = tid & 1;
             const float* yp = sY + px * YLD + hf * 16;
@@ -290,8 +312,13 @@ int launch(const e4s_conv_params& p, const float* rgb_ws, float* rgb_partial, hi
     const int tx_n = (p.Wo + TW - 1) / TW, per_img = ((p.Ho + TH - 1) / TH) * tx_n;
     const int64_t ntiles = (int64_t)p.B * per_img * ntn;
     if (ntiles >= (1ll << 31)) return (int)hipErrorInvalidValue;
-    const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHR), SMEM, st, p, rgb_ws, rgb_partial, ntn, tx_n, per_img, (int)ntiles);
+    const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());               // persistent, one block per CU
+    int abl = 0;
+#ifdef E4S_ABLATIONS
+    if (const char* e = getenv("E4S_C32_ABL")) abl = atoi(e);
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHR), SMEM, st, p, rgb_ws, rgb_partial, ntn, tx_n, per_img, (int)ntiles,
+                       abl);
     E4S_CHECK_LAUNCH();
     return 0;
 }
