@@ -446,22 +446,49 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) st_s[tn] = st_q[tn] = 0.0;
             float* yo = raw ? p.splitk_ws + (size_t)cur.ks * ((size_t)p.B * p.Ho * p.Wo * ycs) : p.y;
+            // registers 4g .. 4g+3 of an accumulator are rows i + 8g + 4kh (i = 0..3) of ONE column per lane: epilogue math per
+            // element, then a 4x4 transpose across each lane quad, then one 16-byte store per (row, 4 columns) -- 4x fewer store
+            // instructions (stores from the accumulators are store-issue bound: common.h)
+            const bool wide = (ycs & 3) == 0;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    const int off = so[row];
-                    if (off < 0) continue;
+                for (int g = 0; g < 4; ++g) {
+                    float v[TN][4];
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        float v = acc[tm][tn][r];
-                        if (!raw) {
-                            v = v * osc[tn] + sn[row * NZ + (SHUF ? nzi[tn] : 0)] + bsv[tn];
-                            if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;
+                        const int row = (wm * TM + tm) * 32 + i + 8 * g + 4 * kh;
+                        const bool live = so[row] >= 0;
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) {
+                            float t = acc[tm][tn][r];
+                            if (!raw) {
+                                t = t * osc[tn] + sn[row * NZ + (SHUF ? nzi[tn] : 0)] + bsv[tn];
+                                if (do_act) t = (t > 0.f ? t : t * slp[tn]) * gain;
+                            }
+                            v[tn][i] = t;
+                            if (stats && live) { st_s[tn] += (double)t; st_q[tn] += (double)t * (double)t; }
                         }
-                        yo[(size_t)off * ycs + coff[tn]] = v;
-                        if (stats) { st_s[tn] += (double)v; st_q[tn] += (double)v * (double)v; }
+                    }
+                    if (wide) {
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) quad_transpose4(v[tn][0], v[tn][1], v[tn][2], v[tn][3], li);
+                        const int off = so[(wm * TM + tm) * 32 + (li & 3) + 8 * g + 4 * kh];
+                        if (off >= 0) {
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn)
+                                *reinterpret_cast<f32x4*>(yo + (size_t)off * ycs + coff[tn] - (li & 3)) =
+                                    f32x4{v[tn][0], v[tn][1], v[tn][2], v[tn][3]};
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int off = so[(wm * TM + tm) * 32 + i + 8 * g + 4 * kh];
+                            if (off < 0) continue;
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn) yo[(size_t)off * ycs + coff[tn]] = v[tn][i];
+                        }
                     }
                 }
             }
@@ -766,24 +793,37 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
     const float gain = (p.act == 1) ? p.gain : 1.f;
     const bool do_act = p.act != 0, scaled = p.out_scale != nullptr, raw = ksplit > 1;
     float* yo = raw ? p.splitk_ws + (size_t)ks * ((size_t)p.B * p.Ho * p.Wo * p.Cout) : p.y;
+    // epilogue math per element, 4x4 transpose across each lane quad, one 16-byte store per (row, 4 columns): see the plain kernel
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int off = s_out[row];
-            if (off < 0) continue;
-            const float nz = s_nz[row];
-            const float* drow = sD + s_grp[row] * BN;
+        for (int g = 0; g < 4; ++g) {
+            float v[TN][4];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int ncol = (wn * TN + tn) * 32 + li;
-                float v = acc[tm][tn][r] * (scaled ? drow[ncol] : 1.f);
-                if (!raw) {
-                    v += nz + bsv[tn];
-                    if (do_act) v = (v > 0.f ? v : v * p.alpha) * gain;
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g + i;
+                const int row = (wm * TM + tm) * 32 + i + 8 * g + 4 * kh;
+                const float nz = s_nz[row];
+                const float* drow = sD + s_grp[row] * BN;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int ncol = (wn * TN + tn) * 32 + li;
+                    float t = acc[tm][tn][r] * (scaled ? drow[ncol] : 1.f);
+                    if (!raw) {
+                        t += nz + bsv[tn];
+                        if (do_act) t = (t > 0.f ? t : t * p.alpha) * gain;
+                    }
+                    v[tn][i] = t;
                 }
-                yo[(size_t)off * p.Cout + n0 + ncol] = v;
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) quad_transpose4(v[tn][0], v[tn][1], v[tn][2], v[tn][3], li);
+            const int off = s_out[(wm * TM + tm) * 32 + (li & 3) + 8 * g + 4 * kh];
+            if (off >= 0) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    *reinterpret_cast<f32x4*>(yo + (size_t)off * p.Cout + n0 + (wn * TN + tn) * 32 + (li & ~3)) =
+                        f32x4{v[tn][0], v[tn][1], v[tn][2], v[tn][3]};
             }
         }
     }
@@ -979,19 +1019,43 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
     double st_s[TN], st_q[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) st_s[tn] = st_q[tn] = 0.0;
+    const int gycs = p.y_cstride ? p.y_cstride : p.Cout;
+    const bool wide = (gycs & 3) == 0;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int off = s_out[row];
-            if (off < 0) continue;
+        for (int g = 0; g < 4; ++g) {
+            float v[TN][4];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                float v = acc[tm][tn][r] + bsv[tn];
-                if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
-                p.y[(size_t)off * (p.y_cstride ? p.y_cstride : p.Cout) + n0 + (wn * TN + tn) * 32 + li] = v;
-                if (stats) { st_s[tn] += (double)v; st_q[tn] += (double)v * (double)v; }
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g + i;
+                const bool live = s_out[(wm * TM + tm) * 32 + i + 8 * g + 4 * kh] >= 0;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    float t = acc[tm][tn][r] + bsv[tn];
+                    if (do_act) t = (t > 0.f ? t : t * slp[tn]) * gain;
+                    v[tn][i] = t;
+                    if (stats && live) { st_s[tn] += (double)t; st_q[tn] += (double)t * (double)t; }
+                }
+            }
+            if (wide) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) quad_transpose4(v[tn][0], v[tn][1], v[tn][2], v[tn][3], li);
+                const int off = s_out[(wm * TM + tm) * 32 + (li & 3) + 8 * g + 4 * kh];
+                if (off >= 0) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        *reinterpret_cast<f32x4*>(p.y + (size_t)off * gycs + n0 + (wn * TN + tn) * 32 + (li & ~3)) =
+                            f32x4{v[tn][0], v[tn][1], v[tn][2], v[tn][3]};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int off = s_out[(wm * TM + tm) * 32 + i + 8 * g + 4 * kh];
+                    if (off < 0) continue;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) p.y[(size_t)off * gycs + n0 + (wn * TN + tn) * 32 + li] = v[tn][i];
+                }
             }
         }
     }

@@ -231,14 +231,19 @@ __global__ __launch_bounds__(NTHR, 2) void conv_bwd_kernel(const e4s_conv_bwd_pa
     }
 
     // ---- store dx, flush ds -----------------------------------------------------------------------
+    // 4x4 quad transposes turn the accumulators' one-column-per-lane layout into 16-byte NHWC stores (common.h)
+    {
+        float* dxo = gsplit > 1 ? dx_ws + (size_t)gs * ((size_t)p.B * p.Hx * p.Wx * p.Cx) : p.dx;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+        for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int off = sm.out_off[row];
-            float* dxo = gsplit > 1 ? dx_ws + (size_t)gs * ((size_t)p.B * p.Hx * p.Wx * p.Cx) : p.dx;
-            if (off >= 0) dxo[(size_t)off * p.Cx + n0 + wn * 32 + li] = acc[tm][r];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float v0 = acc[tm][4 * g4], v1 = acc[tm][4 * g4 + 1], v2 = acc[tm][4 * g4 + 2], v3 = acc[tm][4 * g4 + 3];
+                quad_transpose4(v0, v1, v2, v3, li);
+                const int off = sm.out_off[(wm * TM + tm) * 32 + (li & 3) + 8 * g4 + 4 * kh];
+                if (off >= 0)
+                    *reinterpret_cast<f32x4*>(dxo + (size_t)off * p.Cx + n0 + wn * 32 + (li & ~3)) = f32x4{v0, v1, v2, v3};
+            }
         }
     }
     if (p.ds) {

@@ -377,26 +377,50 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
     const int ycs = p.y_cstride ? p.y_cstride : p.Cout;
     const bool raw = ksplit > 1;
     float* yo = raw ? p.splitk_ws + (size_t)ks * ((size_t)p.B * p.Ho * p.Wo * ycs) : p.y;
+    // epilogue math per element, then 4x4 quad transposes: 16-byte NHWC stores instead of four times as many 4-byte ones (common.h)
+    const bool wide = (ycs & 3) == 0;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int off = s_out[row];
-            if (off < 0) continue;
-            const float nz = s_nz[row];
-            const float* drow = sD + (row_scale ? s_grp[row] * BN : 0);
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float v[TN][4];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int ncol = (wn * TN + tn) * 32 + li;
-                const float sc = row_scale ? drow[ncol] : osc[tn];
-                float v = acc[tm][tn][r] * sc;
-                if (!raw) {
-                    const float nzv = nz_pc ? nzw * p.noise[(size_t)__float_as_int(nz) * p.Cout + n0 + ncol] : nz;
-                    v += nzv + bsv[tn];
-                    if (do_act) v = (v > 0.f ? v : v * slp[tn]) * gain;
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g4 + i;
+                const int row = (wm * TM + tm) * 32 + i + 8 * g4 + 4 * kh;
+                const float nz = s_nz[row];
+                const float* drow = sD + (row_scale ? s_grp[row] * BN : 0);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int ncol = (wn * TN + tn) * 32 + li;
+                    const float sc = row_scale ? drow[ncol] : osc[tn];
+                    float t = acc[tm][tn][r] * sc;
+                    if (!raw) {
+                        const float nzv = nz_pc ? nzw * p.noise[(size_t)__float_as_int(nz) * p.Cout + n0 + ncol] : nz;
+                        t += nzv + bsv[tn];
+                        if (do_act) t = (t > 0.f ? t : t * slp[tn]) * gain;
+                    }
+                    v[tn][i] = t;
                 }
-                yo[(size_t)off * ycs + n0 + ncol] = v;
+            }
+            if (wide) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) quad_transpose4(v[tn][0], v[tn][1], v[tn][2], v[tn][3], li);
+                const int off = s_out[(wm * TM + tm) * 32 + (li & 3) + 8 * g4 + 4 * kh];
+                if (off >= 0) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        *reinterpret_cast<f32x4*>(yo + (size_t)off * ycs + n0 + (wn * TN + tn) * 32 + (li & ~3)) =
+                            f32x4{v[tn][0], v[tn][1], v[tn][2], v[tn][3]};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int off = s_out[(wm * TM + tm) * 32 + i + 8 * g4 + 4 * kh];
+                    if (off < 0) continue;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) yo[(size_t)off * ycs + n0 + (wn * TN + tn) * 32 + li] = v[tn][i];
+                }
             }
         }
     }
