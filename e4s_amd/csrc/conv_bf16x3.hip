@@ -90,7 +90,7 @@ __global__ void splitk_epilogue_kernel(const e4s_conv_params p, const int ksplit
 inline void few_tiles_split(int64_t tiles, int nchunk, int& ksplit, int& cper) {
     ksplit = 1;
     cper = nchunk;
-    if (tiles >= 128 || nchunk < 4) return;
+    if (tiles > 128 || nchunk < 4) return;        // <= 128 tiles: two K halves fill the 256 CUs (the masked 32^2 layers ran on half the chip)
     int want = (int)((256 + tiles - 1) / tiles);
     if (want > nchunk / 2) want = nchunk / 2;
     if (want < 2) return;

@@ -261,34 +261,45 @@ __global__ __launch_bounds__(NTHR) void conv_c32_kernel(const e4s_conv_params p,
     }
 }
 
-// out = partial + bias[c] + upfirdn2d(skip, k4, up=2, pad=(2,1))   (ToRGB's tail, model.py:441-446); NCHW [B,3,H,W]
-__global__ void torgb_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bias, const float* __restrict__ skip,
-                                    const float* __restrict__ k4, float* __restrict__ out, int H, int W, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int xx = (int)(i % W);
-    int64_t q = i / W;
-    const int yy = (int)(q % H);
-    q /= H;                                                     // b * 3 + ch
-    float v = partial[i] + bias[(int)(q % 3)];
+// out = partial + bias[c] + upfirdn2d(skip, k4, up=2, pad=(2,1))   (ToRGB's tail, model.py:441-446); NCHW [B,3,H,W].
+// Thread = 4 consecutive pixels of one row (16-byte loads / stores); grid (W/4 blocks of 64, H, B*3).
+__global__ __launch_bounds__(64) void torgb_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                          const float* __restrict__ skip, const float* __restrict__ k4,
+                                                          float* __restrict__ out, int H, int W) {
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (x0 >= W) return;
+    const int yy = blockIdx.y, plane = blockIdx.z;               // plane = b * 3 + ch
+    const size_t row = ((size_t)plane * H + yy) * W + x0;
+    const bool vec = (W & 3) == 0;                               // otherwise rows are not 16-byte aligned: element-wise tail path
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (vec) v = *reinterpret_cast<const f32x4*>(partial + row);
+    else
+        for (int e = 0; e < 4; ++e)
+            if (x0 + e < W) v[e] = partial[row + e];
+    v += bias[plane % 3];
     if (skip) {
         const int Hs = H >> 1, Ws = W >> 1;
-        const float* sp = skip + q * (int64_t)Hs * Ws;
-        float acc = 0.f;
+        const float* sp = skip + (size_t)plane * Hs * Ws;
 #pragma unroll
         for (int jy = 0; jy < 4; ++jy) {
             const int qy = yy + jy - 2;
             if (qy < 0 || (qy & 1) || (qy >> 1) >= Hs) continue;
+            const float* sr = sp + (size_t)(qy >> 1) * Ws;
 #pragma unroll
-            for (int jx = 0; jx < 4; ++jx) {
-                const int qx = xx + jx - 2;
-                if (qx < 0 || (qx & 1) || (qx >> 1) >= Ws) continue;
-                acc += sp[(qy >> 1) * Ws + (qx >> 1)] * k4[15 - (jy * 4 + jx)];
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    const int qx = x0 + e + jx - 2;
+                    if (qx < 0 || (qx & 1) || (qx >> 1) >= Ws) continue;
+                    v[e] += sr[qx >> 1] * k4[15 - (jy * 4 + jx)];
+                }
             }
         }
-        v += acc;
     }
-    out[i] = v;
+    if (vec) *reinterpret_cast<f32x4*>(out + row) = v;
+    else
+        for (int e = 0; e < 4; ++e)
+            if (x0 + e < W) out[row + e] = v[e];
 }
 
 int num_cus() {
@@ -343,10 +354,9 @@ extern "C" int e4s_conv_c32_bf16x3_f32(const e4s_conv_params* pp, const float* r
 extern "C" int e4s_torgb_finish_f32(const float* partial, const float* bias, const float* skip, const float* k4, float* out, int B,
                                     int H, int W, void* stream) {
     if (!partial || !bias || !out || (skip && (!k4 || ((H | W) & 1)))) return (int)hipErrorInvalidValue;
-    const int64_t n = (int64_t)B * 3 * H * W;
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(torgb_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), partial, bias,
-                       skip, k4, out, H, W, n);
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    hipLaunchKernelGGL(torgb_finish_kernel, dim3((unsigned)(((W + 3) / 4 + 63) / 64), (unsigned)H, (unsigned)(B * 3)), dim3(64), 0,
+                       as_stream(stream), partial, bias, skip, k4, out, H, W);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -100,6 +100,43 @@ __global__ void instnorm_partial_kernel(const float* __restrict__ x, double* __r
     }
 }
 
+// Small maps (HW <= 4096: the 64^2 .. 16^2 levels, where a split-K conv cannot emit the statistics itself): ONE launch, block =
+// (sample, 64-channel slab), 16 pixel groups x 64 channels; fp64 partial sums added in a fixed order, mean / rstd / pooled
+// written directly (the same formulas as instnorm_finalize_kernel).  Batch-1 latency runs paid two launches per statistic.
+__global__ __launch_bounds__(1024) void instnorm_small_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                              float* __restrict__ pooled, int HW, int C, float eps) {
+    const int slabs = C / 64;
+    const int slab = blockIdx.x % slabs, b = blockIdx.x / slabs;
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;       // 16 pixel groups x 64 channels
+    const int c = slab * 64 + cl;
+    const float* xb = x + (int64_t)b * HW * C + c;
+    double s = 0.0, q = 0.0;
+    for (int p = pg; p < HW; p += 16) {
+        const double v = (double)xb[(int64_t)p * C];
+        s += v;
+        q += v * v;
+    }
+    __shared__ double red[2][16][64];
+    red[0][pg][cl] = s;
+    red[1][pg][cl] = q;
+    __syncthreads();
+    if (pg == 0) {
+        s = 0.0;
+        q = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
+        const double mean = s / HW;
+        double var = q / HW - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mean;
+        const float rstd = rsqrtf((float)var + eps);
+        const int64_t i = (int64_t)b * C + c;
+        stats[i * 2] = mf;
+        stats[i * 2 + 1] = rstd;
+        if (pooled) pooled[i] = (float)((mean - (double)mf) * (double)rstd);
+    }
+}
+
 __global__ void instnorm_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats,
                                          float* __restrict__ pooled, int n, int HW, float eps, int nsplit) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,7 +289,18 @@ __global__ void se_gate_kernel(const float* __restrict__ pooled_in, const float*
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float a = 0.f;
-        for (int j = 0; j < Cr; ++j) a += fc2[(int64_t)c * Cr + j] * hidden[j];
+        if ((Cr & 3) == 0) {          // a thread's fc2 row is one contiguous 16..128-byte run: read it as float4s (same summation order)
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(fc2 + (int64_t)c * Cr);
+            for (int j = 0; j < Cr; j += 4) {
+                const f32x4 w = w4[j >> 2];
+                a += w[0] * hidden[j];
+                a += w[1] * hidden[j + 1];
+                a += w[2] * hidden[j + 2];
+                a += w[3] * hidden[j + 3];
+            }
+        } else {
+            for (int j = 0; j < Cr; ++j) a += fc2[(int64_t)c * Cr + j] * hidden[j];
+        }
         gate[(int64_t)b * C + c] = 1.f / (1.f + __expf(-a));
     }
 }
@@ -400,6 +448,11 @@ extern "C" int e4s_instnorm_stats_f32(const float* x, float* stats, float* poole
                                       float eps, void* stream) {
     if (C % 64) return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
+    if (HW <= 4096 && HW >= 16) {                       // policy independent of the batch: a sample's statistics never depend on it
+        hipLaunchKernelGGL(instnorm_small_kernel, dim3(B * (C / 64)), dim3(1024), 0, st, x, stats, pooled, HW, C, eps);
+        E4S_CHECK_LAUNCH();
+        return 0;
+    }
     const int nsplit = instnorm_nsplit(B, HW, C);
     hipLaunchKernelGGL(instnorm_partial_kernel, dim3(B * (C / 64) * nsplit), dim3(256), 0, st, x, ws, HW, C, nsplit);
     E4S_CHECK_LAUNCH();

@@ -349,7 +349,7 @@ def want_bf16x3(b, h, w, cin, cout, ncls=1, masked=False):
     bn = 128 if n % 128 == 0 else 64 if n % 64 == 0 else 32
     tiles = b * ((h + 15) // 16) * ((w + 15) // 16) * (n // bn) * (ncls if masked else 1)
     if tiles >= BF16X3_MIN_BLOCKS:
-        return True
+        return True       # (at exactly 128 tiles the kernels also split K two ways: csrc few_tiles_split)
     # few tiles (batch-1 latency runs): the kernels split the input channels over blocks (csrc: few_tiles_split)
     nchunk = cin // 32
     split = min(nchunk // 2, -(-256 // tiles)) if nchunk >= 4 else 1

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe4s_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int

@@ -334,7 +334,8 @@ def test_d_step_and_r1_step_vs_oracle_f64():
     # ---- R1 (second order) on the UPDATED weights ----
     now = {k: v.detach().clone() for k, v in disc.named_parameters()}
     r1 = it.r1_step(real.to(DEV))
-    sd64 = {k: v.cpu().double().requires_grad_(True) for k, v in now.items()}
+    sd64 = {k: v.double() for k, v in sdd.items()}                           # buffers (blur kernels) from the state dict ...
+    sd64.update({k: v.cpu().double().requires_grad_(True) for k, v in now.items()})      # ... parameters as updated by the D step
     x64 = real.double().requires_grad_(True)
     pred = orc.discriminator_forward(sd64, x64, size)
     gr, = torch.autograd.grad(pred.sum(), x64, create_graph=True)

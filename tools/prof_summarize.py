@@ -23,7 +23,7 @@ def trace(path):
         for row in csv.DictReader(fh):
             d = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
             key = short(row["Kernel_Name"])
-            if "conv_mfma" in key or "upconv" in key or "conv_bwd" in key or "conv_bf16x3" in key:
+            if "conv_mfma" in key or "upconv" in key or "conv_bwd" in key or "conv_bf16x3" in key or "conv_c32" in key:
                 key += " grid=%d" % (int(row["Grid_Size_X"]) // int(row["Workgroup_Size_X"]))
             a = agg[key]
             a[0] += 1
