@@ -129,6 +129,29 @@ def modulate_vec(style, mod_weight, mod_bias):
     return out
 
 
+_JOB_FMT = "qqqQQiiif"            # e4s_rowdot_job (include/e4s_hip.h): 3 x int64, 2 x pointer, 3 x int, float = 56 bytes
+
+
+def rowdot_jobs(jobs, device):
+    """jobs: list of dict(in_off, in_stride, out_off, M, bias, G, O, K, scale) -> (device table uint8, njobs, max_O, max_G).
+    M / bias are tensors (kept alive by the caller: the table holds their raw pointers).  One H2D copy: build OUTSIDE graph
+    capture (the generator caches the table per weight version)."""
+    import struct
+    buf = b"".join(struct.pack(_JOB_FMT, int(j["in_off"]), int(j["in_stride"]), int(j["out_off"]), j["M"].data_ptr(),
+                               j["bias"].data_ptr() if j["bias"] is not None else 0, int(j["G"]), int(j["O"]), int(j["K"]),
+                               float(j["scale"])) for j in jobs)
+    assert struct.calcsize(_JOB_FMT) == 56
+    for j in jobs:
+        if j["M"].dtype != torch.float32 or not j["M"].is_contiguous() or j["K"] % 4:
+            raise RuntimeError("rowdot_jobs: contiguous fp32 matrices with K % 4 == 0")
+    table = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(device)
+    return table, len(jobs), max(j["O"] for j in jobs), max(j["G"] for j in jobs)
+
+
+def rowdot_multi(table, njobs, max_o, max_g, in_base, out_base, mode):
+    call("e4s_rowdot_multi_f32", ptr(table), njobs, fptr(in_base), fptr(out_base), max_o, max_g, mode, stream())
+
+
 def demod_coefs(s, wsq, conv_scale):
     """conv_scale * rsqrt(conv_scale^2 * sum_ci s^2 Wsq[co,ci] + 1e-8): [G, Cout]."""
     g, cin = s.shape

@@ -106,6 +106,7 @@ SIGNATURES = {
     "e4s_clip_u8": [c_p, c_p, c_l, c_p],
     "e4s_conv_c32_bf16x3_f32": [c_p, c_p, c_p, c_p],
     "e4s_torgb_finish_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "e4s_rowdot_multi_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_ema_f32": [c_p, c_p, c_l, c_d, c_p],
     "e4s_adam_step_dev_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_p, c_i, c_p],
     "e4s_torgb_bwd_x_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],

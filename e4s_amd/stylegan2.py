@@ -300,7 +300,7 @@ class StyledConv(nn.Module):
         return (CONV_C32 and not conv.upsample and labels is None and plan is None and conv.in_channel == 32
                 and conv.out_channel % 32 == 0 and K.want_bf16x3(b, h, w, 32, conv.out_channel))
 
-    def run_nhwc(self, x, s, noise, labels=None, num_regions=1, plan=None, rec=None, rgb_ws=None):
+    def run_nhwc(self, x, s, noise, labels=None, num_regions=1, plan=None, rec=None, rgb_ws=None, d=None):
         """x NHWC, s [G,Cin] modulation (G = B*R when masked).  Masked layers pass the label map
         (region-select inside the GEMM) or, alternatively, a gathered RowPlan.  Returns NHWC output
         after noise + bias + leaky-ReLU*sqrt(2).  rgb_ws [B,3,32] (only where c32_eligible and Cout == 32): also return the
@@ -309,7 +309,8 @@ class StyledConv(nn.Module):
         pk = conv.packed()
         b, h, w, _ = x.shape
         ho, wo = (2 * h, 2 * w) if conv.upsample else (h, w)
-        d = K.demod_coefs(s, pk["wsq"], conv.scale)
+        if d is None:                            # (the generator's fused forward hands in all layers' coefficients, computed up front)
+            d = K.demod_coefs(s, pk["wsq"], conv.scale)
         nz, per_ch = _prep_noise(noise, b, ho, wo, x.device)
         if rec is not None:
             if per_ch:
@@ -539,6 +540,47 @@ class Generator(nn.Module):
             image, feats = self._fused_forward(latent, mask, noise)
         return (image, latent, feats) if return_latents else (image, None, feats)
 
+    def _style_plan(self, b, r, nlat, dev):
+        """Job tables of the batched style prologue (e4s_rowdot_multi_f32): every layer's modulation s = EqualLinear(style)
+        and demodulation d in two launches instead of ~43.  Cached per (shapes, weight versions): the tables hold raw pointers
+        of the modulation weights and of the cached sum_k W^2 matrices."""
+        layers = [(self.conv1, 0, "conv"), (self.to_rgb1, 1, "rgb")]
+        i = 1
+        for c1, c2, tr in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
+            layers += [(c1, i, "conv"), (c2, i + 1, "conv"), (tr, i + 2, "rgb")]
+            i += 2
+        key = (b, r, nlat, str(dev)) + tuple(_param_key(l.conv.modulation.weight, l.conv.modulation.bias, l.conv.weight)
+                                             for l, _, _ in layers)
+        plan = getattr(self, "_e4s_style_plan", None)
+        if plan is not None and plan["key"] == key:
+            return plan
+        sjobs, djobs, meta, keep = [], [], {}, []
+        s_off = d_off = 0
+        for layer, idx, kind in layers:
+            mod = layer.conv.modulation
+            cin = mod.weight.shape[0]
+            g = b * r if layer.mask_op else b
+            stride = nlat * 512 if layer.mask_op else r * nlat * 512
+            w, bs = mod.weight.detach(), mod.bias.detach()
+            keep += [w, bs]
+            sjobs.append(dict(in_off=idx * 512, in_stride=stride, out_off=s_off, M=w, bias=bs, G=g, O=cin, K=512,
+                              scale=1.0 / math.sqrt(512)))
+            m = {"s": (s_off, g, cin)}
+            if kind == "conv":
+                pk = layer.conv.packed()
+                cout = layer.conv.out_channel
+                keep.append(pk["wsq"])
+                djobs.append(dict(in_off=s_off, in_stride=cin, out_off=d_off, M=pk["wsq"], bias=None, G=g, O=cout, K=cin,
+                                  scale=layer.conv.scale))
+                m["d"] = (d_off, g, cout)
+                d_off += g * cout
+            s_off += g * cin
+            meta[id(layer)] = m
+        plan = {"key": key, "s": K.rowdot_jobs(sjobs, dev), "d": K.rowdot_jobs(djobs, dev), "meta": meta, "s_floats": s_off,
+                "d_floats": d_off, "keep": keep}
+        self._e4s_style_plan = plan
+        return plan
+
     @torch.no_grad()
     def _fused_forward(self, latent, mask, noise, tape=None):
         """`tape` (a list) records per layer what the backward needs (e4s_amd/autograd.py)."""
@@ -551,13 +593,27 @@ class Generator(nn.Module):
         if soft and tape is not None:
             raise NotImplementedError("backward with soft (non one-hot) masks")
 
+        # style prologue of ALL layers up front (two launches): s = modulation, d = demodulation coefficients
+        sp = None
+        if not soft and lat.shape[3] == 512:
+            sp = self._style_plan(b, r, lat.shape[2], lat.device)
+            sbuf = torch.empty(sp["s_floats"], device=lat.device, dtype=torch.float32)
+            dbuf = torch.empty(sp["d_floats"], device=lat.device, dtype=torch.float32)
+            K.rowdot_multi(*sp["s"], lat, sbuf, 0)
+            K.rowdot_multi(*sp["d"], sbuf, dbuf, 1)
+
+        def pre(layer, which):
+            off, g, c = sp["meta"][id(layer)][which]
+            return (sbuf if which == "s" else dbuf)[off:off + g * c].view(g, c)
+
         def styled(layer, x, idx, nz, rgb_ws=None):
             mod = layer.conv.modulation
-            s = K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
+            s = pre(layer, "s") if sp is not None else K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
             if soft and layer.mask_op:
                 return layer.run_nhwc_soft(x, s, nz, mask)
             rec = {} if tape is not None else None
-            y = layer.run_nhwc(x, s, nz, labels if layer.mask_op else None, r, rec=rec, rgb_ws=rgb_ws)
+            y = layer.run_nhwc(x, s, nz, labels if layer.mask_op else None, r, rec=rec, rgb_ws=rgb_ws,
+                               d=pre(layer, "d") if sp is not None else None)
             partial = None
             if rgb_ws is not None:
                 y, partial = y
@@ -571,7 +627,7 @@ class Generator(nn.Module):
             """conv2 (Cin == Cout == 32, unmasked) with the ToRGB 1x1 modulated conv of ITS OUTPUT in the epilogue
             (model.py:422-440), then bias + FIR-upsampled skip (model.py:441-446): the 1024^2 activation is not read again."""
             mod = to_rgb.conv.modulation
-            s_rgb = K.modulate(lat, idx + 1, False, mod.weight, mod.bias)
+            s_rgb = pre(to_rgb, "s") if sp is not None else K.modulate(lat, idx + 1, False, mod.weight, mod.bias)
             ws = K.rgb_weights(to_rgb.conv.packed()["w"].view(3, -1), s_rgb, to_rgb.conv.scale)
             y, partial = styled(conv2, x, idx, nz, rgb_ws=ws)
             out = K.torgb_finish(partial, to_rgb.bias, skip, to_rgb.upsample.kernel if skip is not None else None)
@@ -582,7 +638,7 @@ class Generator(nn.Module):
 
         def rgb(layer, x, idx, skip):
             mod = layer.conv.modulation
-            s = K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
+            s = pre(layer, "s") if sp is not None else K.modulate(lat, idx, layer.mask_op, mod.weight, mod.bias)
             if soft and layer.mask_op:
                 return layer.run_nhwc_soft(x, s, mask, skip)
             rec = {} if tape is not None else None

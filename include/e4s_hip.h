@@ -61,6 +61,18 @@ int e4s_channel_sum_f32(const float* g, float* out, int64_t n, int step_b, int s
  *        (M = sum_k W^2 [Cout,Cin]; the conv scale 1/sqrt(9*Cin) is folded into the coefficient) */
 int e4s_rowdot_f32(const float* in, int64_t in_stride, const float* M, const float* bias, float* out,
                    int G, int O, int K, int mode, float scale, void* stream);
+/* e4s_rowdot_f32 for many (layer) jobs in ONE launch: out_base[job.out_off + g*O + o] from in_base[job.in_off + g*in_stride + k].
+ * `jobs` is DEVICE memory (njobs records); M / bias inside a record are device pointers (bias may be NULL); K % 4 == 0;
+ * max_O / max_G: the largest O / G over the jobs (grid extent). mode as e4s_rowdot_f32. */
+typedef struct e4s_rowdot_job {
+    int64_t in_off, in_stride, out_off;
+    const float* M;
+    const float* bias;
+    int G, O, K;
+    float scale;
+} e4s_rowdot_job;
+int e4s_rowdot_multi_f32(const e4s_rowdot_job* jobs, int njobs, const float* in_base, float* out_base, int max_O, int max_G,
+                         int mode, void* stream);
 
 /* wsq[co, ci] = sum_k w[co, ci, k]^2 (w is [Cout, Cin, taps]) */
 int e4s_weight_sqsum_f32(const float* w, float* wsq, int cout, int cin, int taps, void* stream);
