@@ -163,6 +163,48 @@ extern "C" int e4s_channel_sum_f32(const float* g, float* out, int64_t n, int st
     return 0;
 }
 
+// up = down = 1 on a channels-last view (minor = C, C % 4 == 0): the Blur of every ConvLayer / ResBlock when the activations are
+// NHWC (Discriminator, GPEN: model.py:683-689).  The generic kernel above takes ONE minor index per block -- right for the
+// reference's [N*C, H, W, 1] view, but on [B, H, W, C] every 4-byte read is its own cache line: 19.7 % of the GPU time of the
+// config-5 legs (profiles/r03_train_kernel_stats.csv: 377 us average, 2.6 ms at 1024^2).  Here a thread owns 4 channels of one
+// output column and a strip of 4 output rows: (kh + 3) x kw 16-byte loads, contiguous across the lanes of a pixel.
+__global__ __launch_bounds__(256) void fir_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ k, float* __restrict__ y,
+                                                       int in_h, int in_w, int C, int kh, int kw, int pad_x0, int pad_y0,
+                                                       int out_h, int out_w) {
+    __shared__ float sk[64];
+    if (threadIdx.x < kh * kw) {
+        const int ky = threadIdx.x / kw, kx = threadIdx.x - ky * kw;
+        sk[threadIdx.x] = k[(kh - 1 - ky) * kw + (kw - 1 - kx)];      // flipped: true convolution (upfirdn2d_kernel.cu:77)
+    }
+    __syncthreads();
+    const int c4n = C >> 2, ppb = 256 / c4n;
+    const int c4 = threadIdx.x % c4n, pxl = threadIdx.x / c4n;
+    const int ox = blockIdx.x * ppb + pxl, oy0 = blockIdx.y * 4;
+    if (pxl >= ppb || ox >= out_w) return;
+    const float* xb = x + (size_t)blockIdx.z * in_h * in_w * C + c4 * 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ry = 0; ry < kh + 3; ++ry) {
+        const int iy = oy0 + ry - pad_y0;
+        if ((unsigned)iy >= (unsigned)in_h) continue;
+        for (int jx = 0; jx < kw; ++jx) {
+            const int ix = ox + jx - pad_x0;
+            if ((unsigned)ix >= (unsigned)in_w) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * in_w + ix) * C);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jy = ry - r;                      // output row oy0 + r reads input row (oy0 + r) + jy - pad_y0
+                if (jy >= 0 && jy < kh) acc[r] += v * sk[jy * kw + jx];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (oy0 + r < out_h)
+            *reinterpret_cast<f32x4*>(y + (((size_t)blockIdx.z * out_h + oy0 + r) * out_w + ox) * C + c4 * 4) = acc[r];
+}
+
 extern "C" int e4s_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
                                  int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
                                  int pad_y0, int pad_y1, void* stream) {
@@ -171,6 +213,14 @@ extern "C" int e4s_upfirdn2d_f32(const float* x, const float* k, float* y, int m
     const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;     // upfirdn2d_kernel.cu:167-168
     const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
     if (out_h <= 0 || out_w <= 0 || major <= 0 || minor <= 0) return 0;
+    if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && minor % 4 == 0 && minor >= 8 && minor <= 1024 && kh * kw <= 64 &&
+        major <= 65535) {
+        const int ppb = 256 / (minor / 4);
+        hipLaunchKernelGGL(fir_nhwc_kernel, dim3((unsigned)((out_w + ppb - 1) / ppb), (unsigned)((out_h + 3) / 4), (unsigned)major),
+                           dim3(256), 0, as_stream(stream), x, k, y, in_h, in_w, minor, kh, kw, pad_x0, pad_y0, out_h, out_w);
+        E4S_CHECK_LAUNCH();
+        return 0;
+    }
     const int tin_h = ((TOH - 1) * down_y + kh - 1) / up_y + 2;
     const int tin_w = ((TOW - 1) * down_x + kw - 1) / up_x + 2;
     const int tiles_x = (out_w + TOW - 1) / TOW, tiles_y = (out_h + TOH - 1) / TOH;

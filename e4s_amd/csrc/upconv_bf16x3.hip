@@ -22,6 +22,7 @@
 //     in registers across the epilogue.
 // Weights arrive pre-packed and pre-split by e4s_subpixel_weights_f32: [Cin/32][Cout/32][9 blocks][32 co][32 hi | 32 lo bf16].
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -66,7 +67,9 @@ struct TileId { int tb, ty, tx, nt; };
 // XF: 0 none, 1 v * in_scale[b][c] while the halo is staged (one style per sample: unmasked StyledConv, model.py:655-657)
 template <int XF>
 __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_params p, const float* __restrict__ k4, const int ntn,
-                                                            const int tx_n, const int per_img, const int ntiles) {
+                                                            const int tx_n, const int per_img, const int ntiles, const int abl) {
+    // abl (profiling builds only, -DE4S_ABLATIONS + env E4S_UPCONV3_ABL; results WRONG): 1 no MFMA stages, 2 no FIR / output
+    // stores, 3 no epilogue at all, 4 no global loads, 5 no LDS staging of the prefetched operands
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                          // [2][HALO][ROWB]
     unsigned char* sB = smem + 2 * A_BYTES;            // [2][9][32][ROWB]
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
         for (int j = 0; j < AJ; ++j) {
             const int item = tid + NTHR * j;
             const size_t off = item_src(id, item, R.ok[j]);
-            R.a[j] = load8(xb + off);
+            if (abl != 4) R.a[j] = load8(xb + off);
             if (XF) R.x[j] = load8(p.in_scale + (real ? (size_t)id.tb * p.Cin + chunk * KC : 0) + (item & 3) * 8);
         }
     };
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int i = tid + NTHR * j;
-            R[j] = *reinterpret_cast<const f32x4*>(wbytes + b_src(i < BPIECES ? i : 0, real ? chunk : 0, real ? id.nt : 0));
+            if (abl != 4) R[j] = *reinterpret_cast<const f32x4*>(wbytes + b_src(i < BPIECES ? i : 0, real ? chunk : 0, real ? id.nt : 0));
         }
     };
     auto store_a = [&](const AReg& R, int buf) {
@@ -249,19 +252,32 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
             // ---- even stage: chunk c0 in buffers 0 ----
             fetch_a(RE, nid, ce, nreal);                     // halo of the next even stage (two stages ahead)
             fetch_b(RB, cur, c0 + 1, true);                  // weights of the odd stage
-            contract(0);
-            store_a(RO, 1);                                  // halo of the odd stage, fetched during the previous odd stage
-            store_b(RB, 1);
+            if (abl != 1) contract(0);
+            if (abl != 5) {
+                store_a(RO, 1);                              // halo of the odd stage, fetched during the previous odd stage
+                store_b(RB, 1);
+            }
             __syncthreads();
             // ---- odd stage: chunk c0 + 1 in buffers 1 ----
             fetch_a(RO, nid, co, nreal);
             fetch_b(RB, nid, ce, nreal);                     // weights of the next even stage
-            contract(1);
-            store_a(RE, 0);
+            if (abl != 1) contract(1);
+            if (abl != 5) store_a(RE, 0);
             // after the tile's last stage the I tile is about to overwrite both weight buffers: the next tile's weights wait
             // in registers until the epilogue is through
-            if (!last_pair) store_b(RB, 0);
+            if (!last_pair && abl != 5) store_b(RB, 0);
             __syncthreads();
+        }
+        if (abl == 3) {
+            asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][7]));
+            if (!has_next) break;
+            store_b(RB, 0);
+            __syncthreads();
+            cur = nxt;
+            t_next += G;
+            has_next = t_next < ntiles;
+            if (has_next) nxt = decode(t_next);
+            continue;
         }
 
         // ---- epilogue (a): accumulators -> I tile; anchor (ay, ax), class (dy, dx) -> I[2 ay + dy][2 ax + dx][co] ----
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
         __syncthreads();
         // ---- epilogue (b): FIR + demodulation + noise + bias + activation.  Output (oyl, oxl) of the tile reads I rows
         // oyl + 1 .. oyl + 4, columns oxl + 1 .. oxl + 4 (tile origin of I = 2 * (first anchor) = output origin - 2) ----
-        if (e_act) {
+        if (e_act && abl != 2) {
             // flipped blur taps (upfirdn2d is a true convolution, upfirdn2d_kernel.cu:77): kf[ay*4+ax] = k4[3-ay][3-ax]; re-read per
             // tile (one scalar load) rather than held in 16 SGPRs across the main loop
             float kf[16];
@@ -402,7 +418,11 @@ extern "C" int e4s_upconv_bf16x3_f32(const e4s_conv_params* pp, const float* k4,
     const int64_t ntiles = (int64_t)p.B * per_img * ntn;
     if (ntiles >= (1ll << 31)) return (int)hipErrorInvalidValue;
     const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHR), SMEM, st, p, k4, ntn, tx_n, per_img, (int)ntiles);
+    int abl = 0;
+#ifdef E4S_ABLATIONS
+    if (const char* e = getenv("E4S_UPCONV3_ABL")) abl = atoi(e);
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHR), SMEM, st, p, k4, ntn, tx_n, per_img, (int)ntiles, abl);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -95,6 +95,22 @@ def test_upfirdn2d_large_matches_oracle():
     assert maxabs(upfirdn2d(x.to(DEV), k.to(DEV), up=2, pad=(2, 1)), orc.upfirdn2d(x, k, up=2, pad=(2, 1))) < 1e-5
 
 
+@pytest.mark.parametrize("b,c,h,w,pad,asym", [(2, 32, 40, 56, (2, 2), False), (1, 64, 33, 17, (2, 1), False), (3, 8, 16, 16, (1, 1), False),
+                                               (1, 544, 8, 8, (1, 2), True), (2, 128, 64, 64, (-1, 0), True)])
+def test_fir_on_channels_last_activations_vs_oracle(b, c, h, w, pad, asym):
+    """The Blur of the ConvLayers (model.py:683-689: up = down = 1) on NHWC activations: e4s_upfirdn2d_f32's coalesced
+    channels-last path (4 channels per lane) == the reference's fallback upfirdn2d on the NCHW tensor; the 4x4 blur and an
+    ASYMMETRIC kernel (flip convention, KAT4), negative pads (crop), the 544-channel padded map, odd sizes."""
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(b, c, h, w, generator=g)
+    k = torch.randn(4, 4, generator=g) if asym else orc.make_blur_kernel()
+    want = orc.upfirdn2d(x, k, pad=pad)
+    got = K.nhwc_to_nchw(K.upfirdn2d_nhwc(K.nchw_to_nhwc(x.to(DEV)), k.to(DEV), pad=pad))
+    assert got.shape == want.shape
+    assert maxabs(got, want) < 1e-5 * max(1.0, float(want.abs().max()))
+
+
 # ---------------------------------------------------------------------------------------------
 # the MFMA conv kernel against plain fp32 convolution
 # ---------------------------------------------------------------------------------------------
