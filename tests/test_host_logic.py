@@ -345,3 +345,21 @@ def test_stitch_host_side_restatements():
     assert u.shape == (12, 10, 3) and bool((u == 77).all())
     one = orc.laplacian_blend_u8(c, c, np.random.RandomState(1).rand(12, 10, 3).astype(np.float32), num_levels=2)
     assert bool((one == 77).all())
+
+
+def test_rowdot_job_record_matches_the_header(tmp_path):
+    """kernels.rowdot_jobs packs e4s_rowdot_job records with struct format "qqqQQiiif": size and field offsets must be what a C
+    compiler gives the struct declared in include/e4s_hip.h."""
+    import struct
+    import subprocess
+    from e4s_amd import kernels as K
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "e4s_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(e4s_rowdot_job),offsetof(e4s_rowdot_job,in_off),offsetof(e4s_rowdot_job,in_stride),'
+                   'offsetof(e4s_rowdot_job,out_off),offsetof(e4s_rowdot_job,M),offsetof(e4s_rowdot_job,bias),'
+                   'offsetof(e4s_rowdot_job,G),offsetof(e4s_rowdot_job,O),offsetof(e4s_rowdot_job,K),'
+                   'offsetof(e4s_rowdot_job,scale));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [struct.calcsize(K._JOB_FMT), 0, 8, 16, 24, 32, 40, 44, 48, 52] and got[0] == 56
