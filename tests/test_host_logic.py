@@ -363,3 +363,55 @@ def test_rowdot_job_record_matches_the_header(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert got == [struct.calcsize(K._JOB_FMT), 0, 8, 16, 24, 32, 40, 44, 48, 52] and got[0] == 56
+
+
+def test_train_iteration_cadence_follows_the_coach_loop():
+    """e4s_amd.train.TrainIteration.iteration = the body of Coach.train() (coach.py:281-398): D step when global_step % d_every ==
+    0, R1 only inside a D step and only when d_reg_every != -1 and batch_idx % d_reg_every == 0, one G step every iteration; D is
+    frozen during the G step and trainable during its own.  CPU stand-ins for the networks (the cadence is host logic)."""
+    from e4s_amd.train import LossOpts, TrainIteration, adv_d_loss, adv_g_loss, d_r1_loss
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(1))
+
+        def forward(self, img, onehot, **kw):
+            return img * self.w, None
+
+    class Disc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(3 * 4 * 4, 1)
+
+        def forward(self, x):
+            return self.lin(x.flatten(1) ** 2)
+    net, disc = Net(), Disc()
+    log = []
+    it = TrainIteration(net, disc, {}, torch.optim.SGD(net.parameters(), lr=1e-3), torch.optim.SGD(disc.parameters(), lr=1e-3),
+                        lo=LossOpts(d_every=3, d_reg_every=2))
+    for name in ("d_step", "r1_step", "g_step"):
+        real = getattr(it, name)
+
+        def wrap(*a, _n=name, _f=real, **k):
+            log.append((_n, it.global_step, all(p.requires_grad for p in disc.parameters())))
+            return _f(*a, **k)
+        setattr(it, name, wrap)
+    img = torch.rand(2, 3, 4, 4)
+    for step in range(7):
+        out = it.iteration(img, None, batch_idx=step)
+        assert "loss" in out and ("d_loss" in out) == (step % 3 == 0) and ("r1_loss" in out) == (step % 3 == 0 and step % 2 == 0)
+    assert [n for n, _, _ in log] == ["d_step", "r1_step", "g_step", "g_step", "g_step", "d_step", "g_step", "g_step", "g_step",
+                                      "d_step", "r1_step", "g_step"]
+    assert it.global_step == 7
+    assert not any(p.requires_grad for p in disc.parameters())            # the last thing that ran was a G step: D frozen
+    it2 = TrainIteration(net, disc, {}, None, None, lo=LossOpts(d_reg_every=-1))
+    assert it2.lo.d_every == 15 and it2.lo.g_adv_lambda == 0.01 and it2.lo.r1_lambda == 10.0     # train_options.py:37-38,53-54
+    # the loss helpers are the reference's formulas (adv_loss.py:8-45)
+    rp, fp = torch.tensor([[0.3], [-1.2]]), torch.tensor([[0.7], [0.1]])
+    assert torch.allclose(adv_g_loss(fp), torch.nn.functional.softplus(-fp).mean())
+    assert torch.allclose(adv_d_loss(rp, fp), torch.nn.functional.softplus(-rp).mean() + torch.nn.functional.softplus(fp).mean())
+    x = torch.rand(2, 3, 4, 4, requires_grad=True)
+    pen = d_r1_loss(disc(x), x)
+    g, = torch.autograd.grad(disc(x).sum(), x, create_graph=True)
+    assert torch.allclose(pen, g.pow(2).reshape(2, -1).sum(1).mean())

@@ -316,3 +316,77 @@ def test_gloo_world2_overlapped_bucket_allreduce_equals_post_hoc():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in res), res
+
+
+def _worker_train_iteration(rank, world, port, q):
+    """TrainIteration.g_step / d_step with GradAverager armed (bucket all-reduces fired from hooks during backward) on two
+    gloo ranks with different shards == the single-process step on the whole batch (mean of shard losses), CPU stand-in nets."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from e4s_amd.ddp import GradAverager
+    from e4s_amd.train import LossOpts, TrainIteration
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 3, 3, padding=1))
+
+        def forward(self, img, onehot, **kw):
+            return self.body(img), None
+
+    class Disc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, stride=2), torch.nn.LeakyReLU(0.2), torch.nn.Flatten(),
+                                            torch.nn.Linear(4 * 3 * 3, 1))
+
+        def forward(self, x):
+            return self.body(x)
+
+    def make():
+        torch.manual_seed(0)
+        return Net(), Disc()
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(4, 3, 8, 8, generator=g)
+    lo_, hi_ = shard.shard_range(4, world, rank)
+    lo = LossOpts(face_parsing_lambda=0, id_lambda=0, lpips_lambda=0, d_every=1)
+
+    def run(distributed):
+        net, disc = make()
+        opt, opt_d = torch.optim.SGD(net.parameters(), lr=0.1), torch.optim.SGD(disc.parameters(), lr=0.1)
+        if distributed:
+            it = TrainIteration(net, disc, {}, opt, opt_d, lo=lo, averager=GradAverager(net.parameters(), bucket_mb=1e-4),
+                                averager_d=GradAverager(disc.parameters(), bucket_mb=1e-4))
+            x = img[lo_:hi_]
+        else:
+            it = TrainIteration(net, disc, {}, opt, opt_d, lo=lo)
+            x = img
+        for step in range(2):
+            it.iteration(x, None, batch_idx=1)
+        fired = it.averager.fired_during_backward if distributed else None
+        return [p.detach().clone() for p in list(net.parameters()) + list(disc.parameters())], fired
+    dist_params, fired = run(True)
+    ref_params, _ = run(False)
+    ok = all(torch.allclose(a, b, atol=1e-6, rtol=1e-5) for a, b in zip(dist_params, ref_params))
+    q.put((rank, ok, fired))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_train_iteration_equals_single_process():
+    """config 5 under data parallelism: two ranks, each on its shard of the batch, overlapped bucket all-reduces inside
+    TrainIteration's G and D steps -> the same parameters after two iterations as one process on the whole batch (equal shard
+    sizes: the mean of shard-mean losses is the batch-mean loss)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_train_iteration, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert all(r[2] is not None and r[2] >= 1 for r in res), res
