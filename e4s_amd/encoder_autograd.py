@@ -39,6 +39,25 @@ def _wt(conv):
     return conv._e4s_wt[1]
 
 
+def _dgrad3x3(gz, conv, x):
+    """dx of y = conv3x3(x, W, stride 1, padding 1): the 'same' 3x3 convolution of gz with the flipped, transposed taps.  Under
+    E4S_PRECISION=auto/bf16x3 this is the FORWARD split-bf16 halo kernel on re-packed weights (364 TFLOP/s algorithmic on the
+    512-channel layers) -- e4s_conv_bwd_mfma_f32, the exact-fp32 dx + ds kernel the generator needs for its per-region styles,
+    ran these plain dgrads at ~66 TFLOP/s: 41 launches x ~190 us = 7.9 ms of a 72 ms G step (profiles/r03_train_kernel_stats.csv).
+    f32: that kernel, as before."""
+    b, h, w, cy = gz.shape
+    cx = conv.weight.shape[1]
+    if K.want_bf16x3(b, h, w, cy, cx):
+        key = _pack3x3(conv) is not None and conv._e4s_pack[0]
+        cached = getattr(conv, "_e4s_wt_fwd", None)
+        if cached is None or cached[0] != key:
+            wp = K.pack_taps(conv.weight.detach().float().flip(2, 3).transpose(0, 1).contiguous())      # [1,9,Cin,Cout]
+            conv._e4s_wt_fwd = cached = (key, wp, K.split_bf16x2(wp))
+        return K.conv_mfma(gz.contiguous(), cached[1], cx, w_split=cached[2])
+    dx, _ = K.conv_bwd(gz, _wt(conv), x, None, None, None, 1, 1, want_ds=False)       # x: shape only (no ds asked for)
+    return dx
+
+
 def unit_forward(unit, x, tape):
     """bottleneck_IR_SE_Ours.run_nhwc with a tape (the PReLU runs as its own pass so that its input is saved)."""
     conv1, prelu, conv2, se = unit.res_layer[1], unit.res_layer[2], unit.res_layer[3], unit.res_layer[5]
@@ -78,7 +97,7 @@ def unit_backward(rec, dout, give):
     # ---- conv2 (3x3, stride s) ----
     give(conv2.weight, _wgrad(dr2, r1, s, 9))
     gz2 = dr2 if s == 1 else K.strided_scatter(dr2, s)
-    dr1, _ = K.conv_bwd(gz2, _wt(conv2), r1, None, None, None, 1, 1, want_ds=False)
+    dr1 = _dgrad3x3(gz2, conv2, r1)
     # ---- PReLU ----
     du1, dslope = K.prelu_bwd(dr1, rec["u1"], prelu.weight)
     give(prelu.weight, dslope)
@@ -86,7 +105,7 @@ def unit_backward(rec, dout, give):
     xn = K.instnorm_apply(x, rec["st_x"])
     give(conv1.weight, _wgrad(du1, xn, 1, 9))
     del xn
-    dxn, _ = K.conv_bwd(du1, _wt(conv1), x, None, None, None, 1, 1, want_ds=False)
+    dxn = _dgrad3x3(du1, conv1, x)
     dx, _ = K.instnorm_bwd(dxn, x, rec["st_x"])
     # ---- shortcut ----
     if unit.in_channel == unit.depth:

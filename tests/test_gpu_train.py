@@ -20,10 +20,13 @@ def _f32(monkeypatch):
     monkeypatch.setattr(K, "PRECISION", "f32")
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 @pytest.mark.parametrize("cin,depth,stride,res", [(64, 128, 2, 32), (128, 128, 1, 16), (512, 512, 2, 16), (128, 256, 2, 32), (512, 512, 1, 8)])
-def test_encoder_unit_backward_vs_oracle_f64(cin, depth, stride, res):
-    """One bottleneck_IR_SE_Ours unit: dx and every parameter gradient vs fp64 autograd of the oracle."""
+def test_encoder_unit_backward_vs_oracle_f64(cin, depth, stride, res, prec, monkeypatch):
+    """One bottleneck_IR_SE_Ours unit: dx and every parameter gradient vs fp64 autograd of the oracle.  bf16x3: the forward convs
+    AND the two plain dgrads run on the split-bf16 halo kernel (encoder_autograd._dgrad3x3); same bounds."""
     from e4s_amd import kernels as K
+    monkeypatch.setattr(K, "PRECISION", prec)
     from e4s_amd.encoder_autograd import unit_backward, unit_forward
     from e4s_amd.encoders import bottleneck_IR_SE_Ours
     pfx = "encoder.body.0."
