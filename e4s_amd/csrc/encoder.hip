@@ -100,7 +100,7 @@ __global__ void instnorm_partial_kernel(const float* __restrict__ x, double* __r
     }
 }
 
-// Small maps (HW <= 4096: the 64^2 .. 16^2 levels, where a split-K conv cannot emit the statistics itself): ONE launch, block =
+// Small maps (HW <= 1024: the 32^2 and 16^2 levels, where a split-K conv cannot emit the statistics itself): ONE launch, block =
 // (sample, 64-channel slab), 16 pixel groups x 64 channels; fp64 partial sums added in a fixed order, mean / rstd / pooled
 // written directly (the same formulas as instnorm_finalize_kernel).  Batch-1 latency runs paid two launches per statistic.
 __global__ __launch_bounds__(1024) void instnorm_small_kernel(const float* __restrict__ x, float* __restrict__ stats,
@@ -448,7 +448,9 @@ extern "C" int e4s_instnorm_stats_f32(const float* x, float* stats, float* poole
                                       float eps, void* stream) {
     if (C % 64) return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
-    if (HW <= 4096 && HW >= 16) {                       // policy independent of the batch: a sample's statistics never depend on it
+    // <= 32x32 maps only: one block per (sample, 64 channels) walks HW / 16 pixels serially -- at 64x64 (256 iterations, 2-16 blocks
+    // on the chip at batch 1) that measured 32 us against ~17 us for the split two-launch form (profiles/r03_b1_steps_kernel_stats.csv)
+    if (HW <= 1024 && HW >= 16) {                       // policy independent of the batch: a sample's statistics never depend on it
         hipLaunchKernelGGL(instnorm_small_kernel, dim3(B * (C / 64)), dim3(1024), 0, st, x, stats, pooled, HW, C, eps);
         E4S_CHECK_LAUNCH();
         return 0;
