@@ -534,6 +534,31 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
 // registers for the 9 taps of a chunk) and splits the product into hi/lo bf16 on its way into the MFMAs: 32 VALU per
 // 6 MFMAs, which the second wave of the SIMD overlaps.  Weights arrive pre-split as in the kernel above; the
 // demodulation table d[region][co] is applied in the epilogue.
+// a = x * s split into hi + lo bf16 (8 products): hi = rne(x s) with the packed convert, re-expanded with one shift / one mask per
+// element, lo = rne(fma(x, s, -hi)) -- the residual of the EXACT product, so the pair is at least as close to x s as the split of
+// the rounded product
+__device__ __forceinline__ void scale_split(const f32x8 x, const f32x8 s, bf16x8& hi, bf16x8& lo) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hp;
+    f32x8 res;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 xs = f32x2{x[2 * j], x[2 * j + 1]}, ss = f32x2{s[2 * j], s[2 * j + 1]};
+        const f32x2 v = xs * ss;
+        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        hp[j] = h2;
+        const f32x2 hf = f32x2{__builtin_bit_cast(float, h2 << 16), __builtin_bit_cast(float, h2 & 0xffff0000u)};
+        f32x2 r;                                     // x s - hi; written out because the compiler turns -hi into 2 integer XORs
+        asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(xs), "v"(ss), "v"(hf));
+        res[2 * j] = r[0];
+        res[2 * j + 1] = r[1];
+    }
+    hi = __builtin_bit_cast(bf16x8, hp);
+    lo = __builtin_convertvector(res, bf16x8);
+}
+
 constexpr int NTHR = 512;
 constexpr int BM = 256, BN = 128;
 constexpr int TH = 16, HALO = (TH + 2) * HALO_W;                               // 324 halo pixels
@@ -549,10 +574,17 @@ constexpr int S_OFF = 2 * A_BYTES + 2 * B_BYTES;
 constexpr int SMEM_REGION = S_OFF + 2 * S_BYTES + BM * 12;
 static_assert(XPIECE * 9 >= XITEMS && XPIECE <= NTHR, "extended halo split");
 
+// Wave layout WN_ (column waves): 1 = 8 x 1 waves of 32 rows x 128 columns (TM 1, TN 4: a scaled-and-split A fragment feeds 12
+// MFMAs, 48 VALU of scale/split per stage and wave), 2 = 4 x 2 waves of 64 x 64 (TM 2, TN 2: 6 MFMAs per fragment, the same rows
+// scaled by both column waves).  SPL: 1 = hand-written split (packed convert, shift/mask re-expansion: 24 VALU per 8 products),
+// 0 = __builtin_convertvector round trip (the compiler converts every element twice: 32 VALU).
+template <int WN_, int SPL>
 __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv_params p, const int ntn,
                                                                   const int tx_n, const int per_img,
                                                                   const int tiles_per_cls, const int ksplit,
-                                                                  const int cper) {
+                                                                  const int cper, const int* __restrict__ only_flagged) {
+    constexpr int WN = WN_, WM = NTHR / 64 / WN, TM = BM / (WM * 32), TN = BN / (WN * 32), NG = 2 * TM;
+    static_assert(TM * TN == 4 && (NG == 2 || NG == 4), "wave layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                          // [2][HALO][ROWB]  fp32 x, 32 channels per row
     unsigned char* sB = smem + 2 * A_BYTES;            // [2][BN][ROWB]    split weights
@@ -571,6 +603,8 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
     const int ks = logical0 % ksplit;
     const int logical = logical0 / ksplit;
     const int mt = logical / ntn, nt = logical - mt * ntn;
+    // second launch behind conv_region_rows_kernel (conv_region.hip): only the pixel tiles that kernel flagged (too many variant rows)
+    if (only_flagged && !only_flagged[mt]) return;
     const int n0 = nt * BN;
     const int cls = mt / tiles_per_cls;
     const int tt = mt - cls * tiles_per_cls;
@@ -727,14 +761,20 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
             pa = load8(it.src + (have_next ? (c_lo + chunk + 1) * KC : 0));
         };
 
-        // -- 4 groups of 6 MFMAs; the next group's fp32 fragment is requested before the current one is converted --
+        // -- NG groups of 3 TN MFMAs; the next group's fp32 fragment is requested before the current one is converted --
         auto mfma_group = [&](int g) {
             const int kk = g / TM, tm = g % TM;
-            const f32x8 v = raw * sv[tm][kk];
-            if (g + 1 < 2 * TM) raw = ldraw(g + 1);
-            const bf16x8 ah = __builtin_convertvector(v, bf16x8);
-            const f32x8 res = v - __builtin_convertvector(ah, f32x8);
-            const bf16x8 al = __builtin_convertvector(res, bf16x8);
+            bf16x8 ah, al;
+            if (SPL) {
+                scale_split(raw, sv[tm][kk], ah, al);
+                if (g + 1 < NG) raw = ldraw(g + 1);
+            } else {
+                const f32x8 v = raw * sv[tm][kk];
+                if (g + 1 < NG) raw = ldraw(g + 1);
+                ah = __builtin_convertvector(v, bf16x8);
+                const f32x8 res = v - __builtin_convertvector(ah, f32x8);
+                al = __builtin_convertvector(res, bf16x8);
+            }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kk][tn], acc[tm][tn], 0, 0, 0);
@@ -747,15 +787,15 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
         };
         mfma_group(0);
         issue_loads();
-        mfma_group(1);
+        if (NG == 4) mfma_group(1);
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x126, 8, 0);      // then up to 8 VALU / SALU / VMEM-read / DS-read
         }
         __builtin_amdgcn_sched_barrier(0);
-        mfma_group(2);
-        mfma_group(3);
+        mfma_group(NG / 2);
+        if (NG == 4) mfma_group(3);
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
@@ -829,8 +869,9 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
     }
 }
 
-int launch_region(const e4s_conv_params& p, hipStream_t st) {
-    auto kern = conv_bf16x3_region_kernel;
+template <int WN_, int SPL>
+int launch_region_v(const e4s_conv_params& p, const int* only_flagged, hipStream_t st) {
+    auto kern = conv_bf16x3_region_kernel<WN_, SPL>;
     static std::atomic<uint64_t> smem_set{0};
     if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), SMEM_REGION, smem_set)) return e;
     const int ntn = p.Cout / BN;
@@ -842,7 +883,7 @@ int launch_region(const e4s_conv_params& p, hipStream_t st) {
     const int64_t blocks = (int64_t)tiles_per_cls * p.ncls * ntn * ksplit;
     if (blocks <= 0) return 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM_REGION, st, p, ntn, tx_n, per_img, tiles_per_cls,
-                       ksplit, cper);
+                       ksplit, cper, only_flagged);
     E4S_CHECK_LAUNCH();
     if (ksplit > 1) {           // slabs already carry d[region]: the second stage adds them and applies noise / bias / act
         e4s_conv_params q = p;
@@ -853,6 +894,19 @@ int launch_region(const e4s_conv_params& p, hipStream_t st) {
         E4S_CHECK_LAUNCH();
     }
     return 0;
+}
+
+int launch_region(const e4s_conv_params& p, const int* only_flagged, hipStream_t st) {
+#ifdef E4S_ABLATIONS
+    static const int v = [] { const char* e = getenv("E4S_REGION_VAR"); return e ? atoi(e) : -1; }();
+    switch (v) {
+        case 0: return launch_region_v<2, 0>(p, only_flagged, st);       // round-2 kernel
+        case 1: return launch_region_v<2, 1>(p, only_flagged, st);
+        case 2: return launch_region_v<1, 0>(p, only_flagged, st);
+        default: break;
+    }
+#endif
+    return launch_region_v<1, 1>(p, only_flagged, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1198,6 +1252,12 @@ int launch_xf(const e4s_conv_params& p, hipStream_t st) {
 
 }  // namespace
 
+// conv_region.hip: the region-select kernel as the fallback / split-K path of e4s_conv_region_bf16x3_f32
+int e4s_launch_region_select(const e4s_conv_params& p, const int* only_flagged, hipStream_t st) {
+    return launch_region(p, only_flagged, st);
+}
+void e4s_region_split_policy(const e4s_conv_params& p, int& ksplit, int& cper) { region_split(p, ksplit, cper); }
+
 extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     const e4s_conv_params& p = *pp;
     const bool up = (p.ncls == 4);
@@ -1221,7 +1281,7 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     if (p.labels) {                       // per-pixel regions: the region-select kernel (128-wide column tiles only)
         if (p.y_cstride || !p.in_scale || p.in_stats || p.act == 2 || p.Cout % BN || p.groups_per_batch < 1 || p.groups_per_batch > MAXR)
             return (int)hipErrorInvalidValue;
-        return launch_region(p, st);
+        return launch_region(p, nullptr, st);
     }
 #ifdef E4S_ABLATIONS      // profiling builds only (E4S_BUILD_ABLATIONS=1 python -m e4s_amd.build): tools/bench_abl.py
     static const int abl = [] { const char* e = getenv("E4S_BF16X3_ABL"); return e ? atoi(e) : 0; }();

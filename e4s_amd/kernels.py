@@ -251,12 +251,14 @@ def region_plan(labels, num_regions, ha, wa, nphase):
 def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, in_scale=None, out_scale=None,
               noise=None, noise_w=None, noise_per_channel=False, bias=None, slope=None, act=0, alpha=0.2,
               gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1, w_split=None, in_stats=None,
-              out=None, tap_shift=0, want_stats=False):
+              out=None, tap_shift=0, want_stats=False, w_split16=None):
     """x NHWC [B,Hi,Wi,Cin]; w [ncls, ntaps, Cout, Cin] -> y NHWC [B,Ho,Wo,Cout].
     anchors = (Ha, Wa); defaults: up-conv (ncls=4) anchors = input grid, output 2x;
     strided conv anchors = output grid.
     w_split: the split-bf16 image of w (split_bf16x2); when given the contraction runs on e4s_conv_bf16x3_f32
     (callers check bf16x3_eligible first -- an ineligible shape is an error, not a silent fp32 run).
+    w_split16: (masked layers, with w_split) the 16-channel-chunk split image (split16_bf16x2): the contraction runs on
+    e4s_conv_region_bf16x3_f32 (variant-rows kernel; the region-select kernel for tiles / launches it does not take).
     in_stats: [B,Cin,2] InstanceNorm statistics of x; the normalisation is applied while the input is staged (split-bf16
     kernel only).
     out: write the Cout channels into the FIRST channels of this wider NHWC tensor [B,Ho,Wo,Cy >= Cout] (returned).
@@ -322,6 +324,16 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
                 or (in_stats is not None and (in_scale is not None or labels is not None))):
             raise RuntimeError("e4s_conv_bf16x3_f32 does not cover this contraction")
         p.w = fptr(w_split)
+        if w_split16 is not None:
+            if labels is None or out is not None:
+                raise RuntimeError("e4s_conv_region_bf16x3_f32 is the masked-layer kernel")
+            nws = lib.load().e4s_conv_region_ws_floats(ctypes.byref(p))    # tile flags, or split-K slabs
+            if nws <= 0:
+                raise RuntimeError("e4s_conv_region_bf16x3_f32 does not cover this contraction")
+            skws = torch.empty(nws, device=x.device, dtype=torch.float32)
+            p.splitk_ws = fptr(skws)
+            call("e4s_conv_region_bf16x3_f32", ctypes.byref(p), ptr(w_split16), stream())
+            return y
         nws = lib.load().e4s_conv_bf16x3_ws_floats(ctypes.byref(p))        # split-K partial sums (few-tile launches)
         skws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
         p.splitk_ws = fptr(skws)
@@ -386,6 +398,16 @@ def split_bf16x2(w):
     out = torch.empty_like(w)
     cin = w.shape[-1]
     call("e4s_split_bf16x2_f32", fptr(w), ptr(out), w.numel() // cin, cin, stream())
+    return out
+
+
+def split16_bf16x2(w):
+    """fp32 tap-packed weights [ncls, 9, Cout, Cin] -> the [ncls*9][Cin/16][Cout][16 hi | 16 lo] split image
+    e4s_conv_region_bf16x3_f32 reads (opaque, same byte size)."""
+    w = _f32(w)
+    out = torch.empty_like(w)
+    cout, cin = w.shape[-2], w.shape[-1]
+    call("e4s_split16_bf16x2_f32", fptr(w), ptr(out), w.numel() // (cout * cin), cout, cin, stream())
     return out
 
 

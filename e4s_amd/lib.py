@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe4s_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -75,6 +75,9 @@ SIGNATURES = {
     "e4s_conv_bf16x3_ws_floats": [ctypes.POINTER(ConvParams)],
     "e4s_conv_mfma_ws_floats": [ctypes.POINTER(ConvParams), c_i],
     "e4s_split_bf16x2_f32": [c_p, c_p, c_l, c_i, c_p],
+    "e4s_conv_region_bf16x3_f32": [ctypes.POINTER(ConvParams), c_p, c_p],
+    "e4s_conv_region_ws_floats": [ctypes.POINTER(ConvParams)],
+    "e4s_split16_bf16x2_f32": [c_p, c_p, c_l, c_i, c_i, c_p],
     "e4s_upconv_blocks_per_cu": [],
     "e4s_instnorm_ws_doubles": [c_i, c_i, c_i],
     "e4s_conv_bwd_mfma_f32": [ctypes.POINTER(ConvBwdParams), c_p],
@@ -167,7 +170,7 @@ SIGNATURES = {
     "e4s_cosine_bwd_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_l, c_i, c_p],
 }
 
-INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats", "e4s_lpips_layer_ws_doubles", "e4s_conv_mfma_ws_floats",
+INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats", "e4s_conv_region_ws_floats", "e4s_lpips_layer_ws_doubles", "e4s_conv_mfma_ws_floats",
                 "e4s_cosine_ws_doubles", "e4s_colsum_ws_floats"}       # size queries: return a count, not an error code
 
 _lib = None

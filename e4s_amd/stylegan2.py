@@ -41,6 +41,8 @@ UPCONV_EXACT_MIN_RES = int(os.environ.get("E4S_UPCONV_MIN_RES", "256"))     # ma
 UPCONV_BF16X3_EXACT = os.environ.get("E4S_UPCONV_BF16X3", "exact") != "polyphase"
 # the Cin == 32 StyledConv (32 -> 32 at 1024^2) on the resident-weights kernel with the ToRGB contraction in its epilogue
 CONV_C32 = os.environ.get("E4S_CONV_C32", "1") != "0"
+# masked layers on the variant-rows kernel (csrc/conv_region.hip); "0": the region-select kernel of conv_bf16x3.hip everywhere
+REGION_ROWS = os.environ.get("E4S_REGION_ROWS", "1") != "0"
 
 
 def make_kernel(k):
@@ -227,6 +229,14 @@ class ModulatedConv2d(nn.Module):
                 pk["w_split"] = K.split_bf16x2(pk["w"])
         return pk["w_split"]
 
+    def split_weights16(self):
+        """16-channel-chunk split image of packed()["w"] for e4s_conv_region_bf16x3_f32 (masked layers; cached with the pack)."""
+        pk = self.packed()
+        if "w_split16" not in pk:
+            with torch.no_grad():
+                pk["w_split16"] = K.split16_bf16x2(pk["w"])
+        return pk["w_split16"]
+
     def forward(self, input, style):
         """Drop-in single-style forward (NCHW in/out), model.py:242-320."""
         b = input.shape[0]
@@ -338,7 +348,8 @@ class StyledConv(nn.Module):
                                ostride=2 if conv.upsample else 1, in_scale=s, out_scale=d, noise=nz,
                                noise_w=self.noise.weight, bias=self.activate.bias, act=1,
                                alpha=self.activate.negative_slope, gain=self.activate.scale,
-                               w_split=conv.split_weights())
+                               w_split=conv.split_weights(),
+                               w_split16=conv.split_weights16() if (labels is not None and REGION_ROWS) else None)
         # a masked tile runs one pass per region present: exact only where 12x28 output tiles are mostly uniform
         if conv.upsample and plan is None and UPCONV_EXACT and (labels is None or ho >= UPCONV_EXACT_MIN_RES):
             return K.upconv_mfma(x, pk["w3"], conv.out_channel, conv.blur.kernel, in_scale=s, out_scale=d,

@@ -193,6 +193,20 @@ int64_t e4s_conv_bf16x3_ws_floats(const e4s_conv_params* p);
 /* w fp32 [rows][cin] -> out [rows][cin/32][32 hi bf16 | 32 lo bf16] (same byte size), cin % 32 == 0 */
 int e4s_split_bf16x2_f32(const float* w, void* out, int64_t rows, int cin, void* stream);
 
+/* Masked StyledConv (model.py:386-400; plain or polyphase up-conv), "variant rows" kernel (csrc/conv_region.hip): the halo of a
+ * 16x16-pixel tile is staged once per 16 input channels, scaled with the style of each halo pixel's OWN region and split to hi|lo
+ * bf16; the (pixel, tap) pairs that cross a region boundary read extra LDS rows scaled with the reading pixel's style, so the
+ * matrix-core loop does no per-fragment arithmetic (e4s_conv_bf16x3_f32's region-select kernel scales and splits every A
+ * fragment).  Same results contract (split-bf16 products, fp32 accumulation, fixed summation order per output).
+ * p as e4s_conv_bf16x3_f32 with labels != NULL (p->w = the e4s_split_bf16x2_f32 image: tiles that need more than 256 variant
+ * rows, and launches of <= 128 tiles that split K, run on the region-select kernel); w16 = the e4s_split16_bf16x2_f32 image of
+ * the same tap-packed weights; p->splitk_ws = e4s_conv_region_ws_floats(p) floats of scratch (tile flags or split-K slabs).
+ * e4s_split16_bf16x2_f32: w fp32 [rows][Cout][Cin] (rows = ncls * 9) -> out [rows][Cin/16][Cout][16 hi bf16 | 16 lo bf16]
+ * (same byte size), Cin % 16 == 0. */
+int e4s_conv_region_bf16x3_f32(const e4s_conv_params* p, const void* w16, void* stream);
+int64_t e4s_conv_region_ws_floats(const e4s_conv_params* p);
+int e4s_split16_bf16x2_f32(const float* w, void* out, int64_t rows, int cout, int cin, void* stream);
+
 /* ---- backward of the fused generator (configs 3 and 5) -------------------- */
 typedef struct {
     const float* gz;         /* dL/d(out_pre), NHWC [B, Hy, Wy, Cy]  (Cy = forward Cout) */

@@ -282,6 +282,87 @@ def test_region_kernel_split_k_vs_fp32(res, cin, cout, up, monkeypatch):
     assert 0 < maxabs(y, ref) < 1e-4 * float(ref.abs().max())
 
 
+def _region_case(b, h, w, cin, cout, up, kind, R=12, seed=41):
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(seed)
+    ncls = 4 if up else 1
+    ho, wo = (2 * h, 2 * w) if up else (h, w)
+    x = torch.randn(b, h, w, cin, generator=g).to(DEV)
+    wt = torch.randn(ncls, 9, cout, cin, generator=g).to(DEV) / math.sqrt(cin * 9)
+    if kind == "face":                      # 512^2 face-like map, legacy-nearest lookup inside the kernel
+        lab = synth.synth_labels_face(b, 512, seed=seed).view(b, 512, 512)
+    elif kind == "blocks":                  # 8x8-pixel blocks at output resolution: boundaries inside every tile
+        lab = torch.randint(0, R, (b, (ho + 7) // 8, (wo + 7) // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :ho, :wo]
+    elif kind == "noise":                   # per-pixel random regions: every tile needs more variant rows than the kernel has
+        lab = torch.randint(0, R, (b, ho, wo), generator=g)
+    elif kind == "half-noise":              # left half noise (tiles overflow -> region-select kernel), right half two regions
+        lab = torch.randint(0, R, (b, ho, wo), generator=g)
+        lab[:, :, wo // 2:] = 3
+        lab[:, ho // 3:, wo // 2 + 5:] = R - 1
+    labels = lab.to(torch.uint8).contiguous().to(DEV)
+    kw = dict(labels=labels, num_regions=R, ncls=ncls, ostride=2 if up else 1,
+              in_scale=(torch.rand(b * R, cin, generator=g) + 0.5).to(DEV), out_scale=(torch.rand(b * R, cout, generator=g) + 0.5).to(DEV),
+              noise=torch.randn(b, 1, ho, wo, generator=g).to(DEV), noise_w=torch.tensor([0.2], device=DEV),
+              bias=(torch.randn(cout, generator=g) * 0.1).to(DEV), act=1)
+    return x, wt, kw
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,up,kind,R", [
+    (2, 48, 40, 64, 128, False, "face", 12), (2, 64, 64, 96, 256, False, "blocks", 12), (9, 64, 64, 512, 128, False, "face", 12),
+    (2, 32, 32, 64, 128, True, "face", 12), (2, 24, 40, 64, 256, True, "blocks", 12), (1, 33, 17, 64, 128, False, "face", 12),
+    (2, 64, 64, 64, 128, False, "noise", 12), (2, 64, 64, 64, 128, False, "half-noise", 12), (2, 32, 48, 64, 128, False, "blocks", 16),
+    (3, 128, 128, 128, 128, False, "face", 12)])
+def test_region_rows_kernel_vs_fp32_and_region_select(b, h, w, cin, cout, up, kind, R):
+    """e4s_conv_region_bf16x3_f32 (variant rows: the halo scaled with each pixel's own region's style once, boundary pairs read extra
+    rows) on masked StyledConv contractions, plain and polyphase, ragged maps, 16 regions: == the exact fp32 region kernel to 1e-4
+    of the output scale, == the region-select split-bf16 kernel to a few 1e-6 (same products, another summation order), bitwise
+    reproducible; per-pixel random regions (every tile overflows the variant rows) fall back to the region-select kernel bit for bit,
+    and a map that overflows only on one side mixes both kernels in one launch."""
+    from e4s_amd import kernels as K
+    x, wt, kw = _region_case(b, h, w, cin, cout, up, kind, R)
+    ws, ws16 = K.split_bf16x2(wt), K.split16_bf16x2(wt)
+    y = K.conv_mfma(x, wt, cout, w_split=ws, w_split16=ws16, **kw)
+    assert torch.equal(y, K.conv_mfma(x, wt, cout, w_split=ws, w_split16=ws16, **kw))
+    ref = K.conv_mfma(x, wt, cout, **kw)
+    sel = K.conv_mfma(x, wt, cout, w_split=ws, **kw)
+    scale = float(ref.abs().max())
+    assert 0 < maxabs(y, ref) < 1e-4 * scale
+    assert maxabs(y, sel) < 5e-6 * scale
+    if kind == "noise":
+        assert torch.equal(y, sel)
+    else:
+        assert maxabs(y, sel) > 0                                        # the variant-rows kernel really produced these tiles
+    if kind == "half-noise":                                             # left-most tiles: fallback (bit-equal); right-most: rows kernel
+        assert torch.equal(y[:, :, :16], sel[:, :, :16]) and not torch.equal(y[:, :, -16:], sel[:, :, -16:])
+
+
+def test_region_rows_kernel_replays_in_a_graph_with_another_mask():
+    """The tile analysis (variant rows, overflow flags) happens inside the launch from the label map it is handed: a captured launch
+    replayed after the labels changed == the eager launch on the new labels."""
+    from e4s_amd import kernels as K
+    x, wt, kw = _region_case(2, 64, 64, 64, 128, False, "face")
+    _, _, kw2 = _region_case(2, 64, 64, 64, 128, False, "half-noise", seed=43)
+    ws, ws16 = K.split_bf16x2(wt), K.split16_bf16x2(wt)
+    lab = kw["labels"][:, ::8, ::8].contiguous()                        # [2,64,64] static label buffer
+    kw["labels"] = lab
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        K.conv_mfma(x, wt, 128, w_split=ws, w_split16=ws16, **kw)
+    torch.cuda.current_stream().wait_stream(st)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        y = K.conv_mfma(x, wt, 128, w_split=ws, w_split16=ws16, **kw)
+    lab.copy_(kw2["labels"])
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, K.conv_mfma(x, wt, 128, w_split=ws, w_split16=ws16, **kw))
+    lab.copy_(torch.zeros_like(lab))
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, K.conv_mfma(x, wt, 128, w_split=ws, w_split16=ws16, **kw))
+
+
 def test_bf16x3_rejects_shapes_it_does_not_cover():
     from e4s_amd import kernels as K
     x = torch.zeros(1, 16, 16, 64, device=DEV)
