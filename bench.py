@@ -105,8 +105,14 @@ def headline_probe(net, batch, mask, reps):
         return exact
     # the kernel the timed step runs for this layer under E4S_PRECISION=auto/bf16x3.  `achieved` stays ALGORITHMIC
     # (one multiply-add per fp32 product); the kernel issues 3 bf16 MFMAs per product, so frac <= 1/3 by construction.
-    ms, ach = timed({"w_split": layer.conv.split_weights()})
-    return {"bound": "mfma", "kernel": "conv_bf16x3_region_kernel (3x v_mfma_f32_32x32x16_bf16 per product) " + what,
+    from e4s_amd import stylegan2 as sg2
+    extra = {"w_split": layer.conv.split_weights()}
+    name = "conv_bf16x3_region_kernel"
+    if sg2.REGION_ROWS:                   # what StyledConv.run_nhwc launches for this layer
+        extra["w_split16"] = layer.conv.split_weights16()
+        name = "conv_region_rows_kernel"
+    ms, ach = timed(extra)
+    return {"bound": "mfma", "kernel": name + " (3x v_mfma_f32_32x32x16_bf16 per product) " + what,
             "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "frac_ceiling": round(1.0 / 3.0, 4),
             "mfma_executed_tflops": round(3 * ach, 1), "traffic": traffic.get("hbm_bytes_per_launch_bf16x3"),

@@ -38,42 +38,52 @@ constexpr int LO = 64;                 // byte offset of the lo half inside a ro
 constexpr int TW = 16, HALO_W = TW + 2;
 constexpr int PBM = 256, PTH = 16, PHALO = (PTH + 2) * HALO_W;      // 16x16-pixel tiles, 324 halo pixels
 constexpr int PNTHR = 512;
-constexpr int PITEMS = PHALO * 4;      // (halo pixel, 8-channel group) work items of one chunk = 1296
-constexpr int PA_BYTES = PHALO * ROWB;
 
 // Column-tile configurations of the plain (one style per sample) kernel.  BN = GEMM columns per tile; TPS = taps per
 // pipeline stage (a stage = TPS taps x 32 input channels): the narrow tiles take three taps per stage so that a stage
 // still carries >= 18 MFMAs per wave between two barriers.
 //   <128, 4, 2, 1>  Cout % 128 == 0 (and the pixel-shuffled up-convs, N = 4 Cout): waves 64 x 64
 //   < 64, 4, 2, 3>  Cout % 64 == 0: waves 64 x 32        < 32, 8, 1, 3>  Cout % 32 == 0: waves 32 x 32
-template <int BN_, int WM_, int WN_, int TPS_>
+//   <128, 4, 2, 3, 16>  the same tile on 16-CHANNEL chunks: one MFMA k-step per tap, three taps per stage = 36 MFMAs per wave
+//                        between two barriers instead of 24, 80-byte LDS rows [16 hi | 16 lo | pad]; measured on the variant-rows
+//                        kernel (conv_region.hip, same pipeline): 8.5 % faster than the 32-channel / one-tap stages at K = 4608
+template <int BN_, int WM_, int WN_, int TPS_, int KCH_ = 32>
 struct PCfg {
-    static constexpr int BN = BN_, WM = WM_, WN = WN_, TPS = TPS_;
+    static constexpr int BN = BN_, WM = WM_, WN = WN_, TPS = TPS_, KCH = KCH_;
     static constexpr int TM = PBM / (WM * 32), TN = BN / (WN * 32);
+    static constexpr int ROWB = KCH == 32 ? 144 : 80;         // LDS row bytes: [KCH hi bf16 | KCH lo bf16 | 16 pad]
+    static constexpr int LO = KCH * 2;                        // byte offset of the lo half inside a row
+    static constexpr int QG = KCH / 8;                        // 8-channel groups per halo pixel
+    static constexpr int KSTEPS = KCH / 16;                   // MFMA k-steps per tap
+    static constexpr int ITEMS = PHALO * QG;                  // (halo pixel, 8-channel group) work items of one chunk
+    static constexpr int A_BYTES = PHALO * ROWB;
     static constexpr int NSTG = 9 / TPS;                      // stages per chunk
-    static constexpr int PIECE = PITEMS / NSTG;               // halo items of the NEXT chunk fetched per stage
-    static constexpr int BITEMS = TPS * BN * 8;               // 16-byte weight pieces per stage
+    static constexpr int PIECE = ITEMS / NSTG;                // halo items of the NEXT chunk fetched per stage
+    static constexpr int BPC = KCH / 4;                       // 16-byte pieces per weight row
+    static constexpr int BITEMS = TPS * BN * BPC;             // 16-byte weight pieces per stage
     static constexpr int BJ = (BITEMS + PNTHR - 1) / PNTHR;
     static constexpr int B_BYTES = TPS * BN * ROWB;
+    static_assert(KCH == 32 || KCH == 16, "chunk");
     static_assert(WM * WN * 64 == PNTHR && TM >= 1 && TN >= 1 && NSTG * TPS == 9, "wave layout");
-    static_assert(PIECE * NSTG == PITEMS && PIECE <= PNTHR, "halo split");
+    static_assert(PIECE * NSTG == ITEMS && PIECE <= PNTHR, "halo split");
 };
 using CfgL = PCfg<128, 4, 2, 1>;
+using CfgL16 = PCfg<128, 4, 2, 3, 16>;
 using CfgM = PCfg<64, 4, 2, 3>;
 using CfgS = PCfg<32, 8, 1, 3>;
 
 template <typename C, bool SHUF>
 constexpr int plain_smem() {      // A x2, B x2, 3 x per-tile metadata {out offset int, noise float x (4 if SHUF)},
-    return 2 * PA_BYTES + 2 * C::B_BYTES + 3 * PBM * 4 * (1 + (SHUF ? 4 : 1))        // + fused-statistics scratch
+    return 2 * C::A_BYTES + 2 * C::B_BYTES + 3 * PBM * 4 * (1 + (SHUF ? 4 : 1))      // + fused-statistics scratch
            + (SHUF ? 0 : C::WM * C::BN * 2 * 8);
 }
 
-__device__ __forceinline__ void split_store(unsigned char* dst, const f32x8 v) {
+__device__ __forceinline__ void split_store(unsigned char* dst, const f32x8 v, const int lo = LO) {
     const bf16x8 h = __builtin_convertvector(v, bf16x8);
     const f32x8 r = v - __builtin_convertvector(h, f32x8);
     const bf16x8 l = __builtin_convertvector(r, bf16x8);
     *reinterpret_cast<bf16x8*>(dst) = h;
-    *reinterpret_cast<bf16x8*>(dst + LO) = l;
+    *reinterpret_cast<bf16x8*>(dst + lo) = l;
 }
 
 __device__ __forceinline__ f32x8 load8(const float* src) {
@@ -126,7 +136,8 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                                                             const int cper) {
     constexpr int BM = PBM, BN = C::BN, NTHR = PNTHR, WN = C::WN, TM = C::TM, TN = C::TN, TH = PTH, TPS = C::TPS;
     constexpr int NSTG = C::NSTG, PIECE = C::PIECE, BITEMS = C::BITEMS, BJ = C::BJ;
-    constexpr int A_BYTES = PA_BYTES, B_BYTES = C::B_BYTES, NZ = SHUF ? 4 : 1;
+    constexpr int A_BYTES = C::A_BYTES, B_BYTES = C::B_BYTES, NZ = SHUF ? 4 : 1;
+    constexpr int KC = C::KCH, ROWB = C::ROWB, LO = C::LO, QG = C::QG, KSTEPS = C::KSTEPS, BPC = C::BPC, PITEMS = C::ITEMS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                          // [2][HALO][ROWB]
     unsigned char* sB = smem + 2 * A_BYTES;            // [2][TPS*BN][ROWB]
@@ -183,13 +194,13 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
 
     // halo item of tile `id` -> (global offset in floats inside the sample, or a dummy in-bounds one)
     auto item_src = [&](const TileId& id, int item, bool& ok) -> size_t {
-        const int h = item >> 2, q = item & 3;
+        const int h = item / QG, q = item % QG;
         const int hy = h / HALO_W, hx = h - hy * HALO_W;
         const int iy = id.tyb * TH + hy - 1, ix = id.txb * TW + hx - 1;
         ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         return ok ? ((size_t)iy * p.Wi + ix) * p.Cin + q * 8 : (size_t)(q * 8);
     };
-    auto item_dst = [&](int item) -> int { return (item >> 2) * ROWB + (item & 3) * 16; };
+    auto item_dst = [&](int item) -> int { return (item / QG) * ROWB + (item % QG) * 16; };
     // the per-channel transform operands of 8 channels starting at channel c of sample tb
     struct XOp { f32x8 a, b; };
     auto load_xop = [&](int tb, int c) -> XOp {
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
     // lives at weight set `phase` ([4][9][Cout][Cin])
     auto b_src = [&](int j, int n0, int tap0, int chunk) -> size_t {
         const int i = tid + NTHR * j;
-        const int row = b_ok[j] ? i >> 3 : 0, pc = i & 7;
+        const int row = b_ok[j] ? i / BPC : 0, pc = i % BPC;
         const int tl = row / BN, n = n0 + (row - tl * BN);
         size_t r;
         if (SHUF) {
@@ -227,13 +238,15 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
         } else {
             r = (size_t)(tap0 + tl) * ngemm + n;
         }
+        // the split weights keep 32-channel chunks [32 hi | 32 lo]; a 16-channel chunk is the (chunk & 1) half of both
+        if (KC == 16) return r * wrow + (size_t)(chunk >> 1) * 128 + (chunk & 1) * 32 + (pc >> 1) * 64 + (pc & 1) * 16;
         return r * wrow + (size_t)chunk * 128 + pc * 16;
     };
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
         const int i = tid + NTHR * j;
         b_ok[j] = i < BITEMS;
-        b_dst[j] = b_ok[j] ? (i >> 3) * ROWB + (i & 7) * 16 : 0;
+        b_dst[j] = b_ok[j] ? (i / BPC) * ROWB + (i % BPC) * 16 : 0;
     }
 
     if (first >= ntiles) return;
@@ -249,9 +262,9 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
             bool ok;
             const size_t off = item_src(cur, item, ok);
             f32x8 v = load8(xb + off);
-            if (XF) v = apply_xop(v, load_xop(cur.tb, cur.c_lo * KC + (item & 3) * 8));
+            if (XF) v = apply_xop(v, load_xop(cur.tb, cur.c_lo * KC + (item % QG) * 8));
             if (!ok) v = zero8;                                 // zero padding applies AFTER the transform (conv pad)
-            split_store(sA + item_dst(item), v);
+            split_store(sA + item_dst(item), v, LO);
         }
         f32x4 pb[BJ];
 #pragma unroll
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                     bool ok;
                     const size_t off = item_src(own, item, ok);
                     P.a = load8((have_nc ? xb_n : p.x) + off);
-                    if (XF) P.x = load_xop(have_nc ? own.tb : 0, c_n * KC + (item & 3) * 8);
+                    if (XF) P.x = load_xop(have_nc ? own.tb : 0, c_n * KC + (item % QG) * 8);
                     P.ok = ok;
                     P.part = have_nc && piece_thr;
                     P.dst = item_dst(item);
@@ -336,7 +349,7 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                 // group's MFMAs are issued, and the order is pinned (left alone, the scheduler sinks each read to just
                 // before its first use and the matrix pipe idles an LDS round trip per group)
                 auto ldB = [&](BFrag& F, int u) {
-                    const int tl = u >> 1, kk = u & 1;
+                    const int tl = u / KSTEPS, kk = u % KSTEPS;
                     const unsigned char* Bt = Bb + tl * BN * ROWB + kk * 32;
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
@@ -346,8 +359,8 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                 };
                 auto ldA = [&](AFrag& F, int g) {
                     const int u = g / TM, tm = g - u * TM;
-                    const int tap = ts * TPS + (u >> 1);
-                    const unsigned char* At = Ab + ((tap / 3) * HALO_W + (tap % 3)) * ROWB + (u & 1) * 32 + arow[tm];
+                    const int tap = ts * TPS + u / KSTEPS;
+                    const unsigned char* At = Ab + ((tap / 3) * HALO_W + (tap % 3)) * ROWB + (u % KSTEPS) * 32 + arow[tm];
                     F.h = *reinterpret_cast<const bf16x8*>(At);
                     F.l = *reinterpret_cast<const bf16x8*>(At + LO);
                 };
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h[tn], acc[tm][tn], 0, 0, 0);
                 };
-                constexpr int NU = 2 * TPS, NGRP = NU * TM;   // sub-steps / MFMA groups (3*TN MFMAs each) per stage
+                constexpr int NU = KSTEPS * TPS, NGRP = NU * TM;   // sub-steps / MFMA groups (3*TN MFMAs each) per stage
                 BFrag B0, B1;
                 AFrag A0, A1;
                 ldB(B0, 0);
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(PNTHR) void conv_bf16x3_kernel(const e4s_conv_param
                     f32x8 v = P.a;
                     if (XF) v = apply_xop(v, P.x);
                     if (!P.ok) v = zero8;
-                    split_store(sA + ((cg + 1) & 1) * A_BYTES + P.dst, v);
+                    split_store(sA + ((cg + 1) & 1) * A_BYTES + P.dst, v, LO);
                 }
                 __syncthreads();
                 ++sg;
@@ -1225,7 +1238,8 @@ int launch(const e4s_conv_params& p, hipStream_t st) {
     const int ntn = ngemm / C::BN;
     const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + PTH - 1) / PTH) * tx_n;
     int ksplit, cper;
-    plain_split(p, ngemm / C::BN, ksplit, cper);
+    plain_split(p, ngemm / C::BN, ksplit, cper);             // policy in 32-channel chunks, whatever the kernel's chunk
+    cper *= 32 / C::KCH;
     if (ksplit > 1 && !p.splitk_ws) return (int)hipErrorInvalidValue;
     const int64_t ntiles = (int64_t)p.B * per_img * ntn * ksplit;
     if (ntiles <= 0) return 0;
@@ -1302,7 +1316,11 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
         if ((4 * p.Cout) % 128) return (int)hipErrorInvalidValue;
         return launch_xf<CfgL, true>(p, st);
     }
-    if (p.Cout % 128 == 0) return launch_xf<CfgL, false>(p, st);
+#ifdef E4S_ABLATIONS
+    static const int k16 = [] { const char* e = getenv("E4S_PLAIN_K16"); return e ? atoi(e) : 1; }();
+    if (p.Cout % 128 == 0 && !k16) return launch_xf<CfgL, false>(p, st);
+#endif
+    if (p.Cout % 128 == 0) return launch_xf<CfgL16, false>(p, st);
     if (p.Cout % 64 == 0) return launch_xf<CfgM, false>(p, st);
     return launch_xf<CfgS, false>(p, st);
 }

@@ -67,6 +67,10 @@ for tag, b, res, cin, cout, up in CASES:
     err_old = float((got - old).abs().max() / ref.abs().max())
     ms = timeit(lambda: K.conv_mfma(x, w, cout, w_split=ws, **kw))
     gf = 2.0 * b * res * res * cin * cout * 9 * ncls / 1e9
-    row = {"layer": tag, "var": var, "ms": round(ms, 4), "tflops_executed_products": round(gf / ms, 1), "max_err_vs_f32": err, "max_diff_vs_region_select": err_old}
+    # the same contraction with ONE style per sample on the plain (persistent, 32-channel chunks) kernel: the rate to compare with
+    kwp = dict(kw, labels=None, num_regions=1, in_scale=s[::R].contiguous(), out_scale=d[::R].contiguous())
+    kwp.pop("w_split16", None)
+    ms_plain = timeit(lambda: K.conv_mfma(x, w, cout, w_split=ws, **kwp))
+    row = {"layer": tag, "var": var, "ms": round(ms, 4), "tflops_executed_products": round(gf / ms, 1), "plain_kernel_ms": round(ms_plain, 4), "max_err_vs_f32": err, "max_diff_vs_region_select": err_old}
     print(json.dumps(row), flush=True)
     out.write(json.dumps(row) + "\n")
