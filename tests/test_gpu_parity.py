@@ -821,6 +821,17 @@ def test_weight_repacking_kernels():
     blur = orc.make_blur_kernel() * 4
     assert maxabs(K.polyphase_weights(w.to(DEV), blur.to(DEV)), polyphase_upconv_weights(w, blur)) < 1e-6
     assert torch.equal(K.pack_taps(w.to(DEV)).cpu(), _pack(w))
+    # the two split-bf16 images of tap-packed weights: [rows][Cin/32][32 hi | 32 lo] and [rows][Cin/16][Cout][16 hi | 16 lo]
+    wt = torch.randn(2, 9, 8, 64, generator=g)
+    hi = wt.bfloat16()
+    lo = (wt - hi.float()).bfloat16()
+    bits = lambda t: t.view(torch.int16)
+    s32 = K.split_bf16x2(wt.to(DEV)).cpu().view(torch.int16).view(18, 8, 2, 2, 32)            # [row][co][chunk][hi|lo][32]
+    assert torch.equal(s32[:, :, :, 0], bits(hi).view(18, 8, 2, 32)) and torch.equal(s32[:, :, :, 1], bits(lo).view(18, 8, 2, 32))
+    s16 = K.split16_bf16x2(wt.to(DEV)).cpu().view(torch.int16).view(18, 4, 8, 2, 16)           # [row][chunk][co][hi|lo][16]
+    want_hi = bits(hi).view(18, 8, 4, 16).permute(0, 2, 1, 3)
+    want_lo = bits(lo).view(18, 8, 4, 16).permute(0, 2, 1, 3)
+    assert torch.equal(s16[:, :, :, 0], want_hi) and torch.equal(s16[:, :, :, 1], want_lo)
 
 
 # ---------------------------------------------------------------------------------------------
