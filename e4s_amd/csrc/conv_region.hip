@@ -83,7 +83,8 @@ __device__ __forceinline__ void scale_split_store(unsigned char* dst, const f32x
 
 __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_params p, const unsigned char* __restrict__ w16,
                                                                 int* __restrict__ tile_flags, const int ntn, const int tx_n,
-                                                                const int per_img, const int tiles_per_cls) {
+                                                                const int per_img, const int tiles_per_cls, const int ksplit,
+                                                                const int cper) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                          // [2][NROW][ROWB]
     unsigned char* sB = smem + OFF_B;                  // [2][TPS*BN][ROWB]
@@ -101,7 +102,11 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
     const int li = lane & 31, kh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    // ksplit > 1 (launches of <= 128 tiles): the 16-channel chunks of a tile are divided over ksplit consecutive blocks; each stores
+    // d[region] * (its partial sum) to its slab of p.splitk_ws and e4s_splitk_epilogue adds the slabs in order (+ noise / bias / act)
+    const int logical0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = logical0 % ksplit;
+    const int logical = logical0 / ksplit;
     const int mt = logical / ntn, nt = logical - mt * ntn;
     const int n0 = nt * BN;
     const int cls = mt / tiles_per_cls;
@@ -118,6 +123,37 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
         const int sx = min((int)floorf((float)ox * ((float)p.Wm / (float)p.Wo)), p.Wm - 1);
         return p.labels[((size_t)tb * p.Hm + sy) * p.Wm + sx];
     };
+
+    const int nchunk_all = p.Cin / KC, c_lo = ks * cper, nchunk = min(nchunk_all - c_lo, cper);        // this block's chunks
+    const float* xb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin + c_lo * KC;
+    const float* stab = p.in_scale + (size_t)tb * R * p.Cin + c_lo * KC;
+    // weight piece of this thread in a tap's 8 KB run: column tid / 4, 16-byte piece tid % 4
+    const size_t wtap = (size_t)nchunk_all * p.Cout * 64, wchunk = (size_t)p.Cout * 64;
+    const unsigned char* wb = w16 + ((size_t)cls * 9 * nchunk_all * p.Cout + n0) * 64 + (size_t)c_lo * wchunk + (size_t)tid * 16;
+    const int b_dst = (tid >> 2) * ROWB + (tid & 3) * 16;
+
+    // ---- loads that do not depend on the label map, issued before the tile analysis so that its two dependent global round trips
+    // (labels, then styles) overlap them: stage 0's weights, the x of the own rows among staging items 0 / 1, the d table ----
+    f32x4 pb0[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) pb0[j] = *reinterpret_cast<const f32x4*>(wb + j * wtap);
+    f32x8 xe[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + NTHR * i, h = e >> 1, q = e & 1;
+        const int hy = h / HALO_W, hx = h - hy * HALO_W;
+        const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
+        const bool inside = h < HALO && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        xe[i] = load8(xb + (inside ? (iy * p.Wi + ix) * p.Cin + q * 8 : 0));
+    }
+    float pd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.out_scale) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = tid + NTHR * k, r = t / BN, n = t - r * BN;
+            if (r < R) pd[k] = p.out_scale[((size_t)tb * R + r) * p.Cout + n0 + n];
+        }
+    }
 
     // ---- tile setup 1: output pixels (offset, noise, region), halo pixels (own region) ----
     if (tid < BM) {
@@ -181,7 +217,7 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
     __syncthreads();
     const int nvar = s_misc[0];
     const bool overflow = nvar > VMAX;
-    if (tid == 0 && nt == 0) tile_flags[mt] = overflow ? 1 : 0;        // overflowing tiles: the region-select kernel, second launch
+    if (tid == 0 && nt == 0 && ks == 0) tile_flags[mt] = overflow ? 1 : 0;        // overflowing tiles: the region-select kernel, second launch
     if (overflow) return;
     if (tid < HALO) {
         unsigned bits = s_need[tid];
@@ -249,25 +285,17 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
         }
     }
 
-    const int nchunk = p.Cin / KC;
-    const float* xb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin;
-    const float* stab = p.in_scale + (size_t)tb * R * p.Cin;
-    // weight piece of this thread in a tap's 8 KB run: column tid / 4, 16-byte piece tid % 4
-    const unsigned char* wb = w16 + ((size_t)cls * 9 * nchunk * p.Cout + n0) * 64 + (size_t)tid * 16;
-    const size_t wtap = (size_t)nchunk * p.Cout * 64, wchunk = (size_t)p.Cout * 64;
-    const int b_dst = (tid >> 2) * ROWB + (tid & 3) * 16;
 
     // ---- prologue: chunk 0's rows, stage 0's weights ----
 #pragma unroll
     for (int i = 0; i < NSTG; ++i)
-        if (a_dst[i] >= 0) scale_split_store(sA + a_dst[i], load8(xb + a_src[i]), load8(stab + a_sty[i]));
-    {
-        f32x4 pb[BJ];
+        if (a_dst[i] >= 0) {
+            const bool early = i == 0 || (i == 1 && tid < 2 * (HALO - NTHR / 2));        // own rows fetched above
+            const f32x8 x = early ? xe[i < 2 ? i : 0] : load8(xb + a_src[i]);
+            scale_split_store(sA + a_dst[i], x, load8(stab + a_sty[i]));
+        }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) pb[j] = *reinterpret_cast<const f32x4*>(wb + j * wtap);
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(sB + j * BN * ROWB + b_dst) = pb[j];
-    }
+    for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(sB + j * BN * ROWB + b_dst) = pb0[j];
     __syncthreads();
 
     f32x16 acc[TM][TN];
@@ -370,9 +398,10 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
     // ---- epilogue: d[region][co] * acc + noise + bias, activation, NHWC store (as the region-select kernel) ----
     float* sD = reinterpret_cast<float*>(sA);          // [R][BN]; the loop's last barrier has passed
     if (p.out_scale) {
-        for (int t = tid; t < R * BN; t += NTHR) {
-            const int r = t / BN, n = t - r * BN;
-            sD[t] = p.out_scale[((size_t)tb * R + r) * p.Cout + n0 + n];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = tid + NTHR * k;
+            if (t < R * BN) sD[t] = pd[k];
         }
         __syncthreads();
     }
@@ -380,7 +409,8 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) bsv[tn] = p.bias ? p.bias[n0 + (wn * TN + tn) * 32 + li] : 0.f;
     const float gain = (p.act == 1) ? p.gain : 1.f;
-    const bool do_act = p.act != 0, scaled = p.out_scale != nullptr;
+    const bool do_act = p.act != 0, scaled = p.out_scale != nullptr, raw = ksplit > 1;
+    float* yo = raw ? p.splitk_ws + (size_t)ks * ((size_t)p.B * p.Ho * p.Wo * p.Cout) : p.y;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -395,8 +425,11 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int ncol = (wn * TN + tn) * 32 + li;
-                    float t = acc[tm][tn][r] * (scaled ? drow[ncol] : 1.f) + nz + bsv[tn];
-                    if (do_act) t = (t > 0.f ? t : t * p.alpha) * gain;
+                    float t = acc[tm][tn][r] * (scaled ? drow[ncol] : 1.f);
+                    if (!raw) {
+                        t += nz + bsv[tn];
+                        if (do_act) t = (t > 0.f ? t : t * p.alpha) * gain;
+                    }
                     v[tn][i] = t;
                 }
             }
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
             if (off >= 0) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    *reinterpret_cast<f32x4*>(p.y + (size_t)off * p.Cout + n0 + (wn * TN + tn) * 32 + (li & ~3)) =
+                    *reinterpret_cast<f32x4*>(yo + (size_t)off * p.Cout + n0 + (wn * TN + tn) * 32 + (li & ~3)) =
                         f32x4{v[tn][0], v[tn][1], v[tn][2], v[tn][3]};
             }
         }
@@ -461,7 +494,7 @@ extern "C" int64_t e4s_conv_region_ws_floats(const e4s_conv_params* pp) {
     int ksplit, cper;
     e4s_region_split_policy(p, ksplit, cper);
     const int64_t tiles = (int64_t)p.B * ((p.Ha + TH - 1) / TH) * ((p.Wa + TW - 1) / TW) * p.ncls;
-    return ksplit > 1 ? (int64_t)ksplit * p.B * p.Ho * p.Wo * p.Cout : tiles;
+    return (ksplit > 1 ? (int64_t)ksplit * p.B * p.Ho * p.Wo * p.Cout : 0) + tiles;        // [split-K slabs][tile flags]
 }
 
 extern "C" int e4s_conv_region_bf16x3_f32(const e4s_conv_params* pp, const void* w16, void* stream) {
@@ -470,7 +503,7 @@ extern "C" int e4s_conv_region_bf16x3_f32(const e4s_conv_params* pp, const void*
     hipStream_t st = as_stream(stream);
     int ksplit, cper;
     e4s_region_split_policy(p, ksplit, cper);
-    if (ksplit > 1 || !w16) return e4s_launch_region_select(p, nullptr, st);      // few tiles (split over K): the region-select kernel
+    if (!w16) return e4s_launch_region_select(p, nullptr, st);
     if (!p.splitk_ws) return (int)hipErrorInvalidValue;
     auto kern = conv_region_rows_kernel;
     static std::atomic<uint64_t> smem_set{0};
@@ -478,12 +511,14 @@ extern "C" int e4s_conv_region_bf16x3_f32(const e4s_conv_params* pp, const void*
     const int ntn = p.Cout / BN;
     const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + TH - 1) / TH) * tx_n;
     const int tiles_per_cls = p.B * per_img;
-    const int64_t blocks = (int64_t)tiles_per_cls * p.ncls * ntn;
+    const int64_t blocks = (int64_t)tiles_per_cls * p.ncls * ntn * ksplit;
     if (blocks <= 0) return 0;
     if (blocks >= (1ll << 31)) return (int)hipErrorInvalidValue;
-    int* flags = reinterpret_cast<int*>(p.splitk_ws);
+    int* flags = reinterpret_cast<int*>(p.splitk_ws + (ksplit > 1 ? (size_t)ksplit * p.B * p.Ho * p.Wo * p.Cout : 0));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM, st, p, reinterpret_cast<const unsigned char*>(w16), flags,
-                       ntn, tx_n, per_img, tiles_per_cls);
+                       ntn, tx_n, per_img, tiles_per_cls, ksplit, cper * (32 / KC));
     E4S_CHECK_LAUNCH();
-    return e4s_launch_region_select(p, flags, st);      // tiles with > VMAX variant rows (flag table written by the launch above)
+    // tiles with > VMAX variant rows (flag table written by the launch above) on the region-select kernel, same K split and slabs;
+    // that launcher also runs the second stage of a split launch
+    return e4s_launch_region_select(p, flags, st);
 }

@@ -311,7 +311,9 @@ def _region_case(b, h, w, cin, cout, up, kind, R=12, seed=41):
     (2, 48, 40, 64, 128, False, "face", 12), (2, 64, 64, 96, 256, False, "blocks", 12), (9, 64, 64, 512, 128, False, "face", 12),
     (2, 32, 32, 64, 128, True, "face", 12), (2, 24, 40, 64, 256, True, "blocks", 12), (1, 33, 17, 64, 128, False, "face", 12),
     (2, 64, 64, 64, 128, False, "noise", 12), (2, 64, 64, 64, 128, False, "half-noise", 12), (2, 32, 48, 64, 128, False, "blocks", 16),
-    (3, 128, 128, 128, 128, False, "face", 12)])
+    (3, 128, 128, 128, 128, False, "face", 12),
+    # launches of <= 128 tiles: the input channels split over blocks (slabs + second stage), variant rows inside each split
+    (1, 32, 32, 512, 512, False, "face", 12), (1, 16, 16, 512, 256, True, "blocks", 12), (2, 64, 64, 256, 128, False, "half-noise", 12)])
 def test_region_rows_kernel_vs_fp32_and_region_select(b, h, w, cin, cout, up, kind, R):
     """e4s_conv_region_bf16x3_f32 (variant rows: the halo scaled with each pixel's own region's style once, boundary pairs read extra
     rows) on masked StyledConv contractions, plain and polyphase, ragged maps, 16 regions: == the exact fp32 region kernel to 1e-4
