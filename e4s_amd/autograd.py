@@ -28,9 +28,26 @@ def styled_conv_backward(rec, dy, num_regions, extras=None):
     dd = K.demod_grad(gz, y, rec["noise"], layer.noise.weight, act.bias, act.negative_slope, act.scale, labels,
                       num_regions) / d                                          # dL/dd  (out_pre = d * c)
     pk = conv.packed()
-    if "wt" not in pk:
-        pk["wt"] = K.pack_taps_bwd(pk["w"])
-    dx, ds = K.conv_bwd(gz, pk["wt"], rec["x"], s, d, labels, num_regions, 4 if conv.upsample else 1)
+    x = rec["x"]
+    b, h, w, cin = x.shape
+    cout = gz.shape[3]
+    if labels is None and not conv.upsample and x.is_contiguous() and K.want_bf16x3(b, h, w, cout, cin):
+        # one style per sample: dx = s * conv(gz * d, flipped W^T) is the FORWARD split-bf16 contraction on re-packed weights (the
+        # exact-fp32 dx + ds kernel ran the 64->64@512^2 / 32->32@1024^2 dgrads of the optimisation step at 0.69 / 0.71 ms, the forward
+        # kernels take ~0.1); ds = sum_p x * (the same contraction) leaves the pass that applies s
+        if "wt_fwd" not in pk:
+            wp = K.pack_taps(conv.weight.detach()[0].float().flip(2, 3).transpose(0, 1).contiguous())      # [1,9,Cin,Cout]
+            pk["wt_fwd"] = (wp, K.split_bf16x2(wp))
+        wp, wps = pk["wt_fwd"]
+        if cout == 32 and cin % 32 == 0:
+            u = K.conv_c32(gz.contiguous(), wps, cin, in_scale=d)
+        else:
+            u = K.conv_mfma(gz.contiguous(), wp, cin, w_split=wps, in_scale=d)
+        dx, ds = K.scale_dot(u, x, s)
+    else:
+        if "wt" not in pk:
+            pk["wt"] = K.pack_taps_bwd(pk["w"])
+        dx, ds = K.conv_bwd(gz, pk["wt"], x, s, d, labels, num_regions, 4 if conv.upsample else 1)
     # d = scale * rsqrt(scale^2 sum_ci s^2 Wsq + eps)  =>  dd/ds_ci = -d^3 s_ci Wsq[co,ci]
     dd3 = dd * d * d * d
     # ds - s * (dd3 @ Wsq): the [G,Cout] x [Cout,Cin] contraction on e4s_grouped_linear_t_f32 with the combine fused

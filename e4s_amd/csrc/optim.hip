@@ -121,6 +121,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
+// dgrad of an unmasked StyledConv on the forward kernels (e4s_amd/autograd.py): u = conv(gz * d, W^T flipped) arrives without the
+// style; one pass writes dx = u * s[b] in place and the partial sums of ds[b][c] = sum_p x[b,p,c] * u[b,p,c] (same ordered scheme
+// as colsum_kernel: rows of one sample per block, part[blk][b*C + c])
+__global__ __launch_bounds__(256) void scale_dot_kernel(float* __restrict__ u, const float* __restrict__ x, const float* __restrict__ s,
+                                                        float* __restrict__ part, int64_t hw, int C, int rpb, int B) {
+    __shared__ f32x4 sm[256];
+    const int c4n = C >> 2, lanes = 256 / c4n;
+    const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+    const int b = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = min(r0 + rpb, hw);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (rl < lanes) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(s + (int64_t)b * C + c4 * 4);
+        for (int64_t r = r0 + rl; r < r1; r += lanes) {
+            const int64_t off = ((int64_t)b * hw + r) * C + c4 * 4;
+            const f32x4 uv = *reinterpret_cast<const f32x4*>(u + off);
+            acc += uv * *reinterpret_cast<const f32x4*>(x + off);
+            *reinterpret_cast<f32x4*>(u + off) = uv * sv;
+        }
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        f32x4 t = sm[c4];
+        for (int l = 1; l < lanes; ++l) t += sm[l * c4n + c4];
+        *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * B + b) * C + c4 * 4) = t;
+    }
+}
+
 inline int colsum_rpb(int64_t rows, int C) {
     // ~2048 rows of work per block, but never more than 1024 blocks (e4s_reduce_parts_f32's two ordered levels)
     int64_t rpb = 2048;
@@ -268,6 +297,21 @@ extern "C" int e4s_colsum_f32(const float* x, float* out, float* ws, int64_t row
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), x, ws, rows, C, rpb);
     E4S_CHECK_LAUNCH();
     return e4s_reduce_parts_f32(ws, out, nblk, C, 1.f, stream);
+}
+
+extern "C" int64_t e4s_scale_dot_ws_floats(int B, int64_t hw, int C) {
+    const int rpb = colsum_rpb(hw, C);
+    return e4s_reduce_parts_ws_floats((int)((hw + rpb - 1) / rpb), (int64_t)B * C);
+}
+
+extern "C" int e4s_scale_dot_f32(float* u, const float* x, const float* s, float* ds, float* ws, int B, int64_t hw, int C,
+                                 void* stream) {
+    if (C % 4 || C > 1024 || C <= 0 || B <= 0 || B > 65535 || hw <= 0 || !ws) return (int)hipErrorInvalidValue;
+    const int rpb = colsum_rpb(hw, C);
+    const int nblk = (int)((hw + rpb - 1) / rpb);
+    hipLaunchKernelGGL(scale_dot_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, as_stream(stream), u, x, s, ws, hw, C, rpb, B);
+    E4S_CHECK_LAUNCH();
+    return e4s_reduce_parts_f32(ws, ds, nblk, (int64_t)B * C, 1.f, stream);
 }
 
 extern "C" int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,

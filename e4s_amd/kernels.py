@@ -890,6 +890,16 @@ def conv_bwd(gz, wt, x, s, d, labels, num_regions, ncls, want_ds=True):
     return dx, ds
 
 
+def scale_dot(u, x, s):
+    """u, x NHWC [B,H,W,C]; s [B,C]: u <- u * s[b] in place (returned) and ds[b,c] = sum_p x * u (the unscaled u), ordered sums."""
+    b, h, w, c = u.shape
+    assert u.is_contiguous() and x.is_contiguous() and x.shape == u.shape and s.shape == (b, c)
+    ds = torch.empty(b, c, device=u.device, dtype=torch.float32)
+    ws = torch.empty(lib.load().e4s_scale_dot_ws_floats(b, h * w, c), device=u.device, dtype=torch.float32)
+    call("e4s_scale_dot_f32", fptr(u), fptr(x), fptr(s), fptr(ds), fptr(ws), b, h * w, c, stream())
+    return u, ds
+
+
 def demod_grad(gz, y, noise, noise_w, bias, alpha, gain, labels, num_regions):
     """dL/dd [G, C] for out_pre = d * c (see e4s_demod_grad_f32); the caller divides by d."""
     b, h, w, c = gz.shape

@@ -97,6 +97,8 @@ SIGNATURES = {
     "e4s_upconv_bf16x3_f32": [c_p, c_p, c_p],
     "e4s_colsum_f32": [c_p, c_p, c_p, c_l, c_i, c_p],
     "e4s_colsum_ws_floats": [c_l, c_i],
+    "e4s_scale_dot_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_p],
+    "e4s_scale_dot_ws_floats": [c_i, c_l, c_i],
     "e4s_mask_to_u8": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_erode_u8": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_gaussian_blur_u8": [c_p, c_p, c_i, c_i, c_i, c_i, ctypes.POINTER(c_i), c_p],
@@ -171,7 +173,7 @@ SIGNATURES = {
 }
 
 INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats", "e4s_conv_region_ws_floats", "e4s_lpips_layer_ws_doubles", "e4s_conv_mfma_ws_floats",
-                "e4s_cosine_ws_doubles", "e4s_colsum_ws_floats"}       # size queries: return a count, not an error code
+                "e4s_cosine_ws_doubles", "e4s_colsum_ws_floats", "e4s_scale_dot_ws_floats"}       # size queries: return a count, not an error code
 
 _lib = None
 

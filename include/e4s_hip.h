@@ -355,6 +355,12 @@ int e4s_batch_sum_f32(const float* x, float* out, int B, int64_t n, void* stream
  * (rows = B*H*W); two ordered levels, bit-reproducible; ws: e4s_colsum_ws_floats(rows, C) floats */
 int e4s_colsum_f32(const float* x, float* out, float* ws, int64_t rows, int C, void* stream);
 int64_t e4s_colsum_ws_floats(int64_t rows, int C);
+/* Tail of an unmasked StyledConv's input gradient when the contraction ran on a forward kernel (model.py:276-320 backward):
+ * u NHWC [B,hw,C] = conv(gz * d, flipped W^T) without the style; in one pass u <- u * s[b] (= dL/dx, in place) and
+ * ds[b][c] = sum_p x[b,p,c] * u[b,p,c] (dL/ds through the modulated weight; ordered two-level sum, bit-reproducible).
+ * C % 4 == 0, C <= 1024; ws: e4s_scale_dot_ws_floats(B, hw, C) floats */
+int e4s_scale_dot_f32(float* u, const float* x, const float* s, float* ds, float* ws, int B, int64_t hw, int C, void* stream);
+int64_t e4s_scale_dot_ws_floats(int B, int64_t hw, int C);
 /* torch.optim.Adam's update (no amsgrad) fused into one pass over p/grad/m/v [n]; `step` >= 1 is the step being taken;
  * bias corrections are evaluated in double on the host as torch does */
 int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2,

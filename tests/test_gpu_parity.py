@@ -987,6 +987,55 @@ def test_styled_conv_backward_vs_oracle_f64(cin, cout, res, up, masked):
     assert maxabs(dweight, wref) < 2e-4 * float(wref.abs().max()), (maxabs(dweight, wref), float(wref.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,res", [(64, 64, 32), (32, 32, 48), (128, 64, 24), (64, 32, 40)])
+def test_unmasked_styled_conv_dgrad_on_the_forward_kernels_vs_oracle_f64(cin, cout, res, monkeypatch):
+    """Unmasked same-resolution StyledConv under the split-bf16 policy: dL/dx = s * conv(gz * d, flipped W^T) runs on the forward
+    kernels (plain split-bf16 kernel; the resident-weights kernel when gz has 32 channels) + e4s_scale_dot_f32 (applies s, reduces
+    dL/ds) instead of the exact-fp32 dx + ds kernel: both against the oracle's fp64 autograd, and close to the fp32 path."""
+    from e4s_amd import kernels as K
+    from e4s_amd.autograd import styled_conv_backward
+    from e4s_amd.stylegan2 import StyledConv
+    sd = _styled_sd(cin, cout, False, 23)
+    m = StyledConv(cin, cout, 3, 512, upsample=False, mask_op=False)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(52)
+    b = 2
+    x = torch.randn(b, cin, res, res, generator=g)
+    style = torch.randn(b, 512, generator=g)
+    noise = torch.randn(b, 1, res, res, generator=g)
+    wgt = torch.randn(b, cout, res, res, generator=g)
+    xd = K.nchw_to_nhwc(x.to(DEV))
+    mod = m.conv.modulation
+    s = K.modulate_vec(style.to(DEV), mod.weight, mod.bias)
+
+    # ONE forward (exact fp32) for both backward paths: lrelu'(y) flips where a pre-activation is within the split-bf16 error of zero,
+    # which would show up as isolated O(|dy|) differences in dx that have nothing to do with the dgrad kernels
+    monkeypatch.setattr(K, "PRECISION", "f32")
+    rec = {}
+    y = m.run_nhwc(xd, s, noise.to(DEV), None, 1, rec=rec)
+    rec.update(layer=m, x=xd, y=y, s=s, labels=None)
+
+    def run(prec):
+        monkeypatch.setattr(K, "PRECISION", prec)
+        dx, ds = styled_conv_backward(rec, K.nchw_to_nhwc(wgt.to(DEV)), 1, {})
+        return K.nhwc_to_nchw(dx), (ds @ mod.weight.detach()) * mod.scale
+
+    dx, dstyle = run("bf16x3")
+    dx32, dstyle32 = run("f32")
+    f64 = torch.float64
+    sd64 = {k: v.to(f64) for k, v in sd.items()}
+    xr = x.to(f64).requires_grad_(True)
+    sr = style.to(f64).requires_grad_(True)
+    yr = orc.styled_conv(sd64, "", xr, sr, None, noise.to(f64), False, False)
+    (yr * wgt.to(f64)).sum().backward()
+    gs, ss = float(xr.grad.abs().max()), float(sr.grad.abs().max())
+    assert maxabs(dx, xr.grad) < 1e-4 * gs, ("split-bf16 forward-kernel dgrad", maxabs(dx, xr.grad), gs)
+    assert maxabs(dx32, xr.grad) < 1e-4 * gs, ("exact fp32 dx + ds kernel", maxabs(dx32, xr.grad), gs)
+    assert 0 < maxabs(dx, dx32)                                   # another kernel, the same gradient
+    assert maxabs(dstyle.view_as(sr), sr.grad) < 3e-4 * ss and maxabs(dstyle, dstyle32) < 3e-4 * ss
+
+
 @pytest.mark.parametrize("cin,res,masked,with_skip", [(512, 8, True, True), (128, 32, False, True), (512, 4, True, False),
                                                        (32, 32, False, True)])
 def test_torgb_backward_vs_oracle_f64(cin, res, masked, with_skip):
