@@ -270,26 +270,26 @@ __global__ void instnorm_apply_stats_kernel(const float* __restrict__ x, const f
     }
 }
 
-// ---- SE gate (helpers.py:56-72): fc1 -> relu -> fc2 -> sigmoid on the pooled vector; one block per sample
-__global__ void se_gate_kernel(const float* __restrict__ pooled_in, const float* __restrict__ fc1,
-                               const float* __restrict__ fc2, float* __restrict__ gate, int C, int Cr) {
-    extern __shared__ float sm[];     // pooled[C], hidden[Cr]
-    float* pooled = sm;
-    float* hidden = sm + C;
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) pooled[c] = pooled_in[(int64_t)b * C + c];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-    for (int j = wv; j < Cr; j += nwv) {
+// ---- SE gate (helpers.py:56-72): fc1 -> relu -> fc2 -> sigmoid on the pooled vector; one block (512 threads) per sample.
+// fc1: the Cr rows are spread over ALL threads -- row j on threads [j*tpr, (j+1)*tpr), tpr = min(64, 512 / Cr) lanes of one wave, each
+// lane a strided share of the C products, combined by a butterfly over the tpr lanes (the first version walked the rows of a wave
+// one after the other: 4 dependent global round trips at Cr = 32, 14 us per launch against ~5 for the launch itself).
+__device__ __forceinline__ void se_body(const float* pooled, float* hidden, const float* __restrict__ fc1,
+                                        const float* __restrict__ fc2, float* __restrict__ gate, int C, int Cr) {
+    int tpr = 64;
+    while (tpr * Cr > (int)blockDim.x && tpr > 1) tpr >>= 1;
+    for (int j0 = 0; j0 < Cr; j0 += blockDim.x / tpr) {
+        const int j = j0 + threadIdx.x / tpr, l = threadIdx.x % tpr;
         float a = 0.f;
-        for (int c = lane; c < C; c += 64) a += fc1[(int64_t)j * C + c] * pooled[c];
-        a = wave_sum(a);
-        if (lane == 0) hidden[j] = a > 0.f ? a : 0.f;
+        if (j < Cr)
+            for (int c = l; c < C; c += tpr) a += fc1[(int64_t)j * C + c] * pooled[c];
+        for (int o = tpr >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (j < Cr && l == 0) hidden[j] = a > 0.f ? a : 0.f;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float a = 0.f;
-        if ((Cr & 3) == 0) {          // a thread's fc2 row is one contiguous 16..128-byte run: read it as float4s (same summation order)
+        if ((Cr & 3) == 0) {          // a thread's fc2 row is one contiguous 16..128-byte run: read it as float4s
             const f32x4* w4 = reinterpret_cast<const f32x4*>(fc2 + (int64_t)c * Cr);
             for (int j = 0; j < Cr; j += 4) {
                 const f32x4 w = w4[j >> 2];
@@ -301,8 +301,48 @@ __global__ void se_gate_kernel(const float* __restrict__ pooled_in, const float*
         } else {
             for (int j = 0; j < Cr; ++j) a += fc2[(int64_t)c * Cr + j] * hidden[j];
         }
-        gate[(int64_t)b * C + c] = 1.f / (1.f + __expf(-a));
+        gate[c] = 1.f / (1.f + __expf(-a));
     }
+}
+
+__global__ __launch_bounds__(512) void se_gate_kernel(const float* __restrict__ pooled_in, const float* __restrict__ fc1,
+                                                      const float* __restrict__ fc2, float* __restrict__ gate, int C, int Cr) {
+    extern __shared__ float sm[];     // pooled[C], hidden[Cr]
+    float* pooled = sm;
+    float* hidden = sm + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) pooled[c] = pooled_in[(int64_t)b * C + c];
+    __syncthreads();
+    se_body(pooled, hidden, fc1, fc2, gate + (int64_t)b * C, C, Cr);
+}
+
+// second stage of the fused InstanceNorm statistics (instnorm_finalize_kernel's arithmetic) + the SE gate of the normalised tensor
+// in one launch: one block per sample
+__global__ __launch_bounds__(512) void finalize_se_kernel(const double* __restrict__ ws, float* __restrict__ stats,
+                                                          const float* __restrict__ fc1, const float* __restrict__ fc2,
+                                                          float* __restrict__ gate, int C, int Cr, int HW, float eps, int nsplit) {
+    extern __shared__ float sm[];     // pooled[C], hidden[Cr]
+    float* pooled = sm;
+    float* hidden = sm + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int64_t i = (int64_t)b * C + c;
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nsplit; ++k) {
+            s += ws[(i * nsplit + k) * 2];
+            q += ws[(i * nsplit + k) * 2 + 1];
+        }
+        const double mean = s / HW;
+        double var = q / HW - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mean;
+        const float rstd = rsqrtf((float)var + eps);
+        stats[i * 2] = mf;
+        stats[i * 2 + 1] = rstd;
+        pooled[c] = (float)((mean - (double)mf) * (double)rstd);
+    }
+    __syncthreads();
+    se_body(pooled, hidden, fc1, fc2, gate + (int64_t)b * C, C, Cr);
 }
 
 __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
@@ -503,7 +543,18 @@ extern "C" int e4s_instnorm_apply_f32(const float* x, const float* stats, const 
 
 extern "C" int e4s_se_gate_f32(const float* pooled, const float* fc1, const float* fc2, float* gate, int B, int C,
                                int Cr, void* stream) {
+    if (B <= 0 || C <= 0 || Cr <= 0 || (size_t)(C + Cr) * sizeof(float) > 48 * 1024) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(512), (size_t)(C + Cr) * sizeof(float), as_stream(stream), pooled, fc1, fc2, gate, C, Cr);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_instnorm_finalize_se_f32(const double* ws, float* stats, const float* fc1, const float* fc2, float* gate, int B,
+                                            int HW, int C, int Cr, int nslots, float eps, void* stream) {
+    if (B <= 0 || C <= 0 || Cr <= 0 || nslots <= 0 || HW <= 0 || (size_t)(C + Cr) * sizeof(float) > 48 * 1024)
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(finalize_se_kernel, dim3(B), dim3(512), (size_t)(C + Cr) * sizeof(float), as_stream(stream), ws, stats, fc1, fc2,
+                       gate, C, Cr, HW, eps, nslots);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -52,7 +52,7 @@ def _conv3x3(x, conv, cout, in_stats=None, want_stats=False, **kw):
     return K.conv_mfma(x, w, cout, want_stats=want_stats, **kw)
 
 
-def _conv_strided(x, conv, cout, stride, ntaps, want_stats=False):
+def _conv_strided(x, conv, cout, stride, ntaps, want_stats=False, se=None):
     """The unit's stride-2 3x3 conv / 1x1 shortcut conv (helpers.py:125-137): per-tap gather kernels -- split-bf16 where
     K.PRECISION asks for it and the launch has enough 256-pixel tiles, exact fp32 otherwise."""
     w = _pack3x3(conv)
@@ -61,8 +61,8 @@ def _conv_strided(x, conv, cout, stride, ntaps, want_stats=False):
     if K.PRECISION != "f32" and cout % 128 == 0 and (K.PRECISION == "bf16x3" or tiles >= K.BF16X3_MIN_BLOCKS):
         if getattr(conv, "_e4s_split", None) is None or conv._e4s_split[0] != conv._e4s_pack[0]:
             conv._e4s_split = (conv._e4s_pack[0], K.split_bf16x2(w))
-        return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps, w_split=conv._e4s_split[1], want_stats=want_stats)
-    return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps, want_stats=want_stats)
+        return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps, w_split=conv._e4s_split[1], want_stats=want_stats, se=se)
+    return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps, want_stats=want_stats, se=se)
 
 
 class SEModule(Module):
@@ -107,12 +107,12 @@ class bottleneck_IR_SE_Ours(Module):
         if st_x is None:
             st_x, _ = K.instnorm_stats(x)
         r = _conv3x3(x, conv1, self.depth, in_stats=st_x, act=2, slope=prelu.weight)
+        se_w = (se.fc1.weight.view(se.fc1.weight.shape[0], -1), se.fc2.weight.view(se.fc2.weight.shape[0], -1))
+        # the SE gate leaves the launch that finishes conv2's statistics (e4s_instnorm_finalize_se_f32)
         if self.stride == 1:
-            r, (st_r, pooled) = _conv3x3(r, conv2, self.depth, want_stats=True)
+            r, (st_r, gate) = _conv3x3(r, conv2, self.depth, want_stats=True, se=se_w)
         else:
-            r, (st_r, pooled) = _conv_strided(r, conv2, self.depth, self.stride, 9, want_stats=True)
-        gate = K.se_gate(pooled, se.fc1.weight.view(se.fc1.weight.shape[0], -1),
-                         se.fc2.weight.view(se.fc2.weight.shape[0], -1))
+            r, (st_r, gate) = _conv_strided(r, conv2, self.depth, self.stride, 9, want_stats=True, se=se_w)
         if self.in_channel == self.depth:
             return K.instnorm_apply(r, st_r, gate=gate, res=x, rs=self.stride, want_stats=want_stats)   # MaxPool2d(1, s)
         sc, (st_sc, _) = _conv_strided(x, self.shortcut_layer[0], self.depth, self.stride, 1, want_stats=True)

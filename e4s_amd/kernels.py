@@ -251,7 +251,7 @@ def region_plan(labels, num_regions, ha, wa, nphase):
 def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, in_scale=None, out_scale=None,
               noise=None, noise_w=None, noise_per_channel=False, bias=None, slope=None, act=0, alpha=0.2,
               gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1, w_split=None, in_stats=None,
-              out=None, tap_shift=0, want_stats=False, w_split16=None):
+              out=None, tap_shift=0, want_stats=False, w_split16=None, se=None):
     """x NHWC [B,Hi,Wi,Cin]; w [ncls, ntaps, Cout, Cin] -> y NHWC [B,Ho,Wo,Cout].
     anchors = (Ha, Wa); defaults: up-conv (ncls=4) anchors = input grid, output 2x;
     strided conv anchors = output grid.
@@ -263,6 +263,8 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     kernel only).
     out: write the Cout channels into the FIRST channels of this wider NHWC tensor [B,Ho,Wo,Cy >= Cout] (returned).
     tap_shift: gather kernels only: 1 = padding-0 strided conv (input coord = anchor*istride + tap).
+    se = (fc1 [Cr,C], fc2 [C,Cr]) with want_stats: the second element of the returned pair is the SE gate [B,Cout] of the
+    normalised output instead of `pooled` (one launch with the statistics' second stage where the epilogue emitted them).
     want_stats: also return the InstanceNorm statistics of the OUTPUT, (y, (stats [B,Cout,2], pooled [B,Cout])): emitted by
     the split-bf16 kernels' epilogue (no extra pass over y) where that applies, by e4s_instnorm_stats_f32 otherwise."""
     b, hi, wi, cin = x.shape
@@ -351,8 +353,12 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
         if fused is not None:
             stats = torch.empty(b, cout, 2, device=x.device, dtype=torch.float32)
             pooled = torch.empty(b, cout, device=x.device, dtype=torch.float32)
-            call("e4s_instnorm_finalize_f32", ptr(fused), fptr(stats), fptr(pooled), b, ho * wo, cout, p.stats_slots, 1e-5,
-                 stream())
+            if se is not None:
+                call("e4s_instnorm_finalize_se_f32", ptr(fused), fptr(stats), fptr(se[0]), fptr(se[1]), fptr(pooled), b, ho * wo,
+                     cout, se[0].shape[0], p.stats_slots, 1e-5, stream())
+            else:
+                call("e4s_instnorm_finalize_f32", ptr(fused), fptr(stats), fptr(pooled), b, ho * wo, cout, p.stats_slots, 1e-5,
+                     stream())
             return y, (stats, pooled)
     elif in_stats is not None:
         raise RuntimeError("fused InstanceNorm staging exists only in e4s_conv_bf16x3_f32")
@@ -362,7 +368,8 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
         p.splitk_ws = fptr(skws)
         call("e4s_conv_mfma_f32", ctypes.byref(p), 1 if spatial else 0, stream())
     if want_stats:
-        return y, instnorm_stats(y, want_pooled=True)
+        stats, pooled = instnorm_stats(y, want_pooled=True)
+        return y, (stats, se_gate(pooled, se[0], se[1]) if se is not None else pooled)
     return y
 
 

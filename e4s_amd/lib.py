@@ -129,6 +129,7 @@ SIGNATURES = {
     "e4s_instnorm_apply_stats_f32": [c_p] * 9 + [c_i] * 5 + [c_p],
     "e4s_instnorm_apply_f32": [c_p] * 7 + [c_i] * 5 + [c_p],
     "e4s_se_gate_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "e4s_instnorm_finalize_se_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "e4s_region_mean_f32": [c_p, c_p, c_i, c_i, c_p] + [c_i] * 7 + [c_p],
     "e4s_conv_wgrad_f32": [ctypes.POINTER(ConvWgradParams), c_p],
     "e4s_conv_wgrad_ws_floats": [ctypes.POINTER(ConvWgradParams)],

@@ -471,6 +471,10 @@ int e4s_instnorm_apply_f32(const float* x, const float* stats, const float* gate
 /* SE gate (helpers.py:56-72): gate[b,c] = sigmoid(fc2 . relu(fc1 . pooled[b]))  */
 int e4s_se_gate_f32(const float* pooled, const float* fc1, const float* fc2, float* gate,
                     int B, int C, int Cr, void* stream);
+/* e4s_instnorm_finalize_f32 + e4s_se_gate_f32 in one launch (one block per sample): stats [B,C,2] of the tensor whose partial
+ * sums are in ws, and the SE gate of its normalisation (bottleneck_IR_SE's IN -> SE tail, helpers.py:56-72,132-144) */
+int e4s_instnorm_finalize_se_f32(const double* ws, float* stats, const float* fc1, const float* fc2, float* gate, int B, int HW,
+                                 int C, int Cr, int nslots, float eps, void* stream);
 /* regional average pooling (psp_encoders.py:264-283): out[b, r, out_off + c] = mean over pixels with
  * label r of feats[b, p, c]; exact 0 for empty regions.  feats NHWC [B,H,W,C]. */
 int e4s_region_mean_f32(const float* feats, const uint8_t* labels, int Hm, int Wm, float* out,
