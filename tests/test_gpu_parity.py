@@ -640,6 +640,29 @@ def test_torgb_vs_oracle(cin, res, masked, with_skip):
 # ---------------------------------------------------------------------------------------------
 # encoder pieces against the oracle
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,h,w,cin,cout,stride", [(2, 32, 32, 64, 128, 1), (3, 32, 48, 128, 256, 2), (2, 16, 16, 512, 512, 1)])
+def test_se_gate_fused_with_the_statistics_finalisation(b, h, w, cin, cout, stride, monkeypatch):
+    """conv -> InstanceNorm statistics -> SE gate: with `se` the gate leaves the launch that adds the epilogue's partial sums
+    (e4s_instnorm_finalize_se_f32) -- same statistics bit for bit, gate == e4s_se_gate_f32 on the pooled vector bit for bit, and
+    == sigmoid(fc2 relu(fc1 pooled)) in fp64."""
+    from e4s_amd import kernels as K
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(b, h, w, cin, generator=g).to(DEV)
+    wt = (torch.randn(1, 9, cout, cin, generator=g) / math.sqrt(9 * cin)).to(DEV)
+    ws = K.split_bf16x2(wt)
+    cr = cout // 16
+    fc1 = (torch.randn(cr, cout, generator=g) * 50).to(DEV)          # pooled is a rounding residue (~1e-8 .. 1e-7): make the gate move
+    fc2 = (torch.randn(cout, cr, generator=g) * 1e6).to(DEV)
+    kw = dict(w_split=ws, want_stats=True, istride=stride)
+    y0, (st0, pooled) = K.conv_mfma(x, wt, cout, **kw)
+    y1, (st1, gate) = K.conv_mfma(x, wt, cout, se=(fc1, fc2), **kw)
+    assert torch.equal(y0, y1) and torch.equal(st0, st1)
+    assert torch.equal(gate, K.se_gate(pooled, fc1, fc2))
+    ref = torch.sigmoid(torch.relu(pooled.double() @ fc1.double().t()) @ fc2.double().t())
+    assert float((gate.double() - ref).abs().max()) < 1e-5 and float((gate - 0.5).abs().max()) > 1e-4
+
+
 @pytest.mark.parametrize("cin,depth,stride,res", [(64, 128, 2, 64), (128, 128, 1, 32), (512, 512, 2, 32)])
 def test_encoder_unit_vs_oracle(cin, depth, stride, res):
     from e4s_amd.encoders import bottleneck_IR_SE_Ours
