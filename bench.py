@@ -275,7 +275,7 @@ def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3):
     img = synth.synth_image(batch, SIZE, seed=7, tag="train_img").to(dev)
     mask = synth.onehot(synth.synth_labels_face(batch, 512, seed=21)).to(dev)
     params = [p for p in net.parameters() if p.requires_grad]
-    opt = FusedAdam(params, lr=1e-4)
+    opt = FusedAdam(params, lr=1e-4, capturable=True)       # (step count on the device: the same object serves the graphed G step)
     crit, disc, opt_d = {}, None, None
     lo = LossOpts(d_reg_every=16)
     if losses == "full":
@@ -305,8 +305,18 @@ def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3):
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
-    g_ms = timed(lambda: it.g_step(img, mask), steps, warmup)
-    out = {"ms_per_step": round(g_ms, 2), "g_step_ms": round(g_ms, 2), "batch": batch, "steps": steps, "warmup": warmup,
+    def g_eager():
+        it.forget_targets()          # every iteration is a new batch: the target features are recomputed, as calc_loss does
+        it.g_step(img, mask)
+    # the step replayed as ONE HIP graph (e4s_amd.train.graphed_g_step; target features, pack rebuilds, Adam and EMA inside).  Captured
+    # BEFORE any eager step: autograd's AccumulateGrad nodes remember the stream they were created on, and nodes left over from eager
+    # steps on the default stream break a later capture on the side stream
+    gs = it.graphed_g_step(img, mask, warmup=warmup)
+    g_ms = timed(gs.step, steps, 1)
+    gs.validate()
+    g_eager_ms = timed(g_eager, steps, 1)
+    out = {"ms_per_step": round(g_ms, 2), "g_step_ms": round(g_ms, 2), "g_step_graphed": True, "g_step_eager_ms": round(g_eager_ms, 2),
+           "batch": batch, "steps": steps, "warmup": warmup,
            "images_per_s": round(batch * 1e3 / g_ms, 2), "trainable_parameters": int(sum(p.numel() for p in params)),
            "losses": losses, "ema": net_ema is not None}
     if disc is not None:

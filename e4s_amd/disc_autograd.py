@@ -43,6 +43,14 @@ class _PackCache:
         return self.packs[name]
 
 
+def invalidate_packs(disc):
+    """Forget D's cached weight packs (a captured graph that must re-pack from the weights of the moment: train.graphed_g_step)."""
+    for m in disc.modules():
+        pc = getattr(m, "_e4s_dpacks", None)
+        if pc is not None:
+            pc.key, pc.packs = None, {}
+
+
 def _pack(w, cache=None):
     make = lambda: K.pack_taps(w.detach().float().contiguous())
     return cache[0].get(cache[1], "fwd", make) if cache is not None else make()

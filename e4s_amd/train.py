@@ -148,6 +148,35 @@ class TrainIteration:
             accumulate(self.net_ema, self.net, self.ema_decay)
         return loss.detach(), terms
 
+    def forget_targets(self):
+        """A new batch: drop the loss networks' cached target features.  criteria.py caches them per target TENSOR (right for the
+        latent optimisation, whose target never changes); a training loop that refills one static image buffer, or a benchmark that
+        feeds the same tensor every step, must not be served the previous batch's features -- the reference recomputes them in every
+        calc_loss (id_loss.py:33-35, lpips.py:27-35, face_parsing_loss.py:60-78)."""
+        for c in self.crit.values():
+            if hasattr(c, "_target"):
+                c._target = None
+
+    def graphed_g_step(self, img, onehot, warmup=2, **fwd):
+        """The G step (forward, every loss term incl. the target features, backward, fused Adam, EMA) captured as ONE HIP graph:
+        returns an optim.GraphedStep; `.step()` replays it on whatever `img` / `onehot` hold then (static buffers, refilled in
+        place).  Needs FusedAdam(capturable=True) and a single process (bucket all-reduces are not captured).  The eager G step is
+        ~2 500 launches, host-bound: 65-92 ms per step depending on the host against ~55 ms of kernel time.  Every weight pack the
+        step reads from a TRAINED network is rebuilt inside the graph (the net's are stale at capture time -- the warm-up steps just
+        updated them --, D's are invalidated here), so replays between eager D steps see the current weights."""
+        from .optim import GraphedStep
+        from . import disc_autograd
+        if self.averager is not None:
+            raise RuntimeError("graphed_g_step: single-process only (gradient averaging is launched from host-side hooks)")
+
+        def body():
+            self.forget_targets()
+            if self.disc is not None:
+                disc_autograd.invalidate_packs(self.disc)
+            loss, _ = self.g_step(img, onehot, **fwd)
+            return loss
+        return GraphedStep(self.opt, body, warmup=warmup)
+
     def iteration(self, img, onehot, batch_idx=0, **fwd):
         """One pass of the loop body at self.global_step (coach.py:281-398)."""
         out = {}

@@ -351,3 +351,60 @@ def test_d_step_and_r1_step_vs_oracle_f64():
             assert p.grad is None or float(p.grad.abs().max()) < 1e-6
             continue
         assert float((p.grad.cpu().double() - ref).norm() / ref.norm()) < 3e-3, k
+
+
+def test_graphed_g_step_equals_the_eager_loop():
+    """TrainIteration.graphed_g_step: forward (encoder + LocalMLPs trainable), the full loss incl. the loss networks' TARGET features
+    and the adversarial term, backward, capturable fused Adam and the EMA replayed as ONE HIP graph == the eager loop bit for bit --
+    after a step on another batch written into the same static buffers (the graph must not serve the previous batch's target
+    features) and with D's weights changed behind its back (its packs are rebuilt inside the graph)."""
+    import copy
+    from e4s_amd.optim import FusedAdam
+    from e4s_amd.train import LossOpts, TrainIteration
+    size, b = 256, 2
+    imgs = [synth.synth_image(b, size, tag="gs_img%d" % i).to(DEV) for i in range(2)]
+    masks = [synth.onehot(synth.synth_labels_face(b, 512, seed=41 + i)).to(DEV) for i in range(2)]
+
+    def build():
+        net, _, _ = _net(size)
+        net.train()
+        crit, disc, _ = _loss_modules(size)
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = FusedAdam(params, lr=1e-4, capturable=True)
+        ema = copy.deepcopy(net).eval()
+        lo = LossOpts(lpips_sizes=(256, 128, 64))
+        return TrainIteration(net, disc, crit, opt, None, lo=lo, net_ema=ema), net, disc, ema
+
+    def bump_d(disc):                       # what an eager D step in between does to D: new weights, same storage
+        with torch.no_grad():
+            for p in disc.parameters():
+                p.mul_(1.01)
+
+    # eager: 3 steps on batch 0, D changes, 1 step on batch 1 (static buffers refilled in place)
+    it_e, net_e, disc_e, ema_e = build()
+    img_e, mask_e = imgs[0].clone(), masks[0].clone()
+    for _ in range(3):
+        it_e.forget_targets()
+        it_e.g_step(img_e, mask_e, randomize_noise=False)
+    bump_d(disc_e)
+    img_e.copy_(imgs[1])
+    mask_e.copy_(masks[1])
+    it_e.forget_targets()
+    loss_e, _ = it_e.g_step(img_e, mask_e, randomize_noise=False)
+
+    # graphed: 2 eager warm-up steps + 1 replay on batch 0, D changes, 1 replay on batch 1
+    it_g, net_g, disc_g, ema_g = build()
+    img_g, mask_g = imgs[0].clone(), masks[0].clone()
+    gs = it_g.graphed_g_step(img_g, mask_g, warmup=2, randomize_noise=False)
+    gs.step()
+    bump_d(disc_g)
+    img_g.copy_(imgs[1])
+    mask_g.copy_(masks[1])
+    loss_g = gs.step()
+    gs.validate()
+    torch.cuda.synchronize()
+    assert torch.equal(loss_g, loss_e)
+    for (n, pe), (_, pg) in zip(net_e.named_parameters(), net_g.named_parameters()):
+        assert torch.equal(pe, pg), n
+    for (n, pe), (_, pg) in zip(ema_e.named_parameters(), ema_g.named_parameters()):
+        assert torch.equal(pe, pg), n
