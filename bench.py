@@ -117,7 +117,7 @@ def headline_probe(net, batch, mask, reps):
             "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "frac_ceiling": round(1.0 / 3.0, 4),
             "mfma_executed_tflops": round(3 * ach, 1), "traffic": traffic.get("hbm_bytes_per_launch_bf16x3"),
             "traffic_source": "profiles/roofline_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of "
-                              "this kernel (separate passes, profiles/r03f_pmc_{fetch,write}.csv); a PMC pass cannot run "
+                              "this kernel (separate passes, profiles/r03g_pmc_{fetch,write}.csv); a PMC pass cannot run "
                               "inside this timed process",
             "avg_launch_ms": round(ms, 4), "flop_per_launch": flops, "exact_fp32_variant": exact}
 
