@@ -111,7 +111,18 @@ __global__ __launch_bounds__(1024) void instnorm_small_kernel(const float* __res
     const int c = slab * 64 + cl;
     const float* xb = x + (int64_t)b * HW * C + c;
     double s = 0.0, q = 0.0;
-    for (int p = pg; p < HW; p += 16) {
+    int p = pg;
+    for (; p + 7 * 16 < HW; p += 8 * 16) {           // eight loads in flight; the sums keep their order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xb[(int64_t)(p + 16 * u) * C];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s += (double)v[u];
+            q += (double)v[u] * (double)v[u];
+        }
+    }
+    for (; p < HW; p += 16) {
         const double v = (double)xb[(int64_t)p * C];
         s += v;
         q += v * v;
@@ -142,6 +153,7 @@ __global__ void instnorm_finalize_kernel(const double* __restrict__ ws, float* _
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s = 0.0, q = 0.0;
+#pragma unroll 8
     for (int k = 0; k < nsplit; ++k) {
         s += ws[((int64_t)i * nsplit + k) * 2];
         q += ws[((int64_t)i * nsplit + k) * 2 + 1];
@@ -281,8 +293,20 @@ __device__ __forceinline__ void se_body(const float* pooled, float* hidden, cons
     for (int j0 = 0; j0 < Cr; j0 += blockDim.x / tpr) {
         const int j = j0 + threadIdx.x / tpr, l = threadIdx.x % tpr;
         float a = 0.f;
-        if (j < Cr)
-            for (int c = l; c < C; c += tpr) a += fc1[(int64_t)j * C + c] * pooled[c];
+        if (j < Cr) {
+            // eight loads in flight per lane (the products are still added in the order c = l, l + tpr, ...): a plain loop waits
+            // one global round trip per element, 32 of them at C = 512
+            const float* row = fc1 + (int64_t)j * C;
+            int c = l;
+            for (; c + 7 * tpr < C; c += 8 * tpr) {
+                float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = row[c + u * tpr];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += w[u] * pooled[c + u * tpr];
+            }
+            for (; c < C; c += tpr) a += row[c] * pooled[c];
+        }
         for (int o = tpr >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
         if (j < Cr && l == 0) hidden[j] = a > 0.f ? a : 0.f;
     }
@@ -291,6 +315,7 @@ __device__ __forceinline__ void se_body(const float* pooled, float* hidden, cons
         float a = 0.f;
         if ((Cr & 3) == 0) {          // a thread's fc2 row is one contiguous 16..128-byte run: read it as float4s
             const f32x4* w4 = reinterpret_cast<const f32x4*>(fc2 + (int64_t)c * Cr);
+#pragma unroll 8
             for (int j = 0; j < Cr; j += 4) {
                 const f32x4 w = w4[j >> 2];
                 a += w[0] * hidden[j];
@@ -328,6 +353,7 @@ __global__ __launch_bounds__(512) void finalize_se_kernel(const double* __restri
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int64_t i = (int64_t)b * C + c;
         double s = 0.0, q = 0.0;
+#pragma unroll 8
         for (int k = 0; k < nsplit; ++k) {
             s += ws[(i * nsplit + k) * 2];
             q += ws[(i * nsplit + k) * 2 + 1];
