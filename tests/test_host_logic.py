@@ -415,3 +415,32 @@ def test_train_iteration_cadence_follows_the_coach_loop():
     pen = d_r1_loss(disc(x), x)
     g, = torch.autograd.grad(disc(x).sum(), x, create_graph=True)
     assert torch.allclose(pen, g.pow(2).reshape(2, -1).sum(1).mean())
+
+
+def test_train_iteration_forgets_targets_per_batch_and_refuses_to_graph_a_multi_process_step():
+    """TrainIteration.forget_targets drops the loss networks' per-target feature caches (a training batch is a NEW target even when it
+    arrives in the same tensor: the reference recomputes the target features in every calc_loss, id_loss.py:33-35), and
+    graphed_g_step refuses a step whose gradient averaging is launched from host-side hooks, and a non-capturable optimiser --
+    both before anything touches a GPU."""
+    import types
+    from e4s_amd.train import TrainIteration
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(1))
+
+        def forward(self, img, onehot, **kw):
+            return img * self.w, None
+    net = Net()
+    crit = {"id": types.SimpleNamespace(_target=("key", "y", "feats")), "lpips": types.SimpleNamespace(_target=(1, 2, 3)),
+            "other": types.SimpleNamespace()}
+    it = TrainIteration(net, None, crit, torch.optim.SGD(net.parameters(), lr=1e-3), None, averager=object())
+    it.forget_targets()
+    assert crit["id"]._target is None and crit["lpips"]._target is None and not hasattr(crit["other"], "_target")
+    img = torch.zeros(1, 3, 4, 4)
+    with pytest.raises(RuntimeError, match="single-process"):
+        it.graphed_g_step(img, img)
+    it.averager = None
+    with pytest.raises(RuntimeError, match="capturable"):
+        it.graphed_g_step(img, img)
