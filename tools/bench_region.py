@@ -1,7 +1,10 @@
 """Micro-benchmark of the region-select split-bf16 kernel on the masked StyledConvs of the generator (8 images): the same-resolution
 layers and the polyphase up-convs, each timed and checked against the exact fp32 kernel on the same operands.
-Profiling builds (E4S_BUILD_ABLATIONS=1) select kernel variants with env E4S_REGION_VAR.  Prints one JSON line per layer and
-appends them to gpurun_out/bench_region.jsonl."""
+E4S_BENCH_ROWS=1: time e4s_conv_region_bf16x3_f32 (variant-rows kernel, what StyledConv.run_nhwc launches); unset: the region-select
+kernel of e4s_conv_bf16x3_f32, whose variants (wave layout / split form, csrc/conv_bf16x3.hip:launch_region) profiling builds
+(E4S_BUILD_ABLATIONS=1) select with env E4S_REGION_VAR = 0..2.  `plain_kernel_ms`: the same contraction with ONE style per sample on the
+plain persistent kernel.  Prints one JSON line per layer and appends them to gpurun_out/bench_region.jsonl
+(profiles/r03f_microbench_region.json collects the round-3 runs)."""
 import json
 import os
 import sys
