@@ -176,28 +176,129 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gra
     p[i] = pv - step_size * (mi / denom);                       // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
-// capturable form (a HIP graph replays the same launch every step): the step count lives in device memory, is advanced by
-// the first kernel and read by the second, which computes the bias corrections in double as the host path does
-__global__ void adam_advance_kernel(int64_t* step) { *step += 1; }
+// capturable form (a HIP graph replays the same launch every step): the step count lives in device memory and the bias corrections are
+// computed from it in double, as the host path does; `lr_dev` (optional) keeps the learning rate in device memory too, so a schedule
+// (coach.py:377-381 multiplies it by 0.1 at step 100000) reaches a captured launch
+__global__ void advance_i64_kernel(int64_t* steps, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) steps[i] += 1;
+}
+
+struct AdamCoef { float step_size, bc2_sqrt, b2, omb1, omb2, eps, wd; };
+
+__device__ __forceinline__ AdamCoef adam_coef(double lr, const double* lr_dev, double beta1, double beta2, float eps, float wd, const int64_t* step) {
+    const double t = (double)*step;
+    if (lr_dev) lr = *lr_dev;
+    AdamCoef c;
+    c.step_size = (float)(lr / (1.0 - pow(beta1, t)));
+    c.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
+    c.b2 = (float)beta2, c.omb1 = (float)(1.0 - beta1), c.omb2 = (float)(1.0 - beta2), c.eps = eps, c.wd = wd;
+    return c;
+}
+
+__device__ __forceinline__ void adam_elem(const AdamCoef& c, float& pv, float g, float& mi, float& vi) {
+    if (c.wd != 0.f) g += c.wd * pv;
+    mi = mi + c.omb1 * (g - mi);                                // exp_avg.lerp_(grad, 1 - beta1)
+    vi = vi * c.b2 + c.omb2 * g * g;                            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(vi) / c.bc2_sqrt + c.eps;
+    pv = pv - c.step_size * (mi / denom);                       // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
 
 __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
-                                float* __restrict__ v, int64_t n, double lr, double beta1, double beta2, float eps, float wd,
-                                const int64_t* __restrict__ step) {
+                                float* __restrict__ v, int64_t n, double lr, const double* __restrict__ lr_dev, double beta1, double beta2,
+                                float eps, float wd, const int64_t* __restrict__ step) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double t = (double)*step;
-    const float step_size = (float)(lr / (1.0 - pow(beta1, t)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
-    const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
-    float g = grad[i];
-    const float pv = p[i];
-    if (wd != 0.f) g += wd * pv;
-    const float mi = m[i] + omb1 * (g - m[i]);
-    const float vi = v[i] * b2 + omb2 * g * g;
+    const AdamCoef c = adam_coef(lr, lr_dev, beta1, beta2, eps, wd, step);
+    float pv = p[i], mi = m[i], vi = v[i];
+    adam_elem(c, pv, grad[i], mi, vi);
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pv - step_size * (mi / denom);
+    p[i] = pv;
+}
+
+// multi-tensor form: up to MT tensors per launch, their pointers BY VALUE in the kernel arguments (no device-side table, no
+// host-to-device copy: the launch is capturable and costs the eager path one launch per 48 tensors instead of two per tensor -- Net3
+// has 344 of them).  Block b owns MT_ELEMS consecutive elements of the tensor whose block range holds b.
+constexpr int MT = 48;
+constexpr int MT_ELEMS = 4096;
+struct AdamChunk {
+    float* p[MT];
+    const float* g[MT];
+    float* m[MT];
+    float* v[MT];
+    const int64_t* step[MT];
+    int64_t n[MT];
+    int blk0[MT + 1];
+};
+struct EmaChunk {
+    float* dst[MT];
+    const float* src[MT];
+    int64_t n[MT];
+    int blk0[MT + 1];
+};
+
+__device__ __forceinline__ int mt_find(const int* blk0, int cnt, int b) {
+    int lo = 0, hi = cnt;                                       // blk0[lo] <= b < blk0[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blk0[mid] <= b) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamChunk c, int cnt, double lr, const double* __restrict__ lr_dev, double beta1,
+                                                         double beta2, float eps, float wd) {
+    const int t = mt_find(c.blk0, cnt, blockIdx.x);
+    const int64_t base = (int64_t)(blockIdx.x - c.blk0[t]) * MT_ELEMS, n = c.n[t];
+    float* __restrict__ p = c.p[t];
+    const float* __restrict__ g = c.g[t];
+    float* __restrict__ m = c.m[t];
+    float* __restrict__ v = c.v[t];
+    const AdamCoef k = adam_coef(lr, lr_dev, beta1, beta2, eps, wd, c.step[t]);
+    const bool al = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+    if (al && base + MT_ELEMS <= n) {
+#pragma unroll
+        for (int j = 0; j < MT_ELEMS / 1024; ++j) {
+            const int64_t i = base + j * 1024 + threadIdx.x * 4;
+            f32x4 pv = *reinterpret_cast<const f32x4*>(p + i), gv = *reinterpret_cast<const f32x4*>(g + i);
+            f32x4 mv = *reinterpret_cast<const f32x4*>(m + i), vv = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) adam_elem(k, pv[e], gv[e], mv[e], vv[e]);
+            *reinterpret_cast<f32x4*>(m + i) = mv;
+            *reinterpret_cast<f32x4*>(v + i) = vv;
+            *reinterpret_cast<f32x4*>(p + i) = pv;
+        }
+        return;
+    }
+    for (int64_t i = base + threadIdx.x; i < min(base + (int64_t)MT_ELEMS, n); i += 256) {
+        float pv = p[i], mi = m[i], vi = v[i];
+        adam_elem(k, pv, g[i], mi, vi);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pv;
+    }
+}
+
+__global__ __launch_bounds__(256) void ema_multi_kernel(const EmaChunk c, int cnt, float decay, float omd) {
+    const int t = mt_find(c.blk0, cnt, blockIdx.x);
+    const int64_t base = (int64_t)(blockIdx.x - c.blk0[t]) * MT_ELEMS, n = c.n[t];
+    float* __restrict__ dst = c.dst[t];
+    const float* __restrict__ src = c.src[t];
+    const bool al = ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0;
+    if (al && base + MT_ELEMS <= n) {
+#pragma unroll
+        for (int j = 0; j < MT_ELEMS / 1024; ++j) {
+            const int64_t i = base + j * 1024 + threadIdx.x * 4;
+            f32x4 d = *reinterpret_cast<const f32x4*>(dst + i);
+            const f32x4 s = *reinterpret_cast<const f32x4*>(src + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = __fmaf_rn(s[e], omd, d[e] * decay);
+            *reinterpret_cast<f32x4*>(dst + i) = d;
+        }
+        return;
+    }
+    for (int64_t i = base + threadIdx.x; i < min(base + (int64_t)MT_ELEMS, n); i += 256) dst[i] = __fmaf_rn(src[i], omd, dst[i] * decay);
 }
 
 // exponential moving average of the weights (src/utils/torch_utils.py:189-194, coach.py:396-398): dst = dst*decay + src*(1-decay),
@@ -335,17 +436,77 @@ extern "C" int e4s_ema_f32(float* dst, const float* src, int64_t n, double decay
     return 0;
 }
 
-extern "C" int e4s_adam_step_dev_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
-                                     double beta2, double eps, double weight_decay, int64_t* step, int advance, void* stream) {
-    if (!step) return (int)hipErrorInvalidValue;
-    hipStream_t st = as_stream(stream);
-    if (advance) {
-        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, step);
-        E4S_CHECK_LAUNCH();
-    }
+extern "C" int e4s_advance_i64(int64_t* steps, int64_t n, void* stream) {
+    if (!steps) return (int)hipErrorInvalidValue;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(adam_dev_kernel, grid1(n), dim3(256), 0, st, p, grad, m, v, n, lr, beta1, beta2, (float)eps,
+    hipLaunchKernelGGL(advance_i64_kernel, grid1(n), dim3(256), 0, as_stream(stream), steps, n);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_adam_step_dev_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, const double* lr_dev, double beta1,
+                                     double beta2, double eps, double weight_decay, const int64_t* step, void* stream) {
+    if (!step) return (int)hipErrorInvalidValue;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(adam_dev_kernel, grid1(n), dim3(256), 0, as_stream(stream), p, grad, m, v, n, lr, lr_dev, beta1, beta2, (float)eps,
                        (float)weight_decay, step);
     E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_adam_multi_dev_f32(int count, float* const* p, const float* const* grad, float* const* m, float* const* v, const int64_t* n,
+                                      const int64_t* const* step, double lr, const double* lr_dev, double beta1, double beta2, double eps,
+                                      double weight_decay, void* stream) {
+    if (count < 0 || (count && (!p || !grad || !m || !v || !n || !step))) return (int)hipErrorInvalidValue;
+    hipStream_t st = as_stream(stream);
+    int i = 0;
+    while (i < count) {
+        AdamChunk c;
+        int cnt = 0;
+        int64_t blocks = 0;
+        c.blk0[0] = 0;
+        while (i < count && cnt < MT) {
+            if (n[i] > 0) {
+                if (!p[i] || !grad[i] || !m[i] || !v[i] || !step[i]) return (int)hipErrorInvalidValue;
+                const int64_t nb = (n[i] + MT_ELEMS - 1) / MT_ELEMS;
+                if (blocks + nb > 0x7fffffff) { if (cnt) break; return (int)hipErrorInvalidValue; }
+                c.p[cnt] = p[i], c.g[cnt] = grad[i], c.m[cnt] = m[i], c.v[cnt] = v[i], c.step[cnt] = step[i], c.n[cnt] = n[i];
+                blocks += nb;
+                c.blk0[++cnt] = (int)blocks;
+            }
+            ++i;
+        }
+        if (!cnt) continue;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, c, cnt, lr, lr_dev, beta1, beta2, (float)eps,
+                           (float)weight_decay);
+        E4S_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int e4s_ema_multi_f32(int count, float* const* dst, const float* const* src, const int64_t* n, double decay, void* stream) {
+    if (count < 0 || (count && (!dst || !src || !n))) return (int)hipErrorInvalidValue;
+    hipStream_t st = as_stream(stream);
+    int i = 0;
+    while (i < count) {
+        EmaChunk c;
+        int cnt = 0;
+        int64_t blocks = 0;
+        c.blk0[0] = 0;
+        while (i < count && cnt < MT) {
+            if (n[i] > 0) {
+                if (!dst[i] || !src[i]) return (int)hipErrorInvalidValue;
+                const int64_t nb = (n[i] + MT_ELEMS - 1) / MT_ELEMS;
+                if (blocks + nb > 0x7fffffff) { if (cnt) break; return (int)hipErrorInvalidValue; }
+                c.dst[cnt] = dst[i], c.src[cnt] = src[i], c.n[cnt] = n[i];
+                blocks += nb;
+                c.blk0[++cnt] = (int)blocks;
+            }
+            ++i;
+        }
+        if (!cnt) continue;
+        hipLaunchKernelGGL(ema_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, c, cnt, (float)decay, (float)(1.0 - decay));
+        E4S_CHECK_LAUNCH();
+    }
     return 0;
 }

@@ -706,12 +706,59 @@ def adam_step(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step):
          float(eps), float(weight_decay), int(step), stream())
 
 
-def adam_step_dev(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step, advance):
-    """adam_step with the step count in a device int64[1] tensor (capturable in a HIP graph); advance: increment it first."""
+def _ptr_array(tensors, dtype=torch.float32):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError(f"multi-tensor call: contiguous {dtype} ROCm tensors expected")
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def advance_steps(steps):
+    """steps (device int64, any shape) += 1 in one launch."""
+    if steps.dtype != torch.int64 or not steps.is_cuda:
+        raise RuntimeError("advance_steps: device int64 tensor")
+    call("e4s_advance_i64", ptr(steps), steps.numel(), stream())
+
+
+def adam_step_dev(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step, lr_dev=None):
+    """adam_step with the step count (already advanced: the step being taken) in a device int64[1] tensor and, optionally, the
+    learning rate in a device float64[1] tensor: capturable in a HIP graph."""
     if step.dtype != torch.int64 or not step.is_cuda:
         raise RuntimeError("adam_step_dev: step must be a device int64 tensor")
-    call("e4s_adam_step_dev_f32", fptr(p), fptr(_f32(grad)), fptr(m), fptr(v), p.numel(), float(lr), float(beta1),
-         float(beta2), float(eps), float(weight_decay), ptr(step), 1 if advance else 0, stream())
+    if lr_dev is not None and (lr_dev.dtype != torch.float64 or not lr_dev.is_cuda):
+        raise RuntimeError("adam_step_dev: lr_dev must be a device float64 tensor")
+    call("e4s_adam_step_dev_f32", fptr(p), fptr(_f32(grad)), fptr(m), fptr(v), p.numel(), float(lr), ptr(lr_dev), float(beta1),
+         float(beta2), float(eps), float(weight_decay), ptr(step), stream())
+
+
+def adam_multi_dev(ps, grads, ms, vs, steps, lr, beta1, beta2, eps, weight_decay, lr_dev=None):
+    """adam_step_dev for lists of tensors: ceil(len / 48) launches (pointers travel in the kernel arguments)."""
+    n = len(ps)
+    if not (n == len(grads) == len(ms) == len(vs) == len(steps)):
+        raise RuntimeError("adam_multi_dev: list lengths differ")
+    if lr_dev is not None and (lr_dev.dtype != torch.float64 or not lr_dev.is_cuda):
+        raise RuntimeError("adam_multi_dev: lr_dev must be a device float64 tensor")
+    for p, g in zip(ps, grads):
+        if g.shape != p.shape:
+            raise RuntimeError("adam_multi_dev: gradient shape differs from its parameter's")
+    sizes = (ctypes.c_int64 * n)(*[p.numel() for p in ps])
+    call("e4s_adam_multi_dev_f32", n, _ptr_array(ps), _ptr_array(grads), _ptr_array(ms), _ptr_array(vs), sizes,
+         _ptr_array(steps, torch.int64), float(lr), ptr(lr_dev), float(beta1), float(beta2), float(eps), float(weight_decay), stream())
+
+
+def ema_multi_(dsts, srcs, decay):
+    """dst <- dst * decay + src * (1 - decay) for lists of tensors: ceil(len / 48) launches; version counters advance."""
+    n = len(dsts)
+    if n != len(srcs):
+        raise RuntimeError("ema_multi_: list lengths differ")
+    for d, s_ in zip(dsts, srcs):
+        if d.shape != s_.shape:
+            raise RuntimeError("ema_multi_: shapes differ")
+    sizes = (ctypes.c_int64 * n)(*[d.numel() for d in dsts])
+    call("e4s_ema_multi_f32", n, _ptr_array(dsts), _ptr_array(srcs), sizes, float(decay), stream())
+    torch.autograd.graph.increment_version(dsts)         # raw-pointer writes: keep (data_ptr, _version) pack keys honest
 
 
 def ema_(dst, src, decay):

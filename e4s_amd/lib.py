@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe4s_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -113,7 +113,10 @@ SIGNATURES = {
     "e4s_torgb_finish_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_rowdot_multi_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_ema_f32": [c_p, c_p, c_l, c_d, c_p],
-    "e4s_adam_step_dev_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_p, c_i, c_p],
+    "e4s_adam_step_dev_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_p, c_d, c_d, c_d, c_d, c_p, c_p],
+    "e4s_advance_i64": [c_p, c_l, c_p],
+    "e4s_adam_multi_dev_f32": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_d, c_d, c_d, c_d, c_p],
+    "e4s_ema_multi_f32": [c_i, c_p, c_p, c_p, c_d, c_p],
     "e4s_torgb_bwd_x_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_shift_scale_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p],
     "e4s_torgb_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p],

@@ -1,9 +1,15 @@
 """Fused optimiser step for the latent-optimisation loop (scripts/optimization.py:125-161 builds torch.optim.Adam over the
-[1,12,1280] style vectors; SURVEY.md 8(f) N1 'Adam step fusion').  Same hyper-parameters and state as torch.optim.Adam
-(no amsgrad); each parameter is updated by ONE kernel (e4s_adam_step_f32) instead of ~10 elementwise launches.
-`capturable=True` keeps the step count on the device (e4s_adam_step_dev_f32), so the whole optimisation step -- forward,
-backward and update -- can be captured in a HIP graph (`GraphedStep`) and replayed.  Measured at 1024^2: 11.6 ms replayed vs
-11.9 ms eager on the l2-only step, 20.4 vs ~25 ms with the LPIPS and identity terms."""
+[1,12,1280] style vectors; SURVEY.md 8(f) N1 'Adam step fusion') and the joint train step (coach.py:119-150).  Same
+hyper-parameters and state as torch.optim.Adam (no amsgrad).
+
+* default: each parameter is updated by ONE kernel (e4s_adam_step_f32) instead of ~10 elementwise launches; step counts are host ints.
+* `capturable=True`: nothing step-dependent is computed on the host, so the whole optimisation step -- forward, backward and update -- can
+  be captured in a HIP graph (`GraphedStep`) and replayed.  The step counts of a parameter group live in ONE flat device int64 tensor
+  (`state[p]["step"]` is a one-element view of it, so `state_dict()` round-trips per parameter as torch's capturable Adam does) advanced by
+  one launch per group; the learning rate lives in a device float64 (`sync_hyper()` uploads `group["lr"]` when it changed: coach.py:377-381's
+  schedule reaches a captured graph); the updates of ALL parameters go out as multi-tensor launches (e4s_adam_multi_dev_f32, 48 tensors
+  per launch with their pointers in the kernel arguments): Net3's 344 tensors are 1 + 8 launches per step, not 688.
+Measured at 1024^2: 11.6 ms replayed vs 11.9 ms eager on the l2-only step, 20.4 vs ~25 ms with the LPIPS and identity terms."""
 import torch
 
 from . import kernels as K
@@ -14,8 +20,66 @@ class FusedAdam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self.capturable = capturable      # step counts live in state[p]["step"] as device int64[1] tensors (as torch's
-                                          # capturable Adam keeps them): per parameter, and part of state_dict()
+        self.capturable = capturable
+        self._dev = {}                    # group index -> {"lr": device f64[1], "lr_host": float, "hyper": tuple, "flat": int64 [n] | None}
+
+    # ---- capturable plumbing ----------------------------------------------------------------------------------------
+    def _group_dev(self, gi, group, device):
+        d = self._dev.get(gi)
+        if d is None or d["lr"].device != device:
+            d = {"lr": torch.full((1,), float(group["lr"]), device=device, dtype=torch.float64), "lr_host": float(group["lr"]),
+                 "hyper": None, "flat": None}
+            self._dev[gi] = d
+        return d
+
+    def sync_hyper(self):
+        """Upload every group's learning rate if it changed on the host (one fill launch per changed group; call it OUTSIDE a capture --
+        GraphedStep.step() does).  betas / eps / weight_decay travel by value in the launches: a captured graph keeps the values it was
+        captured with, so changing them under a GraphedStep raises instead of being silently ignored."""
+        for gi, group in enumerate(self.param_groups):
+            d = self._dev.get(gi)
+            if d is None:
+                continue
+            if float(group["lr"]) != d["lr_host"]:
+                d["lr"].fill_(float(group["lr"]))
+                d["lr_host"] = float(group["lr"])
+            hyper = (tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"]))
+            if d["hyper"] is not None and d["hyper"] != hyper:
+                raise RuntimeError("FusedAdam: betas / eps / weight_decay changed after a step was captured; re-capture the GraphedStep")
+
+    def _flat_steps(self, d, plist, device):
+        """One int64 tensor holding the step counts of `plist` (state[p]['step'] are views of it).  Re-packed when the state was
+        loaded from a checkpoint (separate tensors / host ints) or the set of parameters with state changed."""
+        flat = d["flat"]
+        ok = flat is not None and flat.numel() == len(plist)
+        if ok:
+            base = flat.data_ptr()
+            for i, p in enumerate(plist):
+                st = self.state[p].get("step")
+                if not torch.is_tensor(st) or st.data_ptr() != base + 8 * i:
+                    ok = False
+                    break
+        if not ok:
+            vals = []
+            for p in plist:
+                st = self.state[p].get("step", 0)
+                vals.append(st.reshape(1).to(device=device, dtype=torch.int64) if torch.is_tensor(st)
+                            else torch.full((1,), int(st), device=device, dtype=torch.int64))
+            flat = torch.cat(vals) if vals else torch.zeros(0, device=device, dtype=torch.int64)
+            for i, p in enumerate(plist):
+                self.state[p]["step"] = flat[i:i + 1]
+            d["flat"] = flat
+        return flat
+
+    def written_tensors(self):
+        """Every tensor step() writes through raw pointers (GraphedStep advances their version counters after a replay)."""
+        return [p for g in self.param_groups for p in g["params"] if p in self.state]
+
+    def _check(self, p):
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            raise RuntimeError("FusedAdam handles contiguous fp32 parameters")
+        if p.grad.is_sparse or p.grad.device != p.device or p.grad.dtype != torch.float32:
+            raise RuntimeError("FusedAdam needs a dense fp32 gradient on the parameter's device")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -23,27 +87,40 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise RuntimeError("FusedAdam handles contiguous fp32 parameters")
-                if p.grad.is_sparse or p.grad.device != p.device or p.grad.dtype != torch.float32:
-                    raise RuntimeError("FusedAdam needs a dense fp32 gradient on the parameter's device")
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
+                continue
+            for p in live:
+                self._check(p)
                 st = self.state[p]
-                if not st:
-                    st["step"] = torch.zeros(1, device=p.device, dtype=torch.int64) if self.capturable else 0
+                if "exp_avg" not in st:
+                    st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
-                if self.capturable:
-                    if not torch.is_tensor(st["step"]):         # state loaded from a non-capturable optimiser
-                        st["step"] = torch.full((1,), int(st["step"]), device=p.device, dtype=torch.int64)
-                    K.adam_step_dev(p, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
-                                    group["weight_decay"], st["step"], True)
-                    torch.autograd.graph.increment_version(p)
-                    continue
+            if self.capturable:
+                dev = live[0].device
+                d = self._group_dev(gi, group, dev)
+                capturing = torch.cuda.is_current_stream_capturing()
+                if not capturing:
+                    self.sync_hyper()
+                d["hyper"] = (tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"]))
+                with_state = [p for p in group["params"] if p in self.state and "exp_avg" in self.state[p]]
+                flat = self._flat_steps(d, with_state, dev)
+                if len(live) == len(with_state):
+                    K.advance_steps(flat)                        # one launch for the whole group
+                else:                                            # some parameters have no gradient this step: theirs do not advance
+                    for p in live:
+                        K.advance_steps(self.state[p]["step"])
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in live]
+                K.adam_multi_dev(live, grads, [self.state[p]["exp_avg"] for p in live], [self.state[p]["exp_avg_sq"] for p in live],
+                                 [self.state[p]["step"] for p in live], group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                                 lr_dev=d["lr"])
+                torch.autograd.graph.increment_version(live)
+                continue
+            for p in live:
+                st = self.state[p]
                 if torch.is_tensor(st["step"]):                 # state loaded from a capturable optimiser (one sync, once)
                     st["step"] = int(st["step"].item())
                 st["step"] += 1
@@ -60,9 +137,14 @@ class GraphedStep:
     optimiser and returns the loss tensor; it must be free of host synchronisation and read its inputs from tensors whose
     storage does not change between steps (update them in place).  The constructor runs `warmup` REAL steps eagerly on a side
     stream (they count as optimisation steps), then captures one more without executing it; `step()` replays it and returns
-    the (static) loss tensor."""
+    the (static) loss tensor.
 
-    def __init__(self, opt, body, warmup=2):
+    `also_written`: tensors other than the optimiser's parameters that the captured body writes through raw pointers (the EMA copy
+    of the weights).  A replay changes them without passing through torch, so step() advances the version counter of every written
+    tensor afterwards -- the weight packs of eager consumers (a D step between two replays, an evaluation of net_ema) are keyed on
+    (data_ptr, _version) and would otherwise keep serving the weights of the capture."""
+
+    def __init__(self, opt, body, warmup=2, also_written=(), capture_error_mode=None):
         if not getattr(opt, "capturable", False):
             raise RuntimeError("GraphedStep needs FusedAdam(capturable=True): the host-side step count cannot be replayed")
         self.opt = opt
@@ -78,14 +160,20 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         flags = torch.zeros(1, device=opt.param_groups[0]["params"][0].device, dtype=torch.int32)
         opt.zero_grad(set_to_none=True)
+        if capture_error_mode is None:       # a live process group's watchdog thread polls events: "global" would fail the capture
+            import torch.distributed as dist
+            capture_error_mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
         with K.flag_sink(flags):                                # this thread's mask checks accumulate here instead of syncing
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
                 self.loss = body()
         self.flags = flags
+        self._written = list(opt.written_tensors()) + list(also_written)
 
     def step(self):
+        self.opt.sync_hyper()                                   # a changed group["lr"] reaches the replay through device memory
         self.graph.replay()
         self.steps_done += 1
+        torch.autograd.graph.increment_version(self._written)
         return self.loss
 
     def validate(self):

@@ -26,13 +26,20 @@ def requires_grad(model, flag=True):
         p.requires_grad = flag
 
 
+EMA_DECAY = 0.5 ** (32 / (100 * 1000))      # coach.py:29 `ACCUM` = 0.99977822... (its inline comment "0.9977..." drops a digit)
+
+
 def accumulate(model1, model2, decay=0.999):
-    """torch_utils.accumulate (src/utils/torch_utils.py:189-194): EMA of model2's parameters into model1, one native launch per
-    tensor; version counters advance (kernels.ema_), so cached weight packs of model1 are rebuilt on next use."""
+    """torch_utils.accumulate (src/utils/torch_utils.py:189-194; same default decay): EMA of model2's parameters into model1 as
+    multi-tensor launches (48 tensors each); version counters advance (kernels.ema_multi_), so cached weight packs of model1 are
+    rebuilt on next use."""
     p2 = dict(model2.named_parameters())
+    dst, src = [], []
+    for k, p in model1.named_parameters():
+        dst.append(p.detach())
+        src.append(p2[k].detach().contiguous())
     with torch.no_grad():
-        for k, p in model1.named_parameters():
-            K.ema_(p, p2[k].detach(), decay)
+        K.ema_multi_(dst, src, decay)
 
 
 def adv_g_loss(fake_pred):
@@ -65,9 +72,9 @@ class LossOpts:
 class TrainIteration:
     """net: Net3 in train mode; disc: Discriminator or None (train_D False); crit: dict with optional 'lpips', 'id', 'parsing'
     (e4s_amd.criteria modules); opt / opt_d: optimisers over net's / disc's trainable parameters; averager / averager_d:
-    ddp.GradAverager (N > 1) or None; net_ema: EMA copy of net or None."""
+    ddp.GradAverager (N > 1) or None; net_ema: EMA copy of net or None; ema_decay: coach.py:29's ACCUM by default."""
 
-    def __init__(self, net, disc, crit, opt, opt_d, lo=None, averager=None, averager_d=None, net_ema=None, ema_decay=0.999):
+    def __init__(self, net, disc, crit, opt, opt_d, lo=None, averager=None, averager_d=None, net_ema=None, ema_decay=EMA_DECAY):
         self.net, self.disc, self.crit, self.opt, self.opt_d = net, disc, crit, opt, opt_d
         self.lo = lo or LossOpts()
         self.averager, self.averager_d, self.net_ema, self.ema_decay = averager, averager_d, net_ema, ema_decay

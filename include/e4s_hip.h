@@ -365,11 +365,20 @@ int64_t e4s_scale_dot_ws_floats(int B, int64_t hw, int C);
  * bias corrections are evaluated in double on the host as torch does */
 int e4s_adam_step_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                       double eps, double weight_decay, int step, void* stream);
-/* the same update with the step count in DEVICE memory (int64, advanced by this call when `advance`): nothing step-dependent
- * is computed on the host, so the launch can be captured in a HIP graph and replayed (one `step` per optimiser, advanced by
- * the first parameter's call) */
-int e4s_adam_step_dev_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
-                          double eps, double weight_decay, int64_t* step, int advance, void* stream);
+/* the same update with the step count in DEVICE memory (int64, >= 1 = the step being taken): nothing step-dependent is computed on the
+ * host, so the launch can be captured in a HIP graph and replayed.  lr_dev: optional DEVICE double that overrides `lr` (a learning-rate
+ * schedule -- coach.py:377-381 -- then reaches captured launches).  The caller advances the counts first (e4s_advance_i64: one launch
+ * for all the counts of a parameter group, kept in one flat tensor) */
+int e4s_adam_step_dev_f32(float* p, const float* grad, float* m, float* v, int64_t n, double lr, const double* lr_dev, double beta1,
+                          double beta2, double eps, double weight_decay, const int64_t* step, void* stream);
+int e4s_advance_i64(int64_t* steps, int64_t n, void* stream);
+/* multi-tensor forms: `count` tensors given as HOST arrays of device pointers / element counts.  The library hands them to the kernels
+ * BY VALUE, 48 tensors per launch (no device-side table, no host-to-device copy: capturable): Net3's 344 parameter tensors are 8
+ * launches instead of 344.  Arithmetic per element identical to the single-tensor entry points (bit for bit). */
+int e4s_adam_multi_dev_f32(int count, float* const* p, const float* const* grad, float* const* m, float* const* v, const int64_t* n,
+                           const int64_t* const* step, double lr, const double* lr_dev, double beta1, double beta2, double eps,
+                           double weight_decay, void* stream);
+int e4s_ema_multi_f32(int count, float* const* dst, const float* const* src, const int64_t* n, double decay, void* stream);
 /* Exact up-sampling StyledConv on the split-bf16 matrix-core path (csrc/upconv_bf16x3.hip): conv_transpose2d(stride 2) +
  * Blur (src/models/stylegan2/model.py:287-300, 206-213) + NoiseInjection + FusedLeakyReLU (:396-404) in one kernel, one style
  * per sample (unmasked layers, model.py:655-657); Cin % 32 == 0, Cout % 32 == 0.
