@@ -415,7 +415,11 @@ def main():
         dev = torch.device("cuda", dev_index)
         sync = torch.cuda.synchronize
     dist = None
-    if world > 1:
+    from e4s_amd import shard
+    # E4S_FORCE_COLLECTIVES=1 with WORLD_SIZE=1 (torchrun --nproc-per-node 1): the N>1 code path -- RCCL init, the overlapped uint8
+    # all-gather, barrier, MAX all-reduce of the time -- runs on one GPU (collectives of one rank; the line says so in `config`)
+    multi = world > 1 or (shard._FORCE and "RANK" in os.environ)
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -451,8 +455,6 @@ def main():
         print(json.dumps(dict(config3_legs(net, one, args), steps=args.opt_steps)))
         return
 
-    from e4s_amd import shard
-
     graphed = None
     if stub:
         swap = lambda d, dm, t, tm, sm, noise: 0.5 * d + 0.25 * t          # any deterministic function of the rank's shard
@@ -474,20 +476,20 @@ def main():
         pack = postproc.tensor2im
     if args.gather_fp32:
         pack = None
-    overlap = shard.OverlappedGather(world * B, pack=pack) if (world > 1 and not args.sync_gather) else None
+    overlap = shard.OverlappedGather(world * B, pack=pack) if (multi and not args.sync_gather) else None
 
     def step():
         img = swap(*inputs[:5], noise=inputs[5])
         if overlap is not None:
             overlap.submit(img)                       # step i's gather runs under step i+1's compute
-        elif world > 1:                               # RCCL all_gather_into_tensor of the rank's shard
+        elif multi:                                   # RCCL all_gather_into_tensor of the rank's shard
             shard.gather_outputs(img if pack is None else pack(img), world * B)
         return img
 
     def fence():
         if overlap is not None:
             overlap.drain()                           # every submitted gather completes inside the timed region
-        if world > 1:
+        if multi:
             dist.barrier()
         sync()
 
@@ -501,7 +503,7 @@ def main():
     dt = time.perf_counter() - t0
     if graphed is not None:
         graphed.validate()                            # the one-hot precondition of the replayed graph (one sync, untimed)
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -522,7 +524,7 @@ def main():
                                     }[K.PRECISION], "parallelism": f"image-parallel x{world}" + (
                           (", RCCL all_gather of the " + ("fp32 [B,3,H,W]" if args.gather_fp32 else "uint8 [B,H,W,3]")
                            + " outputs" + ("" if args.sync_gather else " overlapped with the next step"))
-                          if world > 1 else "")}}
+                          if multi else "") + (" [forced collectives on a world of one rank]" if multi and world == 1 else "")}}
     if stub:
         # what the plumbing test asserts: the last step's gathered uint8 batch holds rank r's shard at rows [r*B, (r+1)*B)
         gathered = overlap.drain() if overlap is not None else (
@@ -595,7 +597,7 @@ def main():
             out["parity_b1_max_abs_vs_oracle"] = err[1]       # the batch-1 latency run
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -264,7 +264,11 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamChunk c, int 
             f32x4 pv = *reinterpret_cast<const f32x4*>(p + i), gv = *reinterpret_cast<const f32x4*>(g + i);
             f32x4 mv = *reinterpret_cast<const f32x4*>(m + i), vv = *reinterpret_cast<const f32x4*>(v + i);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) adam_elem(k, pv[e], gv[e], mv[e], vv[e]);
+            for (int e = 0; e < 4; ++e) {
+                float pe = pv[e], me = mv[e], ve = vv[e];
+                adam_elem(k, pe, gv[e], me, ve);
+                pv[e] = pe, mv[e] = me, vv[e] = ve;
+            }
             *reinterpret_cast<f32x4*>(m + i) = mv;
             *reinterpret_cast<f32x4*>(v + i) = vv;
             *reinterpret_cast<f32x4*>(p + i) = pv;

@@ -13,7 +13,20 @@ Overlap with the backward (VERDICT r2 #1d): a bucket's all-reduce is launched th
     24 units in reverse), so the encoder's buckets leave while the earlier units are still being differentiated.
 `arm()` before `loss.backward()`, `finish()` after it: finish() launches whatever has not fired (parameters without a gradient
 count as zeros), waits, divides by the world size and writes the averaged gradients back.  `average()` is the non-overlapped
-form (everything after backward); both give bit-identical results (same buffers, same collectives, same order)."""
+form (everything after backward); both give bit-identical results (same buffers, same collectives, same order).
+
+Collectives are issued in BUCKET-INDEX order on every rank, whatever order the gradients arrive in: a bucket that fills early
+waits (host side) for its predecessors, exactly as torch DDP orders its buckets -- ranks whose autograd engines finish parameters
+in different orders, or where one rank gets no gradient for a parameter, still issue the same sequence of same-sized collectives.
+
+Everything here is capturable: inside a HIP graph capture (train.TrainIteration.graphed_g_step) the staging copies, the RCCL
+all-reduces (on RCCL's stream, forked from and joined to the capturing stream by the events `Work.wait()` records), the division and
+the write-back become graph nodes, and a replay runs the whole data-parallel G step without touching the host.
+
+`force=True` keeps the collectives on a world of ONE rank (they are no-ops numerically): the RCCL path -- communicator
+init, all_reduce, stream fork/join, capture -- then runs on a single GPU (tests/test_gpu_nccl_world1.py)."""
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -28,10 +41,14 @@ def notify_grad(param, grad):
 
 
 class GradAverager:
-    def __init__(self, params, group=None, bucket_mb=64):
+    def __init__(self, params, group=None, bucket_mb=64, force=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if force is None:
+            from . import shard
+            force = shard._FORCE                         # E4S_FORCE_COLLECTIVES=1
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
         cap = int(bucket_mb * (1 << 20) // 4)
         self.buckets, cur, n = [], [], 0
         for p in reversed(self.params):                  # backward finishes the LAST layers first
@@ -51,10 +68,15 @@ class GradAverager:
                 o += p.numel()
         self._armed = False
         self._sent, self._ready, self._works = set(), [0] * len(self.buckets), [None] * len(self.buckets)
+        self._next = 0                                   # buckets [0, _next) have been launched (index order on every rank)
         self.fired_during_backward = 0                   # diagnostics: buckets launched before finish()
-        if self.world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
-            for p in self.params:
-                p.register_post_accumulate_grad_hook(self._hook)
+        if self.active:
+            if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+                for p in self.params:
+                    p.register_post_accumulate_grad_hook(self._hook)
+            else:
+                warnings.warn("GradAverager: this torch has no register_post_accumulate_grad_hook; only gradients announced through "
+                              "ddp.notify_grad overlap with the backward, the rest are reduced in finish()")
 
     # ---- plumbing ---------------------------------------------------------------------------------------------------
     def _buffer(self, i):
@@ -73,7 +95,7 @@ class GradAverager:
 
     def notify(self, p, grad):
         """`grad` is the complete gradient of `p` for this backward: stage it, and launch the bucket when it is full."""
-        if not self._armed or self.world == 1:
+        if not self._armed or not self.active:
             return
         key = id(p)
         if key not in self._where:
@@ -85,24 +107,26 @@ class GradAverager:
             self._buffer(i)[o:o + p.numel()].copy_(grad.detach().reshape(-1))
         self._sent.add(key)
         self._ready[i] += 1
-        if self._ready[i] == len(self.buckets[i]):
-            self._fire(i)
+        while self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next]):
+            self._fire(self._next)                       # strictly in index order: a later bucket that filled first waits here
+            self._next += 1
             self.fired_during_backward += 1
 
     # ---- API --------------------------------------------------------------------------------------------------------
     def arm(self):
         global _ACTIVE
-        if self.world == 1:
+        if not self.active:
             return
         self._armed = True
         self._sent, self._ready, self._works = set(), [0] * len(self.buckets), [None] * len(self.buckets)
+        self._next = 0
         self.fired_during_backward = 0
         _ACTIVE = self
 
     def finish(self):
         """grad <- mean over ranks of grad, for every parameter (a missing grad counts as zeros on that rank)."""
         global _ACTIVE
-        if self.world == 1:
+        if not self.active:
             return
         if _ACTIVE is self:
             _ACTIVE = None
@@ -121,6 +145,7 @@ class GradAverager:
                     else:
                         flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
                 self._fire(i)
+            self._next = len(self.buckets)
             for i, bucket in enumerate(self.buckets):
                 self._works[i].wait()
                 flat = self._flat[i]
@@ -136,8 +161,9 @@ class GradAverager:
 
     def average(self):
         """Non-overlapped form: everything after backward() has finished."""
-        if self.world == 1:
+        if not self.active:
             return
         self._armed = False
         self._sent, self._ready, self._works = set(), [0] * len(self.buckets), [None] * len(self.buckets)
+        self._next = 0
         self.finish()

@@ -5,9 +5,31 @@ contiguous slice of the batch with no exchange, and the only collective is one a
 [B/N, 3, H, W] outputs (RCCL over xGMI; `torch.distributed` backend "nccl" on ROCm).  The reference has
 no counterpart (its only collective is DDP's gradient all-reduce, src/training/coach.py:46-85).
 One process per GPU; on CPU the same code runs over gloo (tests/test_shard_gloo.py).
+
+E4S_FORCE_COLLECTIVES=1 (or `force_collectives(True)`): a world of ONE rank normally skips every collective; with the switch on
+and a process group initialised, the all-gathers (and ddp.GradAverager's all-reduces) are issued anyway -- numerically no-ops, but
+the whole RCCL path (communicator init with device_id, all_gather_into_tensor, asynchronous work on RCCL's stream, stream capture
+in thread_local mode) then executes on the one GPU that is reachable here: tests/test_gpu_nccl_world1.py,
+`E4S_FORCE_COLLECTIVES=1 torchrun --nproc-per-node 1 bench.py --gpus 1`.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+_FORCE = os.environ.get("E4S_FORCE_COLLECTIVES", "0") == "1"
+
+
+def force_collectives(flag=True):
+    global _FORCE
+    _FORCE = bool(flag)
+
+
+def collectives_active(group=None):
+    """True when collectives must be issued: more than one rank, or one rank with the force switch on."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or _FORCE
 
 
 def shard_range(n, world, rank):
@@ -38,7 +60,7 @@ def shard_batch(tensors, world, rank):
 def gather_outputs(local, n_total, group=None):
     """All-gather ragged shards [b_r, ...] into [n_total, ...] in rank order (every rank gets the result)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not collectives_active(group):
         return local
     rank = dist.get_rank(group)
     base, extra = divmod(n_total, world)
@@ -74,6 +96,7 @@ class OverlappedGather:
         ends with (scripts/face_swap.py:276, torch_utils.tensor2im): the collective then moves a quarter of the bytes
         and the fp32 -> staging copy disappears (the pack kernel IS the copy)."""
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = collectives_active(group)
         if n_total % self.world:
             raise ValueError("OverlappedGather needs equal shards (use gather_outputs for ragged batches)")
         self.n_total, self.group, self.depth, self.pack = n_total, group, depth, pack
@@ -81,7 +104,7 @@ class OverlappedGather:
         self.i = 0
 
     def submit(self, local):
-        if self.world == 1:
+        if not self.active:
             self.out[0] = self.pack(local) if self.pack is not None else local
             return
         k = self.i % self.depth
@@ -102,7 +125,7 @@ class OverlappedGather:
         self.i += 1
 
     def drain(self):
-        if self.world == 1:
+        if not self.active:
             return self.out[0]
         for w in self.work:
             if w is not None:

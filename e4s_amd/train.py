@@ -165,16 +165,22 @@ class TrainIteration:
                 c._target = None
 
     def graphed_g_step(self, img, onehot, warmup=2, **fwd):
-        """The G step (forward, every loss term incl. the target features, backward, fused Adam, EMA) captured as ONE HIP graph:
-        returns an optim.GraphedStep; `.step()` replays it on whatever `img` / `onehot` hold then (static buffers, refilled in
-        place).  Needs FusedAdam(capturable=True) and a single process (bucket all-reduces are not captured).  The eager G step is
-        ~2 500 launches, host-bound: 65-92 ms per step depending on the host against ~55 ms of kernel time.  Every weight pack the
-        step reads from a TRAINED network is rebuilt inside the graph (the net's are stale at capture time -- the warm-up steps just
-        updated them --, D's are invalidated here), so replays between eager D steps see the current weights."""
+        """The G step (forward, every loss term incl. the target features, backward, [bucketed gradient all-reduces,] fused Adam, EMA)
+        captured as ONE HIP graph: returns an optim.GraphedStep; `.step()` replays it on whatever `img` / `onehot` hold then (static
+        buffers, refilled in place).  Needs FusedAdam(capturable=True).  With a ddp.GradAverager the RCCL all-reduces are captured with
+        the rest (coach.py:74-85,340-357: DDP's bucket all-reduces overlapped with the backward): they sit on RCCL's own stream in the
+        graph, forked where a bucket fills and joined before the write-back, so a replay overlaps them with the remaining backward
+        exactly as the eager step does.  The eager G step is ~2 500 launches, host-bound: 65-97 ms per step depending on the host
+        against ~55 ms of kernel time.  Every weight pack the step reads from a TRAINED network is rebuilt inside the graph (the net's are
+        stale at capture time -- the warm-up steps just updated them --, D's are invalidated here); after a replay the version counters
+        of everything the graph wrote (parameters, EMA copy) are advanced, so eager consumers between replays (D steps, net_ema
+        evaluation) re-pack from the current weights."""
         from .optim import GraphedStep
         from . import disc_autograd
-        if self.averager is not None:
-            raise RuntimeError("graphed_g_step: single-process only (gradient averaging is launched from host-side hooks)")
+        gen = getattr(self.net, "G", None)
+        if gen is not None and any(p.requires_grad for p in gen.parameters()):
+            raise RuntimeError("graphed_g_step: a trainable generator (train_G) rebuilds its style-prologue job tables with a host-to-"
+                               "device copy whenever its weights change, which a stream capture cannot hold; use g_step()")
 
         def body():
             self.forget_targets()
@@ -182,7 +188,8 @@ class TrainIteration:
                 disc_autograd.invalidate_packs(self.disc)
             loss, _ = self.g_step(img, onehot, **fwd)
             return loss
-        return GraphedStep(self.opt, body, warmup=warmup)
+        ema = [p.detach() for p in self.net_ema.parameters()] if self.net_ema is not None else []
+        return GraphedStep(self.opt, body, warmup=warmup, also_written=ema)
 
     def iteration(self, img, onehot, batch_idx=0, **fwd):
         """One pass of the loop body at self.global_step (coach.py:281-398)."""

@@ -1,0 +1,46 @@
+"""RCCL on the one GPU that is reachable (VERDICT r3 'missing' 1-2, 'next' 5): a world of ONE rank on backend "nccl" with the
+collectives forced on, in subprocesses -- (a) tests/nccl_world1_worker.py: gather / overlapped gather / a face-swap graph captured
+under a live process group / eager and GRAPH-CAPTURED data-parallel G steps (bucket all-reduces inside the HIP graph), each equal
+bit for bit to the collective-free computation; (b) bench.py's own main() launched the way the driver launches N ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(port):
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", E4S_FORCE_COLLECTIVES="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def test_world1_nccl_collectives_gather_and_graph_captured_ddp_step():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_world1_worker.py")], env=_env(29541), cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("NCCL_WORLD1 ")][-1]
+    res = json.loads(line[len("NCCL_WORLD1 "):])
+    print(res)
+    assert res["backend"] == "nccl"
+    for key in ("gather_outputs_equal", "overlapped_gather_equal", "overlapped_gather_works_were_real", "graphed_swap_equal_eager",
+                "graphed_swap_gather_equal", "averager_active", "eager_averaged_step_equal", "graphed_averaged_step_equal"):
+        assert res[key] is True, (key, res)
+    assert res["buckets_fired_during_backward"] >= 1, res          # at least one all-reduce left while the backward was still running
+
+
+def test_world1_nccl_bench_main_runs_the_multi_rank_path():
+    """bench.py under the driver's launch protocol (RANK / WORLD_SIZE / MASTER_* in the environment) with one rank and forced
+    collectives: init_process_group('nccl', device_id=...), GraphedFaceSwap captured in thread_local mode, OverlappedGather of the uint8
+    images on RCCL's stream, barrier, MAX all-reduce of the time, the JSON line."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--steps-only"],
+                       env=_env(29543), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 50 and "forced collectives" in line["config"]["parallelism"], line
+    assert "RCCL all_gather of the uint8" in line["config"]["parallelism"]

@@ -61,6 +61,116 @@ def test_fused_adam_matches_torch_adam():
         assert float((a.detach().cpu() - p0).abs().max()) > 1e-2                      # it really moved
 
 
+def test_multi_tensor_capturable_adam_and_ema_vs_torch():
+    """FusedAdam(capturable=True): one step-advance launch per group + multi-tensor updates (48 tensors per launch, pointers in the
+    kernel arguments) on 120 tensors of awkward sizes (1 element, not a multiple of 4, exactly / just over one 4096-element block, a
+    view at an odd offset) == torch.optim.Adam; a parameter that gets no gradient in a step does not advance; the learning rate is
+    read from device memory (a changed group['lr'] acts on the next step); state_dict round trip; the multi-tensor EMA ==
+    `p.mul_(decay).add_(q, alpha=1-decay)` bit for bit."""
+    import copy
+    from e4s_amd import kernels as K
+    from e4s_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(11)
+    sizes = [1, 3, 4, 5, 255, 1023, 4095, 4096, 4097, 8192 + 7, 70001] + [17 + 13 * i for i in range(108)]
+    vals = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    odd = torch.zeros(8, device=DEV)
+    odd[1:6] = vals[3]                              # parameter 3 lives 4 bytes into an allocation: the unaligned (scalar) path
+    a = [v.clone().requires_grad_(True) for v in vals]
+    a[3] = odd[1:6].detach().requires_grad_(True)
+    assert a[3].data_ptr() % 16 == 4
+    b = [v.clone().requires_grad_(True) for v in vals]
+    oa = FusedAdam(a, lr=1e-2, weight_decay=0.01, capturable=True)
+    ob = torch.optim.Adam(b, lr=1e-2, weight_decay=0.01)
+    for step in range(5):
+        if step == 3:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 1e-3
+        for i, (pa, pb) in enumerate(zip(a, b)):
+            gr = torch.randn(pa.shape, generator=g).to(DEV) * (0.1 + step)
+            if step == 2 and i == 7:
+                pa.grad = pb.grad = None            # no gradient this step: skipped, its step count stays
+                continue
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for i, (pa, pb) in enumerate(zip(a, b)):
+        assert maxabs(pa, pb) < 3e-6, (i, sizes[i], maxabs(pa, pb))
+        assert int(oa.state[pa]["step"].item()) == (4 if i == 7 else 5)
+    flat = oa._dev[0]["flat"]
+    assert flat.numel() == len(a) and oa.state[a[5]]["step"].data_ptr() == flat.data_ptr() + 8 * 5
+    # state_dict round trip: a reloaded optimiser continues bit for bit
+    a2 = [p.detach().clone().requires_grad_(True) for p in a]
+    oc = FusedAdam(a2, lr=1e-3, weight_decay=0.01, capturable=True)
+    oc.load_state_dict(copy.deepcopy(oa.state_dict()))
+    for pa, pc in zip(a, a2):
+        gr = torch.randn(pa.shape, generator=g).to(DEV)
+        pa.grad, pc.grad = gr.clone(), gr.clone()
+    oa.step()
+    oc.step()
+    for i, (pa, pc) in enumerate(zip(a, a2)):
+        assert torch.equal(pa.detach(), pc.detach()), i
+        assert int(oc.state[pc]["step"].item()) == (5 if i == 7 else 6)
+    # multi-tensor EMA
+    dst = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    src = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    want = [d.clone().mul_(0.999).add_(s_, alpha=1 - 0.999) for d, s_ in zip(dst, src)]
+    v0 = dst[0]._version
+    K.ema_multi_(dst, src, 0.999)
+    assert dst[0]._version == v0 + 1
+    for i, (d, w) in enumerate(zip(dst, want)):
+        assert maxabs(d, w) < 1e-7 * (1 + float(w.abs().max())), i
+        one = src[i].clone()
+        ref1 = dst[i].clone()
+        K.ema_(ref1, one, 0.5)
+        many = [dst[i].clone()]
+        K.ema_multi_(many, [one], 0.5)
+        assert torch.equal(ref1, many[0])           # == the single-tensor kernel bit for bit
+
+
+def test_graphed_step_reads_the_learning_rate_from_device_memory():
+    """a captured step used to bake group['lr'] into its kernel arguments; coach.py:390-392 multiplies it by 0.1 at step
+    100000.  Now the replayed Adam launches read it from a device double that GraphedStep.step() refreshes: graphed == eager across
+    an lr change; changing betas under a captured step raises."""
+    from e4s_amd.optim import FusedAdam, GraphedStep
+    g = torch.Generator().manual_seed(3)
+    w0 = torch.randn(300, generator=g)
+    x = torch.randn(300, generator=g).to(DEV)
+
+    def run_graphed():
+        w = w0.clone().to(DEV).requires_grad_(True)
+        opt = FusedAdam([w], lr=1e-2, capturable=True)
+
+        def body():
+            loss = ((w * x - 1.0) ** 2).sum()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        gs = GraphedStep(opt, body, warmup=2)         # 2 eager steps, then the captured one
+        for i in range(6):
+            if i == 3:
+                opt.param_groups[0]["lr"] = 1e-3
+            gs.step()
+        return w.detach().clone(), opt, gs
+
+    # eager twin: 2 warm-up steps at 1e-2, then 6 steps with the change before the 4th
+    w = w0.clone().to(DEV).requires_grad_(True)
+    opt = FusedAdam([w], lr=1e-2, capturable=True)
+    for i in range(8):
+        if i == 5:
+            opt.param_groups[0]["lr"] = 1e-3
+        opt.zero_grad(set_to_none=True)
+        loss = ((w * x - 1.0) ** 2).sum()
+        loss.backward()
+        opt.step()
+    wg, og, gs = run_graphed()
+    assert torch.equal(wg, w.detach()), float((wg - w.detach()).abs().max())
+    v = og.param_groups[0]["params"][0]._version
+    gs.step()
+    assert og.param_groups[0]["params"][0]._version == v + 1          # a replay advances the version of what it wrote
+    og.param_groups[0]["betas"] = (0.5, 0.999)
+    with pytest.raises(RuntimeError, match="re-capture"):
+        gs.step()
+
+
 def test_optimisation_step_gradients_are_bit_reproducible():
     """Two identical fwd+bwd passes at 256^2 (masked + unmasked layers, fixed noise) give bitwise-identical latent
     gradients: ds / dd / ToRGB-weight reductions and the LocalMLP backward add their partial sums in a fixed order."""

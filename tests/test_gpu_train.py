@@ -408,3 +408,17 @@ def test_graphed_g_step_equals_the_eager_loop():
         assert torch.equal(pe, pg), n
     for (n, pe), (_, pg) in zip(ema_e.named_parameters(), ema_g.named_parameters()):
         assert torch.equal(pe, pg), n
+    # the replays wrote the parameters and the EMA copy through raw pointers; eager consumers AFTER two replays (a D step's
+    # net forward, an evaluation of net_ema) must re-pack from the current weights, not serve the packs of the capture.  The eager twin
+    # holds bit-identical weights and went through torch's version counters all the way.
+    from e4s_amd import packs
+    with torch.no_grad():
+        out_g = net_g(img_g, mask_g, randomize_noise=False)[0]
+        out_e = net_e(img_e, mask_e, randomize_noise=False)[0]
+        ema_out_g = ema_g(img_g, mask_g, randomize_noise=False)[0]
+        ema_out_e = ema_e(img_e, mask_e, randomize_noise=False)[0]
+        packs.invalidate_packs()                                   # ... and against freshly built packs of the same weights
+        out_fresh = net_g(img_g, mask_g, randomize_noise=False)[0]
+        ema_fresh = ema_g(img_g, mask_g, randomize_noise=False)[0]
+    assert torch.equal(out_g, out_e) and torch.equal(out_g, out_fresh)
+    assert torch.equal(ema_out_g, ema_out_e) and torch.equal(ema_out_g, ema_fresh)

@@ -417,11 +417,12 @@ def test_train_iteration_cadence_follows_the_coach_loop():
     assert torch.allclose(pen, g.pow(2).reshape(2, -1).sum(1).mean())
 
 
-def test_train_iteration_forgets_targets_per_batch_and_refuses_to_graph_a_multi_process_step():
+def test_train_iteration_forgets_targets_per_batch_and_refuses_steps_it_cannot_capture():
     """TrainIteration.forget_targets drops the loss networks' per-target feature caches (a training batch is a NEW target even when it
     arrives in the same tensor: the reference recomputes the target features in every calc_loss, id_loss.py:33-35), and
-    graphed_g_step refuses a step whose gradient averaging is launched from host-side hooks, and a non-capturable optimiser --
-    both before anything touches a GPU."""
+    graphed_g_step refuses a trainable generator (its job tables are re-uploaded whenever its weights change: not capturable) and
+    a non-capturable optimiser -- both before anything touches a GPU.  (A gradient averager is NOT refused any more: its bucket
+    all-reduces are captured with the step, tests/test_gpu_nccl_world1.py.)"""
     import types
     from e4s_amd.train import TrainIteration
 
@@ -429,6 +430,7 @@ def test_train_iteration_forgets_targets_per_batch_and_refuses_to_graph_a_multi_
         def __init__(self):
             super().__init__()
             self.w = torch.nn.Parameter(torch.ones(1))
+            self.G = torch.nn.Linear(2, 2)
 
         def forward(self, img, onehot, **kw):
             return img * self.w, None
@@ -439,8 +441,9 @@ def test_train_iteration_forgets_targets_per_batch_and_refuses_to_graph_a_multi_
     it.forget_targets()
     assert crit["id"]._target is None and crit["lpips"]._target is None and not hasattr(crit["other"], "_target")
     img = torch.zeros(1, 3, 4, 4)
-    with pytest.raises(RuntimeError, match="single-process"):
+    with pytest.raises(RuntimeError, match="train_G"):
         it.graphed_g_step(img, img)
-    it.averager = None
+    for p in net.G.parameters():
+        p.requires_grad = False
     with pytest.raises(RuntimeError, match="capturable"):
         it.graphed_g_step(img, img)

@@ -390,3 +390,59 @@ def test_gloo_world2_train_iteration_equals_single_process():
         assert p.exitcode == 0
     assert all(r[1] for r in res), res
     assert all(r[2] is not None and r[2] >= 1 for r in res), res
+
+
+def _worker_ddp_order(rank, world, port, q):
+    """Ranks announce their gradients in DIFFERENT orders (rank 0 first parameter first, rank 1 last first) and rank 1 never announces
+    one parameter: the collectives must still go out in bucket-index order on both ranks (torch DDP's rule), or the two
+    ranks would pair all-reduces of different buckets -- a hang or silent corruption on RCCL."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from e4s_amd.ddp import GradAverager
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(50 + 7 * i)) for i in range(9)]
+    avg = GradAverager(params, bucket_mb=1e-4)                    # every parameter its own bucket (different sizes)
+    fired = []
+    real_fire = avg._fire
+    avg._fire = lambda i: (fired.append(i), real_fire(i))[1]
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = [torch.randn(p.shape, generator=g) for p in params]
+    order = list(range(9)) if rank == 0 else list(range(8, -1, -1))
+    avg.arm()
+    for i in order:
+        if rank == 1 and i == 4:
+            continue                                              # never announced on rank 1: finish() sends zeros
+        params[i].grad = grads[i].clone()
+        avg.notify(params[i], params[i].grad)
+    during = avg.fired_during_backward
+    avg.finish()
+    all_g = []
+    for r in range(world):
+        gr = torch.Generator().manual_seed(100 + r)
+        all_g.append([torch.randn(p.shape, generator=gr) for p in params])
+    ok = fired == sorted(fired) and len(fired) == len(avg.buckets)
+    for i, p in enumerate(params):
+        want = (all_g[0][i] + (0 if i == 4 else all_g[1][i])) / world
+        ok = ok and bool(torch.allclose(p.grad, want, atol=1e-6))
+    q.put((rank, ok, during, fired))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_buckets_are_reduced_in_index_order_whatever_the_arrival_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ddp_order, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    by_rank = {r: during for r, _, during, _ in res}
+    # bucket 0 holds the LAST parameter (reverse order): rank 1 announces it first and fires buckets as they complete a prefix; rank 0
+    # announces it last and can only fire everything then
+    assert by_rank[0] >= 1 and by_rank[1] >= 1, res
