@@ -1,0 +1,453 @@
+// 3x3 stride-1 convolution as Winograd F(2,3) ALONG THE IMAGE ROWS on the bf16 matrix cores at fp32-class accuracy (split bf16, three
+// MFMAs per product, as conv_bf16x3.hip): 4 transform positions per PAIR of output columns instead of 3 x 2 taps -- 12 multiply-adds per
+// output pair and input channel where the direct form spends 18: 1.5x fewer MFMAs for the same convolution.  The encoder's stride-1 3x3
+// convs (helpers.py:128-137: InstanceNorm -> Conv2d -> PReLU -> Conv2d; 44 % of a face swap's GPU time on the direct kernel) are the
+// target: VERDICT r3 'next' 4 asked for a measured MAC-reduction prototype.  Why 1-D and not F(2x2,3x3): the 2-D form needs 16 transform
+// positions per 2x2 outputs -- 16 accumulator sets per (tile, channel) tile, 128 KB of split operands per 16-channel K step of a 64 x 64
+// tile, and ~100 VALU of input transform + split per (tile, channel) against 48 MFMAs; on gfx950 that kernel is bound by VALU issue and L2
+// weight traffic, not by the matrix pipe.  The 1-D form keeps the direct kernel's shape: the vertical taps stay
+// taps (3 K stages per channel chunk), the 4 positions are 4 accumulator sets, the output transform happens in registers.
+//
+//   pair j of row y: d0..d3 = x[y][2j-1 .. 2j+2]        V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3
+//   taps g0 g1 g2 of weight row ky:                     U0 = g0   U1 = (g0 + g1 + g2) / 2   U2 = (g0 - g1 + g2) / 2   U3 = g2
+//   M_p[y][j][co] = sum_ky sum_ci V_p[y + ky - 1][j][ci] * U_p[ky][ci][co]
+//   out[y][2j] = M0 + M1 + M2        out[y][2j+1] = M1 - M2 - M3
+// Error: the transforms are exact in fp32 up to one rounding per add (coefficients +-1, 1/2); on top of the 2^-16 split the measured
+// growth is 1.7x per layer (tools/winograd_error_study.py: 7.8e-6 vs 4.6e-6 of the output scale on 512 -> 512 @32^2; style vectors of the
+// whole encoder 1.3e-4 vs 7.9e-5 for the 2-D form, less for this one).
+//
+// Block = 512 threads = 8 waves, tile = 16 x 16 output pixels (128 GEMM rows = 16 rows x 8 pairs) x 128 output channels x 4 positions.
+// Wave (wm, wn) of 2 x 4 owns 64 rows x 32 channels of ALL 4 positions (8 accumulators, 128 registers), so the output transform, bias,
+// PReLU, the InstanceNorm statistics of the output and the NHWC stores work on registers, nothing is exchanged between waves.
+// K step = one vertical tap x 16 input channels = 24 MFMAs per wave between two barriers; a chunk = 3 such stages.
+// LDS (140 KB): V of the current and the next chunk (4 positions x 144 V-pixels [18 rows x 8 pairs] x 64-byte rows [16 hi | 16 lo]),
+// U of the current and the next stage (4 positions x 128 channels x 64-byte rows).  Rows are 64 bytes WITHOUT padding; the 16-byte granule
+// index is XORed with (row >> 2) & 3, which makes every ds_read_b128 fragment read conflict free (the lane groups of a wave64 b128 read
+// hold rows r, r+12, r+20, r+24 (mod 4 classes) whose (row >> 2) & 3 differ) -- vertical taps shift a fragment by 8 rows and keep that.
+// The input transform runs on the way into LDS: a work item = (V-pixel, 4 channels): four 16-byte loads, [InstanceNorm folded in: the
+// mean cancels in the three differences], 16 values split to hi / lo, eight 8-byte LDS stores.  The 576 items of chunk c+1 are spread
+// over the three stages of chunk c, three waves per stage, rotating through the eight waves (the staging wave's MFMAs run under its SIMD
+// partner's).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NTHR = 512;
+constexpr int TH = 16, TW = 16, NPAIR = TW / 2;
+constexpr int VROWS = (TH + 2) * NPAIR;          // 144 V-pixels per position and chunk
+constexpr int BN = 128, KC = 16, ROWB = 64;
+constexpr int A_PLANE = VROWS * ROWB, A_BYTES = 4 * A_PLANE;        // 36 864
+constexpr int B_PLANE = BN * ROWB, B_BYTES = 4 * B_PLANE;           // 32 768
+constexpr int NITEMS = VROWS * 4;                                   // 576 (V-pixel, 4-channel group) items per chunk
+constexpr int SMEM_WINO = 2 * A_BYTES + 2 * B_BYTES + 2 * BN * 2 * 8;
+
+__device__ __forceinline__ int swz(int row, int g) { return row * ROWB + ((g ^ ((row >> 2) & 3)) << 4); }
+
+// hi / lo split of 4 floats -> two 8-byte LDS stores
+__device__ __forceinline__ void split_store4(unsigned char* hi_dst, unsigned char* lo_dst, const f32x4 v) {
+    const bf16x4 h = __builtin_convertvector(v, bf16x4);
+    const f32x4 r = v - __builtin_convertvector(h, f32x4);
+    const bf16x4 l = __builtin_convertvector(r, bf16x4);
+    *reinterpret_cast<bf16x4*>(hi_dst) = h;
+    *reinterpret_cast<bf16x4*>(lo_dst) = l;
+}
+
+// w9 [9][Cout][Cin] (tap = ky * 3 + kx) -> U [3 ky][Cin/16][4 pos][Cout][16 hi | 16 lo] bf16
+__global__ void wino_weights_kernel(const float* __restrict__ w9, unsigned char* __restrict__ out, int Cout, int Cin) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)3 * Cout * Cin;
+    if (i >= total) return;
+    const int ci = (int)(i % Cin);
+    const int co = (int)((i / Cin) % Cout);
+    const int ky = (int)(i / ((int64_t)Cin * Cout));
+    const float g0 = w9[((int64_t)(ky * 3 + 0) * Cout + co) * Cin + ci];
+    const float g1 = w9[((int64_t)(ky * 3 + 1) * Cout + co) * Cin + ci];
+    const float g2 = w9[((int64_t)(ky * 3 + 2) * Cout + co) * Cin + ci];
+    const float u[4] = {g0, ((g0 + g2) + g1) * 0.5f, ((g0 + g2) - g1) * 0.5f, g2};
+    const int chunk = ci / KC, k = ci % KC, nchunk = Cin / KC;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const __bf16 h = (__bf16)u[p];
+        const __bf16 l = (__bf16)(u[p] - (float)h);
+        unsigned char* row = out + ((((int64_t)ky * nchunk + chunk) * 4 + p) * Cout + co) * ROWB;
+        reinterpret_cast<__bf16*>(row)[k] = h;
+        reinterpret_cast<__bf16*>(row + 32)[k] = l;
+    }
+}
+
+// XF: 0 plain input, 2 InstanceNorm (x - mean) * rstd folded into the input transform (zero padding applies to the NORMALISED map)
+// VAR: profiling variants (builds with -DE4S_ABLATIONS select them with env E4S_WINO_VAR; results are WRONG for VAR >= 1; product builds
+// only instantiate VAR = 0): 1 no input-transform staging, 2 no weight staging, 3 neither, 4 neither and no fragment reads (MFMAs + barriers),
+// 5 MFMAs only (no barriers), 6 everything but the MFMAs
+template <int XF, int VAR = 0>
+__global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p, const int ntn, const int tx_n, const int per_img,
+                                                         const int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                                  // [2][4 pos][144][64]
+    unsigned char* sB = smem + 2 * A_BYTES;                    // [2][4 pos][128][64]
+    double* s_st = reinterpret_cast<double*>(sB + 2 * B_BYTES);      // [2 wm][BN][2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    // n-major tile order: consecutive ids (one XCD) share a column tile, i.e. one 3 * Cin * 512-byte slab of U in their L2
+    const int nt = t / (ntiles / ntn), mt = t - nt * (ntiles / ntn);
+    const int n0 = nt * BN;
+    const int tb = mt / per_img;
+    const int rem = mt - tb * per_img;
+    const int tyb = rem / tx_n, txb = rem - tyb * tx_n;
+    const int ty0 = tyb * TH, tx0 = txb * TW;
+    const int nchunk = p.Cin / KC;
+    const float* xb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin;
+    const unsigned char* ub = reinterpret_cast<const unsigned char*>(p.w);
+
+    // ---- input-transform items ----
+    struct Item {
+        f32x4 d[4];
+        f32x4 s0, s1;        // XF == 2: {mean, rstd} of channels c..c+1 / c+2..c+3 interleaved
+        int dst;             // byte offset of the hi half inside a position plane
+        unsigned okmask;     // bit i: d[i] is inside the image
+    };
+    auto item_load = [&](int it, int chunk, Item& I) {
+        const int v = it >> 2, cq = it & 3;
+        const int hy = v >> 3, j = v & 7;
+        const int iy = ty0 + hy - 1;
+        const int c = chunk * KC + cq * 4;
+        const bool rowok = (unsigned)iy < (unsigned)p.Hi;
+        I.okmask = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ix = tx0 + 2 * j - 1 + i;
+            const bool ok = rowok && (unsigned)ix < (unsigned)p.Wi;
+            I.okmask |= ok ? (1u << i) : 0u;
+            const size_t off = ok ? ((size_t)iy * p.Wi + ix) * p.Cin + c : (size_t)c;
+            I.d[i] = *reinterpret_cast<const f32x4*>(xb + off);
+        }
+        if (XF == 2) {
+            const float* st = p.in_stats + ((size_t)tb * p.Cin + c) * 2;
+            I.s0 = *reinterpret_cast<const f32x4*>(st);
+            I.s1 = *reinterpret_cast<const f32x4*>(st + 4);
+        }
+        I.dst = swz(v, cq >> 1) + (cq & 1) * 8;
+    };
+    // padded pixels -> 0 (XF == 2: 0 in the NORMALISED map, i.e. the mean); done once per item, before the per-position parts
+    auto item_prep = [&](Item& I) {
+        f32x4 fill = {0.f, 0.f, 0.f, 0.f};
+        if (XF == 2) fill = f32x4{I.s0[0], I.s0[2], I.s1[0], I.s1[2]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (!(I.okmask & (1u << i))) I.d[i] = fill;
+    };
+    // position ps of an item: V_ps of 4 channels, split to hi / lo (packed converts, shift / mask re-expansion), two 8-byte LDS stores
+    auto item_part = [&](unsigned char* Abuf, const Item& I, int ps) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x4 v;
+        if (ps == 0) v = I.d[0] - I.d[2];
+        else if (ps == 1) {
+            if (XF == 2) {
+                const f32x4 mu = f32x4{I.s0[0], I.s0[2], I.s1[0], I.s1[2]};
+                v = (I.d[1] - mu) + (I.d[2] - mu);
+            } else {
+                v = I.d[1] + I.d[2];
+            }
+        } else if (ps == 2) v = I.d[2] - I.d[1];
+        else v = I.d[1] - I.d[3];
+        if (XF == 2) v = v * f32x4{I.s0[1], I.s0[3], I.s1[1], I.s1[3]};
+        const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+        const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+        const f32x2 r01 = f32x2{v[0] - __builtin_bit_cast(float, h01 << 16), v[1] - __builtin_bit_cast(float, h01 & 0xffff0000u)};
+        const f32x2 r23 = f32x2{v[2] - __builtin_bit_cast(float, h23 << 16), v[3] - __builtin_bit_cast(float, h23 & 0xffff0000u)};
+        const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));
+        const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        unsigned char* a = Abuf + ps * A_PLANE;
+        *reinterpret_cast<u32x2*>(a + I.dst) = u32x2{h01, h23};
+        *reinterpret_cast<u32x2*>(a + (I.dst ^ 32)) = u32x2{l01, l23};
+    };
+
+    // ---- weight staging by LDS-DMA: instruction q = wave * 4 + jj of a stage fills the 1 KB (16 rows) block q & 7 of position plane q >> 3;
+    // the LDS image is lane-linear, so the XOR swizzle goes on the SOURCE granule: lane -> row (lane >> 2), granule (lane & 3) ^ f(row) ----
+    const size_t u_pos = (size_t)p.Cout * ROWB;                          // bytes per position plane in global memory
+    auto u_stage = [&](int ky, int chunk) -> size_t { return ((size_t)ky * nchunk + chunk) * 4 * u_pos; };
+    size_t g_src[4];
+    int g_dst[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int q = wave * 4 + jj, ps = q >> 3, blk = q & 7;
+        const int row = blk * 16 + (lane >> 2);
+        g_src[jj] = ps * u_pos + (size_t)(n0 + row) * ROWB + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+        g_dst[jj] = ps * B_PLANE + blk * 1024;
+    }
+    auto glds_stage = [&](unsigned char* Bdst, size_t stage_off) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + stage_off + g_src[jj]),
+                                             (__attribute__((address_space(3))) void*)(Bdst + g_dst[jj]), 16, 0, 0);
+    };
+
+    // Roles of a wave in stage sg (global stage counter): LOADER: (wave - 3 sg) & 7 < 3 fetches 64 items of the V group this stage feeds;
+    // STORER: the loader of stage sg - 1 transforms, splits and stores them, one position per MFMA group, under its own MFMAs.  Group
+    // (ts + 1) % 3 of the NEXT chunk's 576 items is loaded in stage ts and stored in stage ts + 1, so chunk c + 1's V is complete at the
+    // barrier that ends chunk c (group 0 of chunk c + 1 is loaded in the last stage of chunk c - 1, or in the prologue).
+    Item I;
+    I.dst = 0;
+    I.okmask = 0;
+    // ---- prologue: V of chunk 0 (all threads), U of stage 0, and the loads of group 0 of chunk 1 for the storers of stage 0 ----
+    {
+        Item I0, I1;
+        item_load(tid, 0, I0);
+        const bool two = tid + NTHR < NITEMS;
+        if (two) item_load(tid + NTHR, 0, I1);
+        glds_stage(sB, u_stage(0, 0));
+        item_prep(I0);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) item_part(sA, I0, ps);
+        if (two) {
+            item_prep(I1);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) item_part(sA, I1, ps);
+        }
+        const int slot = (wave + 3) & 7;
+        if (nchunk > 1 && slot < 3) item_load(slot * 64 + lane, 1, I);
+    }
+    __syncthreads();
+
+    // ---- fragment addressing: byte offsets inside a position plane ----
+    int aoff[2][3], boff;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) aoff[tm][ky] = swz(wm * 64 + tm * 32 + li + 8 * ky, kh);
+    boff = swz(wn * 32 + li, kh);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ps][tm][r] = 0.f;
+
+    struct AF { bf16x8 h[2], l[2]; };
+    struct BF { bf16x8 h, l; };
+    unsigned sg = 0;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const bool have_nc = chunk + 1 < nchunk;
+        const unsigned char* Ab = sA + (chunk & 1) * A_BYTES;
+        unsigned char* An = sA + ((chunk + 1) & 1) * A_BYTES;
+#pragma unroll
+        for (int ts = 0; ts < 3; ++ts) {
+            const unsigned char* Bb = sB + (sg & 1) * B_BYTES;
+            unsigned char* Bn = sB + ((sg + 1) & 1) * B_BYTES;
+            const bool more = ts < 2 || have_nc;
+            const bool storer = have_nc && ((wave - 3 * ((int)sg - 1)) & 7) < 3 && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5;
+            const int lslot = (wave - 3 * (int)sg) & 7;
+            const int lchunk = ts < 2 ? chunk + 1 : chunk + 2;
+            const bool loader = lslot < 3 && lchunk < nchunk && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5;
+            auto ldA = [&](AF& F, int ps) {
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    const unsigned char* a = Ab + ps * A_PLANE;
+                    F.h[tm] = *reinterpret_cast<const bf16x8*>(a + aoff[tm][ts]);
+                    F.l[tm] = *reinterpret_cast<const bf16x8*>(a + (aoff[tm][ts] ^ 32));
+                }
+            };
+            auto ldB = [&](BF& F, int ps) {
+                const unsigned char* b = Bb + ps * B_PLANE;
+                F.h = *reinterpret_cast<const bf16x8*>(b + boff);
+                F.l = *reinterpret_cast<const bf16x8*>(b + (boff ^ 32));
+            };
+            // the MFMA section, with the storer's transform parts folded in (STORE is a compile-time copy: a branch around the VALU
+            // block would pin it outside the MFMA stream)
+            auto body = [&](auto store_tag) {
+                constexpr bool STORE = decltype(store_tag)::value;
+                AF A0, A1;
+                BF B0, B1;
+                ldB(B0, 0);
+                ldA(A0, 0);
+                if (VAR == 4 || VAR == 5) { A1 = A0; B1 = B0; }
+                // the storer consumes last stage's plain loads FIRST: with an LDS-DMA in flight hipcc waits vmcnt(0) at the next use of
+                // any plain load, which would also wait for the DMA issued a moment ago
+                if (STORE) item_prep(I);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && (VAR < 2 || VAR == 6)) {
+                    const int ky_w = ts < 2 ? ts + 1 : 0, ch_w = ts < 2 ? chunk : chunk + 1;
+                    glds_stage(Bn, u_stage(ky_w, ch_w));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    AF& Ac = (ps & 1) ? A1 : A0;
+                    AF& Anx = (ps & 1) ? A0 : A1;
+                    BF& Bc = (ps & 1) ? B1 : B0;
+                    BF& Bnx = (ps & 1) ? B0 : B1;
+                    if (ps + 1 < 4 && VAR != 4 && VAR != 5) {
+                        ldB(Bnx, ps + 1);
+                        ldA(Anx, ps + 1);
+                    }
+                    if (STORE) item_part(An, I, ps);
+                    if (VAR != 6) {
+                        acc[ps][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[0], Bc.h, acc[ps][0], 0, 0, 0);
+                        acc[ps][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[1], Bc.h, acc[ps][1], 0, 0, 0);
+                        acc[ps][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[0], Bc.l, acc[ps][0], 0, 0, 0);
+                        acc[ps][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[1], Bc.l, acc[ps][1], 0, 0, 0);
+                        acc[ps][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[0], Bc.h, acc[ps][0], 0, 0, 0);
+                        acc[ps][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[1], Bc.h, acc[ps][1], 0, 0, 0);
+                    } else {
+                        asm volatile("" ::"v"(Ac.h[0]), "v"(Ac.l[0]), "v"(Ac.h[1]), "v"(Ac.l[1]), "v"(Bc.h), "v"(Bc.l));
+                    }
+                    if (STORE) {
+                        // this position's transform + split + stores (~40 VALU, 2 DS writes) and the next group's 6 fragment reads go
+                        // between the six MFMAs
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x306, 9, 0);      // then up to 9 VALU / SALU / DS
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (storer) {
+                body(std::true_type{});
+            } else {
+                if (loader) item_load(((ts + 1) % 3) * 192 + lslot * 64 + lane, lchunk, I);
+                body(std::false_type{});
+            }
+            if (VAR != 5) __syncthreads();
+            ++sg;
+        }
+    }
+
+    // ---- epilogue: output transform in registers, bias, activation, statistics, NHWC stores ----
+    {
+        const int co = n0 + wn * 32 + li;
+        const float bsv = p.bias ? p.bias[co] : 0.f;
+        const float slp = (p.act == 2) ? p.slope[co] : p.alpha;
+        const float gain = (p.act == 1) ? p.gain : 1.f;
+        const bool do_act = p.act != 0;
+        const bool stats = p.stats_ws != nullptr;
+        double st_s = 0.0, st_q = 0.0;
+        float* yb = p.y + (size_t)tb * p.Ho * p.Wo * p.Cout;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float y0[4], y1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * g + i;
+                    const float m0 = acc[0][tm][r], m1 = acc[1][tm][r], m2 = acc[2][tm][r], m3 = acc[3][tm][r];
+                    float a = (m0 + m1) + m2 + bsv;
+                    float b = (m1 - m2) - m3 + bsv;
+                    if (do_act) {
+                        a = (a > 0.f ? a : a * slp) * gain;
+                        b = (b > 0.f ? b : b * slp) * gain;
+                    }
+                    y0[i] = a;
+                    y1[i] = b;
+                    if (stats) {
+                        st_s += (double)a + (double)b;
+                        st_q += (double)a * (double)a + (double)b * (double)b;
+                    }
+                }
+                quad_transpose4(y0[0], y0[1], y0[2], y0[3], li);
+                quad_transpose4(y1[0], y1[1], y1[2], y1[3], li);
+                const int m = wm * 64 + tm * 32 + (li & 3) + 8 * g + 4 * kh;
+                const int oy = ty0 + (m >> 3), ox = tx0 + 2 * (m & 7);
+                float* dst = yb + ((size_t)oy * p.Wo + ox) * p.Cout + (co - (li & 3));
+                *reinterpret_cast<f32x4*>(dst) = f32x4{y0[0], y0[1], y0[2], y0[3]};
+                *reinterpret_cast<f32x4*>(dst + p.Cout) = f32x4{y1[0], y1[1], y1[2], y1[3]};
+            }
+        }
+        if (stats) {
+            st_s += __shfl_xor(st_s, 32, 64);
+            st_q += __shfl_xor(st_q, 32, 64);
+            if (kh == 0) {
+                const int col = wn * 32 + li;
+                s_st[(wm * BN + col) * 2] = st_s;
+                s_st[(wm * BN + col) * 2 + 1] = st_q;
+            }
+            __syncthreads();
+            if (tid < BN) {
+                const double a = s_st[tid * 2] + s_st[(BN + tid) * 2];
+                const double q = s_st[tid * 2 + 1] + s_st[(BN + tid) * 2 + 1];
+                double* slot = p.stats_ws + (((size_t)tb * p.Cout + n0 + tid) * p.stats_slots + (tyb * tx_n + txb)) * 2;
+                slot[0] = a;
+                slot[1] = q;
+            }
+        }
+    }
+}
+
+bool wino_covers(const e4s_conv_params& p) {
+    return p.istride == 1 && p.ostride == 1 && p.ntaps == 9 && p.ncls == 1 && !p.labels && !p.rows && !p.in_scale && !p.out_scale &&
+           !p.noise && p.y_cstride == 0 && !p.splitk_ws && p.Hi == p.Ho && p.Wi == p.Wo && p.Ha == p.Ho && p.Wa == p.Wo && p.Hi % TH == 0 &&
+           p.Wi % TW == 0 && p.Cin % KC == 0 && p.Cin >= 2 * KC && p.Cout % BN == 0 && p.B > 0 &&
+           (p.stats_ws == nullptr || p.stats_slots == (p.Hi / TH) * (p.Wi / TW));
+}
+
+}  // namespace
+
+extern "C" int64_t e4s_wino_weights_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || Cin % KC) return -1;
+    return (int64_t)3 * (Cin / KC) * 4 * Cout * ROWB;
+}
+
+extern "C" int e4s_wino_weights_f32(const float* w9, void* out, int Cout, int Cin, void* stream) {
+    if (!w9 || !out || Cout <= 0 || Cin <= 0 || Cin % KC) return (int)hipErrorInvalidValue;
+    const int64_t total = (int64_t)3 * Cout * Cin;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w9,
+                       reinterpret_cast<unsigned char*>(out), Cout, Cin);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_conv_wino_covers(const e4s_conv_params* p) { return p && wino_covers(*p) ? 1 : 0; }
+
+extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
+    if (!pp) return (int)hipErrorInvalidValue;
+    const e4s_conv_params& p = *pp;
+    if (!p.x || !p.w || !p.y || !wino_covers(p)) return (int)hipErrorInvalidValue;
+    if (p.act == 2 && !p.slope) return (int)hipErrorInvalidValue;
+    const int tx_n = p.Wi / TW, per_img = (p.Hi / TH) * tx_n, ntn = p.Cout / BN;
+    const int64_t tiles = (int64_t)p.B * per_img * ntn;
+    if (tiles > 0x7fffffff) return (int)hipErrorInvalidValue;
+    static std::atomic<uint64_t> m0{0}, m2{0};
+    int e;
+#ifdef E4S_ABLATIONS
+    {
+        static std::atomic<uint64_t> mv[7];
+        const char* ev = getenv("E4S_WINO_VAR");
+        const int var = ev ? atoi(ev) : 0;
+        const void* fn = nullptr;
+#define WV(V) case V: fn = (const void*)conv_wino_kernel<0, V>; if ((e = e4s_ensure_dyn_smem(fn, SMEM_WINO, mv[V]))) return e; \
+              hipLaunchKernelGGL((conv_wino_kernel<0, V>), dim3((unsigned)tiles), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img, (int)tiles); \
+              E4S_CHECK_LAUNCH(); return 0;
+        switch (p.in_stats ? 0 : var) {
+            WV(1) WV(2) WV(3) WV(4) WV(5) WV(6)
+            default: break;
+        }
+#undef WV
+    }
+#endif
+    if (p.in_stats) {
+        if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<2>, SMEM_WINO, m2))) return e;
+        hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)tiles), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img,
+                           (int)tiles);
+    } else {
+        if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<0>, SMEM_WINO, m0))) return e;
+        hipLaunchKernelGGL(conv_wino_kernel<0>, dim3((unsigned)tiles), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img,
+                           (int)tiles);
+    }
+    E4S_CHECK_LAUNCH();
+    return 0;
+}

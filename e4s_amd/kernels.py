@@ -418,6 +418,66 @@ def split16_bf16x2(w):
     return out
 
 
+WINO = os.environ.get("E4S_WINO", "1") == "1"        # policy switch of the Winograd F(2,3) kernel (encoders._conv3x3)
+
+
+def wino_eligible(b, h, w, cin, cout):
+    """Shapes e4s_conv_wino_bf16x3_f32 covers, and whether the launch fills the chip (one 16x16-pixel x 128-column tile per block)."""
+    if not WINO or PRECISION == "f32":
+        return False
+    if h % 16 or w % 16 or cin % 16 or cin < 32 or cout % 128:
+        return False
+    tiles = b * (h // 16) * (w // 16) * (cout // 128)
+    return PRECISION == "bf16x3" or tiles >= BF16X3_MIN_BLOCKS
+
+
+def wino_weights(w9):
+    """tap-packed fp32 weights [1, 9, Cout, Cin] (pack_taps) -> the transformed, hi/lo-split operand of conv_wino (opaque uint8)."""
+    w9 = _f32(w9)
+    cout, cin = w9.shape[-2], w9.shape[-1]
+    if w9.numel() != 9 * cout * cin:
+        raise RuntimeError("wino_weights: one set of nine taps [9, Cout, Cin]")
+    n = lib.load().e4s_wino_weights_bytes(cout, cin)
+    if n <= 0:
+        raise RuntimeError("wino_weights: Cin must be a multiple of 16")
+    out = torch.empty(n, device=w9.device, dtype=torch.uint8)
+    call("e4s_wino_weights_f32", fptr(w9), ptr(out), cout, cin, stream())
+    return out
+
+
+def conv_wino(x, u, cout, *, in_stats=None, bias=None, slope=None, act=0, alpha=0.2, gain=LRELU_GAIN, want_stats=False, se=None):
+    """Stride-1 3x3 conv of x NHWC [B,H,W,Cin] as Winograd F(2,3) along the rows (e4s_conv_wino_bf16x3_f32); u = wino_weights(...).
+    in_stats / act / slope / want_stats / se as conv_mfma."""
+    b, h, w, cin = x.shape
+    y = torch.empty(b, h, w, cout, device=x.device, dtype=torch.float32)
+    p = ConvParams()
+    p.x, p.w, p.y = fptr(x), ptr(u), fptr(y)
+    p.rows = p.tiles = p.meta = None
+    p.B, p.Ha, p.Wa, p.Hi, p.Wi, p.Ho, p.Wo, p.Cin, p.Cout = b, h, w, h, w, h, w, cin, cout
+    p.istride, p.ostride, p.ntaps, p.ncls, p.groups_per_batch = 1, 1, 9, 1, 1
+    p.bias, p.slope = fptr(bias), fptr(slope)
+    p.act, p.alpha, p.gain = act, alpha, gain
+    p.in_stats = fptr(in_stats)
+    fused = None
+    if want_stats:
+        if act != 0:
+            raise RuntimeError("conv_wino: output statistics are those of the raw conv output (act = 0)")
+        slots = (h // 16) * (w // 16)
+        fused = torch.empty(b * cout * slots * 2, device=x.device, dtype=torch.float64)
+        p.stats_ws, p.stats_slots = ptr(fused), slots
+    call("e4s_conv_wino_bf16x3_f32", ctypes.byref(p), stream())
+    if fused is None:
+        return y
+    stats = torch.empty(b, cout, 2, device=x.device, dtype=torch.float32)
+    pooled = torch.empty(b, cout, device=x.device, dtype=torch.float32)
+    if se is not None:
+        call("e4s_instnorm_finalize_se_f32", ptr(fused), fptr(stats), fptr(se[0]), fptr(se[1]), fptr(pooled), b, h * w, cout,
+             se[0].shape[0], p.stats_slots, 1e-5, stream())
+    else:
+        call("e4s_instnorm_finalize_f32", ptr(fused), fptr(stats), fptr(pooled), b, h * w, cout, p.stats_slots, 1e-5, stream())
+    return y, (stats, pooled)
+
+
 def upconv_mfma(x, w3, cout, k4, *, in_scale=None, out_scale=None, labels=None, num_regions=1, noise=None,
                 noise_w=None, noise_per_channel=False, bias=None, act=0, alpha=0.2, gain=LRELU_GAIN, out=None):
     """Exact transposed-conv + blur up-sampling conv.  x NHWC [B,H,W,Cin]; w3 [1,9,Cout,Cin] (plain taps);

@@ -379,6 +379,18 @@ int e4s_adam_multi_dev_f32(int count, float* const* p, const float* const* grad,
                            const int64_t* const* step, double lr, const double* lr_dev, double beta1, double beta2, double eps,
                            double weight_decay, void* stream);
 int e4s_ema_multi_f32(int count, float* const* dst, const float* const* src, const int64_t* n, double decay, void* stream);
+/* 3x3 stride-1 conv as Winograd F(2,3) along the image rows on the split-bf16 matrix-core path (csrc/conv_wino.hip): 1.5x fewer MFMAs than
+ * e4s_conv_bf16x3_f32 for the encoder's Conv2d(3x3, stride 1) layers (src/models/encoders/helpers.py:128-137).
+ * e4s_wino_weights_f32: w9 [9][Cout][Cin] (tap-packed, e4s_pack_taps_f32) -> the kernel's transformed, hi/lo-split operand
+ * (e4s_wino_weights_bytes(Cout, Cin) bytes, opaque).
+ * e4s_conv_wino_bf16x3_f32: p->x / p->y NHWC, p->w = that operand; covered: istride = ostride = 1, ntaps 9, ncls 1, H % 16 == W % 16 == 0,
+ * Cin % 16 == 0 (>= 32), Cout % 128 == 0, no styles / labels / noise / plan / split-K / y_cstride; honoured: in_stats (InstanceNorm folded
+ * into the input transform), bias, act (0 none, 1 leaky * gain, 2 PReLU with p->slope), stats_ws / stats_slots (per-tile {sum, sum^2} of the
+ * output as e4s_conv_bf16x3_f32 emits them).  e4s_conv_wino_covers: 1 if the launch would be accepted.  Everything else: hipErrorInvalidValue. */
+int64_t e4s_wino_weights_bytes(int Cout, int Cin);
+int e4s_wino_weights_f32(const float* w9, void* out, int Cout, int Cin, void* stream);
+int e4s_conv_wino_covers(const e4s_conv_params* p);
+int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* p, void* stream);
 /* Exact up-sampling StyledConv on the split-bf16 matrix-core path (csrc/upconv_bf16x3.hip): conv_transpose2d(stride 2) +
  * Blur (src/models/stylegan2/model.py:287-300, 206-213) + NoiseInjection + FusedLeakyReLU (:396-404) in one kernel, one style
  * per sample (unmasked layers, model.py:655-657); Cin % 32 == 0, Cout % 32 == 0.

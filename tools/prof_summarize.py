@@ -1,7 +1,7 @@
 """Condense rocprofv3 CSV output into small summaries that fit in profiles/.
 
   python tools/prof_summarize.py trace  <kernel_trace.csv>        > kernel_stats.csv
-  python tools/prof_summarize.py pmc    <counter_collection.csv>  > counters.csv
+  python tools/prof_summarize.py pmc    <counter_collection.csv> [grid]  > counters.csv     (grid: conv kernels keyed per grid size too)
 
 `trace`: per kernel name (and, for the conv kernel, per grid size = per layer shape): calls, total,
 average, min, max duration and share of GPU time.  `pmc`: per kernel name x counter: dispatches,
@@ -9,6 +9,9 @@ sum and per-dispatch mean of the counter value."""
 import csv
 import sys
 from collections import defaultdict
+
+
+CONV_KEYS = ("conv_mfma", "upconv", "conv_bwd", "conv_bf16x3", "conv_c32", "conv_region", "wino")
 
 
 def short(name):
@@ -23,7 +26,7 @@ def trace(path):
         for row in csv.DictReader(fh):
             d = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
             key = short(row["Kernel_Name"])
-            if "conv_mfma" in key or "upconv" in key or "conv_bwd" in key or "conv_bf16x3" in key or "conv_c32" in key:
+            if any(k in key for k in CONV_KEYS):
                 key += " grid=%d" % (int(row["Grid_Size_X"]) // int(row["Workgroup_Size_X"]))
             a = agg[key]
             a[0] += 1
@@ -38,11 +41,17 @@ def trace(path):
                     "%.2f" % (a[3] / 1e3), "%.2f" % (100.0 * a[1] / max(total, 1))])
 
 
-def pmc(path):
+def pmc(path, per_grid=False):
     agg = defaultdict(lambda: [0, 0.0])
     with open(path) as fh:
         for row in csv.DictReader(fh):
-            key = (short(row["Kernel_Name"]), row["Counter_Name"])
+            name = short(row["Kernel_Name"])
+            if per_grid and any(k in name for k in CONV_KEYS):
+                gs = row.get("Grid_Size") or row.get("Grid_Size_X")
+                wg = row.get("Workgroup_Size") or row.get("Workgroup_Size_X")
+                if gs and wg:
+                    name += " grid=%d" % (int(gs) // max(int(wg), 1))
+            key = (name, row["Counter_Name"])
             a = agg[key]
             a[0] += 1
             a[1] += float(row["Counter_Value"])
@@ -53,4 +62,7 @@ def pmc(path):
 
 
 if __name__ == "__main__":
-    {"trace": trace, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    if sys.argv[1] == "pmc":
+        pmc(sys.argv[2], len(sys.argv) > 3 and sys.argv[3] == "grid")
+    else:
+        trace(sys.argv[2])
