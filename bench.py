@@ -88,10 +88,17 @@ def headline_probe(net, batch, mask, reps):
         return ms, flops / (ms * 1e-3) / 1e12
 
     traffic = {}
+    traffic_stale = False
     tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.isfile(tp):
         try:
             traffic = json.load(open(tp))
+            # the PMC figure belongs to ONE version of the kernel: keyed on a hash of its source, so that it cannot go stale silently
+            import hashlib
+            rows = traffic.get("bf16x3_rows", {})
+            src = os.path.join(ROOT, rows.get("kernel_source", "e4s_amd/csrc/conv_region.hip"))
+            if hashlib.sha256(open(src, "rb").read()).hexdigest() != rows.get("kernel_source_sha256"):
+                traffic_stale = True
         except Exception:
             traffic = {}
     ms32, ach32 = timed({})
@@ -115,10 +122,15 @@ def headline_probe(net, batch, mask, reps):
     return {"bound": "mfma", "kernel": name + " (3x v_mfma_f32_32x32x16_bf16 per product) " + what,
             "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "frac_ceiling": round(1.0 / 3.0, 4),
-            "mfma_executed_tflops": round(3 * ach, 1), "traffic": traffic.get("hbm_bytes_per_launch_bf16x3"),
+            "mfma_executed_tflops": round(3 * ach, 1),
+            # power-limited rate of a register-resident v_mfma_f32_32x32x16_bf16 stream on random operands (tools/mfma_peak.sh,
+            # profiles/r04a_mfma_peak.jsonl: 1 774-1 782 TF at 1.69 GHz / 1 350 W; zero operands reach 2 471-2 480 TF at 2.36 GHz):
+            # what `frac` could reach for a 3-MFMA-per-product kernel is 1780 / 3 / 2500 = 0.237
+            "frac_of_power_limited_mfma_rate": round(3 * ach / 1780.0, 4),
+            "traffic": None if traffic_stale else traffic.get("hbm_bytes_per_launch_bf16x3"), "traffic_stale": traffic_stale,
             "traffic_source": "profiles/roofline_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of "
-                              "this kernel (separate passes, profiles/r03g_pmc_{fetch,write}.csv); a PMC pass cannot run "
-                              "inside this timed process",
+                              "this kernel (separate passes, profiles/r04a_pmc_{fetch,write}.csv), valid for the kernel source whose "
+                              "sha256 the file records; a PMC pass cannot run inside this timed process",
             "avg_launch_ms": round(ms, 4), "flop_per_launch": flops, "exact_fp32_variant": exact}
 
 
@@ -251,6 +263,9 @@ def stitch_leg(net, inputs, reps=10):
         out[name] = round((time.perf_counter() - t0) / reps * 1e3, 3)
     out["batch"] = b
     out["out"] = f"uint8 {list(res.shape)}"
+    # cv2 / skimage exist neither in the build container nor on the GPU box (probed this round): the OpenCV halves of the stitch (erode,
+    # fixed-point GaussianBlur, pyrDown / pyrUp) are checked against a restatement of OpenCV's algorithms, not against cv2 itself
+    out["parity"] = "mask swap / create_masks / tensor2im / alpha composite: pinned to the reference's own outputs; cv2 parts: unpinned"
     return out
 
 

@@ -505,15 +505,25 @@ class Generator(nn.Module):
 
     def mean_latent(self, n_latent):
         latent_in = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
-        return self.style(latent_in).mean(0, keepdim=True)
+        return self.get_latent(latent_in).mean(0, keepdim=True)
 
     def get_latent(self, input):
+        """The mapping network z -> w (model.py:489-497, 570-574: PixelNorm + n_mlp x EqualLinear(lr_mul, fused_lrelu)) on the native
+        kernels (e4s_pixelnorm_f32 + one e4s_grouped_linear_f32 per layer, leaky-ReLU gain folded into scale and bias) for ROCm inputs
+        that need no gradient (Net3 freezes G.style, networks.py:68-70); otherwise the module chain as written (differentiable ATen)."""
+        if input.is_cuda and input.ndim == 2 and not (torch.is_grad_enabled() and (
+                input.requires_grad or any(p.requires_grad for p in self.style.parameters()))):
+            with torch.no_grad():
+                w = K.pixelnorm(input.to(torch.float32).contiguous())
+                for lin in list(self.style)[1:]:
+                    w = equal_linear_lrelu(lin, w)
+            return w
         return self.style(input)
 
     # ------------------------------------------------------------------------------------------
     def _assemble_latent(self, styles, input_is_latent, inject_index, truncation, truncation_latent):
         if not input_is_latent:
-            styles = [self.style(s) for s in styles]
+            styles = [self.get_latent(s) for s in styles]
         if truncation < 1:
             styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
         if len(styles) < 2:

@@ -1345,3 +1345,26 @@ def test_encoder_forward_with_and_without_winograd_vs_oracle(monkeypatch):
             out[wino] = maxabs(sv, ref)
     print("style vectors vs fp64 oracle: winograd %.3e, direct %.3e (scale %.2f)" % (out[True], out[False], float(ref.abs().max())))
     assert out[True] < 3e-4 and out[False] < 3e-4
+
+
+def test_mapping_network_native_vs_module_chain():
+    """Generator.get_latent / mean_latent (model.py:489-497, 570-574: PixelNorm + 8 x EqualLinear(lr_mul 0.01, fused_lrelu)) on the
+    native kernels == the reference module chain evaluated in fp64 on the CPU; under autograd (z requires grad) the ATen chain is kept."""
+    from e4s_amd.stylegan2 import Generator
+    g = Generator(256, 512, 8)
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for lin in list(g.style)[1:]:
+            lin.weight.copy_(torch.randn(lin.weight.shape, generator=gen) / 0.01)        # EqualLinear init: randn / lr_mul
+            lin.bias.copy_(torch.randn(lin.bias.shape, generator=gen))
+    z = torch.randn(5, 512, generator=gen)
+    x = (z.double() * torch.rsqrt((z.double() ** 2).mean(1, keepdim=True) + 1e-8))
+    for lin in list(g.style)[1:]:
+        x = torch.nn.functional.leaky_relu(x @ (lin.weight.double() * lin.scale).t() + lin.bias.double() * lin.lr_mul, 0.2) * 2 ** 0.5
+    g = g.to(DEV)
+    w = g.get_latent(z.to(DEV))
+    assert maxabs(w, x) < 2e-5 * float(x.abs().max()), maxabs(w, x)
+    zg = z.to(DEV).requires_grad_(True)
+    wg = g.get_latent(zg)                                          # differentiable path: the module chain
+    assert wg.requires_grad and maxabs(wg, x) < 1e-4 * float(x.abs().max())
+    assert tuple(g.mean_latent(64).shape) == (1, 512)
