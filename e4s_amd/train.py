@@ -59,14 +59,24 @@ def d_r1_loss(real_pred, real_img):
     return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
 
 
+def w_norm_loss(latent, latent_avg=None, start_from_latent_avg=True):
+    """WNormLoss, src/criteria/w_norm.py:5-14 on the regional latent [B,R,n_latent,512] (coach.py:438-445; w_norm_lambda is 0 as
+    shipped): a scalar reduction of a ~1 MB tensor, left to autograd's ATen ops."""
+    if start_from_latent_avg:
+        latent = latent - latent_avg
+    return torch.sum(latent.norm(2, dim=(2, 3))) / (latent.shape[0] * latent.shape[1])
+
+
 class LossOpts:
-    """The loss weights of train_options.py:44-57 (defaults as shipped)."""
+    """The loss weights of train_options.py:44-57 (defaults as shipped; style_lambda -- the VGG16 gram-matrix loss of
+    coach.py:446-450, 0 as shipped, needs torchvision's VGG16 -- is not built)."""
 
     def __init__(self, face_parsing_lambda=0.1, id_lambda=0.1, l2_lambda=1.0, lpips_lambda=0.8, g_adv_lambda=0.01,
-                 r1_lambda=10.0, d_every=15, d_reg_every=-1, lpips_sizes=(1024, 512, 256)):
+                 r1_lambda=10.0, d_every=15, d_reg_every=-1, lpips_sizes=(1024, 512, 256), w_norm_lambda=0.0):
         self.face_parsing_lambda, self.id_lambda, self.l2_lambda = face_parsing_lambda, id_lambda, l2_lambda
         self.lpips_lambda, self.g_adv_lambda, self.r1_lambda = lpips_lambda, g_adv_lambda, r1_lambda
         self.d_every, self.d_reg_every, self.lpips_sizes = d_every, d_reg_every, tuple(lpips_sizes)
+        self.w_norm_lambda = w_norm_lambda
 
 
 class TrainIteration:
@@ -82,7 +92,7 @@ class TrainIteration:
         self.global_step = 0
 
     # ---- coach.py:403-453 -------------------------------------------------------------------------------------------
-    def calc_loss(self, img, recon):
+    def calc_loss(self, img, recon, latent=None):
         lo, loss, terms = self.lo, 0.0, {}
         if lo.face_parsing_lambda > 0 and "parsing" in self.crit:
             terms["parsing"] = self.crit["parsing"](recon, img)[0]
@@ -97,11 +107,20 @@ class TrainIteration:
             # the three adaptive_avg_pool2d scales of coach.py:425-434, pooled inside the networks' first pass
             terms["lpips"] = self.crit["lpips"].forward_pooled(recon, img, lo.lpips_sizes)
             loss = loss + terms["lpips"] * lo.lpips_lambda
+        if lo.w_norm_lambda > 0:
+            if latent is None:
+                raise RuntimeError("w_norm_lambda > 0 needs the latent (Net3.forward(..., return_latents=True))")
+            terms["w_norm"] = w_norm_loss(latent, self.net.latent_avg, getattr(self.net.opts, "start_from_latent_avg", True))
+            loss = loss + terms["w_norm"] * lo.w_norm_lambda
         return loss, terms
 
     def generator_loss(self, img, onehot, **fwd):
-        recon, _ = self.net(img, onehot, **fwd)
-        loss, terms = self.calc_loss(img, recon)
+        latent = None
+        if self.lo.w_norm_lambda > 0:
+            recon, _, latent = self.net(img, onehot, return_latents=True, **fwd)
+        else:
+            recon, _ = self.net(img, onehot, **fwd)
+        loss, terms = self.calc_loss(img, recon, latent)
         if self.disc is not None:
             terms["g_adv"] = adv_g_loss(self.disc(recon))
             loss = loss + self.lo.g_adv_lambda * terms["g_adv"]

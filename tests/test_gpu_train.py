@@ -58,14 +58,14 @@ def test_encoder_unit_backward_vs_oracle_f64(cin, depth, stride, res, prec, monk
         grads[id(p)] = gr if id(p) not in grads else grads[id(p)] + gr
     dx = unit_backward(tape[0], K.nchw_to_nhwc(wgt.to(DEV)), give)
     scale = float(x64.grad.abs().max())
-    # A pre-activation of conv1 within ~1e-5 of zero (2 are expected among the 2.6e5 of the 512-channel cases) lands on the other side
-    # of the PReLU kink in ANY two fp32-class implementations -- the direct split-bf16 kernel, the Winograd one (1.7x its error), ATen in
-    # fp32 -- and changes dx on the 3 x 3 x Cin elements conv1's transpose spreads it over.  So: max-abs everywhere except on at most two
-    # such patches, and a relative-L2 bound that a real defect cannot pass.
+    # A pre-activation of conv1 within ~1e-5 of zero (one or two are expected among the 2.6e5 of the 512-channel cases) lands on the other
+    # side of the PReLU kink in ANY two fp32-class implementations -- the direct split-bf16 kernel, the Winograd one (1.7x its error), ATen
+    # in fp32 -- and changes dx on the 3 x 3 x Cin elements conv1's transpose spreads it over (measured with one flip: 3 469 elements off,
+    # max 3e-3 of the scale, relative L2 7e-4).  So: the max-abs bound on all but at most two such patches, plus a relative-L2 bound that
+    # no real defect (a wrong tap, a missing term: >= 1e-1) can pass.
     d = (K.nhwc_to_nchw(dx).cpu().double() - x64.grad).abs()
-    n_off = int((d > 2e-4 * scale).sum())
-    rel_l2 = float(d.norm() / x64.grad.norm())
-    assert n_off <= 2 * 9 * cin and rel_l2 < 3e-4, (float(d.max()), scale, n_off, rel_l2)
+    n_off, rel_l2 = int((d > 2e-4 * scale).sum()), float(d.norm() / x64.grad.norm())
+    assert n_off <= 2 * 9 * cin and rel_l2 < 2e-3, (float(d.max()), scale, n_off, rel_l2)
     for name, p in unit.named_parameters():
         ref = sd64[pfx + name].grad
         got = grads[id(p)]

@@ -44,3 +44,25 @@ def test_torgb_matches_reference_module():
     want = m(x, style, mask, skip)
     got = orc.to_rgb(sd, "", x, style, mask, skip, True)
     assert float((got - want).abs().max()) < 1e-5
+
+
+def test_w_norm_loss_matches_reference_class():
+    """train.w_norm_loss == src/criteria/w_norm.py:WNormLoss (loaded by file path), value and gradient."""
+    import importlib.util
+    import os
+    from e4s_amd.train import w_norm_loss
+    sp = importlib.util.spec_from_file_location("ref_w_norm", os.path.join(ref_shim.REF if hasattr(ref_shim, "REF") else "/root/reference",
+                                                                          "src", "criteria", "w_norm.py"))
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    g = torch.Generator().manual_seed(2)
+    lat = torch.randn(2, 12, 18, 512, generator=g, requires_grad=True)
+    lat2 = lat.detach().clone().requires_grad_(True)
+    avg = torch.randn(18, 512, generator=g)
+    for flag in (True, False):
+        a = w_norm_loss(lat, avg, flag)
+        b = mod.WNormLoss(start_from_latent_avg=flag)(lat2, avg)
+        assert float((a - b).abs()) < 1e-5 * float(b.abs())
+    a.backward()
+    b.backward()
+    assert torch.allclose(lat.grad, lat2.grad)

@@ -1,6 +1,7 @@
 // tools/mfma_peak: what rate does a register-resident v_mfma_f32_32x32x16_bf16 stream sustain on this MI355X, and at what clock?
 // (VERDICT r3 "Next round" 3a: settle the ceiling the split-bf16 conv kernels are priced against.)  Standalone HIP program, no torch.
-//   mfma_peak <random|zero> <waves_per_simd 1|2|4> <nacc 4|8> <iters> <reps>
+//   mfma_peak <random|zero> <waves_per_simd 1|2|4> <nacc 1|2|4|8> <iters> <reps>     (nacc = independent accumulators per wave: the
+//   distance between two MFMAs on the same accumulator)
 // Every wave runs `iters` rounds of NACC independent accumulators x 4 (A,B) operand pairs; operands are random bf16 (or zeros) and stay in
 // registers: no LDS, no memory traffic in the loop.  Prints one JSON line: TFLOP/s from HIP events over `reps` launches, and the effective
 // shader clock = s_memtime ticks of the loop / its wall time (the guide: tick = shader cycle).
@@ -71,7 +72,7 @@ int main(int argc, char** argv) {
     unsigned long long* ticks;
     CK(hipMalloc(&out, (size_t)grid * 256 * 4));
     CK(hipMalloc(&ticks, (size_t)grid * 8));
-    void (*fn)(float*, unsigned long long*, int, int) = nacc == 8 ? mfma_loop<8> : mfma_loop<4>;
+    void (*fn)(float*, unsigned long long*, int, int) = nacc == 8 ? mfma_loop<8> : nacc == 2 ? mfma_loop<2> : nacc == 1 ? mfma_loop<1> : mfma_loop<4>;
     CK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -90,14 +91,15 @@ int main(int argc, char** argv) {
     double tk = 0;
     for (int i = 0; i < grid; ++i) tk += (double)h[i];
     tk /= grid;
-    const double nmfma = (double)grid * 4 * iters * 4 * (nacc == 8 ? 8 : 4);
+    const int na = nacc == 8 ? 8 : nacc == 2 ? 2 : nacc == 1 ? 1 : 4;
+    const double nmfma = (double)grid * 4 * iters * 4 * na;
     const double tflops = nmfma * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e12;
     // cycles per MFMA per SIMD as the wave saw them (ticks are shader cycles if s_memtime counts them; reported raw as well)
     printf("{\"operands\": \"%s\", \"waves_per_simd\": %d, \"nacc\": %d, \"iters\": %d, \"cus\": %d, \"ms_per_launch\": %.4f, \"tflops\": %.1f, "
            "\"frac_of_2500\": %.4f, \"ticks_per_launch\": %.0f, \"ticks_per_mfma_per_simd\": %.2f, \"tick_rate_ghz\": %.4f, "
            "\"implied_clock_ghz_at_32cyc_per_mfma\": %.4f}\n",
-           zero ? "zero" : "random", wps, nacc == 8 ? 8 : 4, iters, cus, ms, tflops, tflops / 2500.0, tk,
-           tk / ((double)iters * 4 * (nacc == 8 ? 8 : 4) * wps), tk / (ms * 1e-3) / 1e9,
+           zero ? "zero" : "random", wps, na, iters, cus, ms, tflops, tflops / 2500.0, tk,
+           tk / ((double)iters * 4 * na * wps), tk / (ms * 1e-3) / 1e9,
            nmfma / (cus * 4.0) * 32.0 / (ms * 1e-3) / 1e9);
     return 0;
 }
