@@ -83,7 +83,8 @@ __global__ void wino_weights_kernel(const float* __restrict__ w9, unsigned char*
 // XF: 0 plain input, 2 InstanceNorm (x - mean) * rstd folded into the input transform (zero padding applies to the NORMALISED map)
 // VAR: profiling variants (builds with -DE4S_ABLATIONS select them with env E4S_WINO_VAR; results are WRONG for VAR >= 1; product builds
 // only instantiate VAR = 0): 1 no input-transform staging, 2 no weight staging, 3 neither, 4 neither and no fragment reads (MFMAs + barriers),
-// 5 MFMAs only (no barriers), 6 everything but the MFMAs
+// 5 MFMAs only (no barriers), 6 everything but the MFMAs, 7 input items loaded but not transformed / stored, 8 transformed / stored but
+// not loaded (stale registers)
 template <int XF, int VAR = 0>
 __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p, const int ntn, const int tx_n, const int per_img,
                                                          const int ntiles) {
@@ -248,10 +249,10 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
             const unsigned char* Bb = sB + (sg & 1) * B_BYTES;
             unsigned char* Bn = sB + ((sg + 1) & 1) * B_BYTES;
             const bool more = ts < 2 || have_nc;
-            const bool storer = have_nc && ((wave - 3 * ((int)sg - 1)) & 7) < 3 && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5;
+            const bool storer = have_nc && ((wave - 3 * ((int)sg - 1)) & 7) < 3 && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5 && VAR != 7;
             const int lslot = (wave - 3 * (int)sg) & 7;
             const int lchunk = ts < 2 ? chunk + 1 : chunk + 2;
-            const bool loader = lslot < 3 && lchunk < nchunk && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5;
+            const bool loader = lslot < 3 && lchunk < nchunk && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5 && VAR != 8;
             auto ldA = [&](AF& F, int ps) {
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) {
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
             } else {
                 if (loader) item_load(((ts + 1) % 3) * 192 + lslot * 64 + lane, lchunk, I);
                 body(std::false_type{});
+                if (VAR == 7 && loader) asm volatile("" ::"v"(I.d[0]), "v"(I.d[1]), "v"(I.d[2]), "v"(I.d[3]));
             }
             if (VAR != 5) __syncthreads();
             ++sg;
@@ -425,7 +427,7 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
     int e;
 #ifdef E4S_ABLATIONS
     {
-        static std::atomic<uint64_t> mv[7];
+        static std::atomic<uint64_t> mv[9];
         const char* ev = getenv("E4S_WINO_VAR");
         const int var = ev ? atoi(ev) : 0;
         const void* fn = nullptr;
@@ -433,7 +435,7 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
               hipLaunchKernelGGL((conv_wino_kernel<0, V>), dim3((unsigned)tiles), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img, (int)tiles); \
               E4S_CHECK_LAUNCH(); return 0;
         switch (p.in_stats ? 0 : var) {
-            WV(1) WV(2) WV(3) WV(4) WV(5) WV(6)
+            WV(1) WV(2) WV(3) WV(4) WV(5) WV(6) WV(7) WV(8)
             default: break;
         }
 #undef WV

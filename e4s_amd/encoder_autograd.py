@@ -52,7 +52,11 @@ def _dgrad3x3(gz, conv, x):
         cached = getattr(conv, "_e4s_wt_fwd", None)
         if cached is None or cached[0] != key:
             wp = K.pack_taps(conv.weight.detach().float().flip(2, 3).transpose(0, 1).contiguous())      # [1,9,Cin,Cout]
-            conv._e4s_wt_fwd = cached = (key, wp, K.split_bf16x2(wp))
+            conv._e4s_wt_fwd = cached = (key, wp, K.split_bf16x2(wp), {})
+        if K.wino_eligible(b, h, w, cy, cx):       # Winograd F(2,3) form of the same convolution (csrc/conv_wino.hip): 1.5x fewer MFMAs
+            if "u" not in cached[3]:
+                cached[3]["u"] = K.wino_weights(cached[1])
+            return K.conv_wino(gz.contiguous(), cached[3]["u"], cx)
         return K.conv_mfma(gz.contiguous(), cached[1], cx, w_split=cached[2])
     dx, _ = K.conv_bwd(gz, _wt(conv), x, None, None, None, 1, 1, want_ds=False)       # x: shape only (no ds asked for)
     return dx

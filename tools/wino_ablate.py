@@ -21,9 +21,9 @@ if len(sys.argv) > 1:
     e1.record(); torch.cuda.synchronize()
     print("MS %.4f" % (e0.elapsed_time(e1) / 30))
 else:
-    names = {0: "full", 1: "no input-transform staging", 2: "no weight staging", 3: "no staging", 4: "MFMAs + barriers", 5: "MFMAs only", 6: "no MFMAs"}
+    names = {0: "full", 1: "no input-transform staging", 2: "no weight staging", 3: "no staging", 4: "MFMAs + barriers", 5: "MFMAs only", 6: "no MFMAs", 7: "items loaded, not transformed", 8: "items transformed, not loaded"}
     res = {}
-    for v in range(7):
+    for v in range(9):
         env = dict(os.environ, E4S_WINO_VAR=str(v))
         out = subprocess.run([sys.executable, __file__, "run"], env=env, capture_output=True, text=True).stdout
         ms = [l for l in out.splitlines() if l.startswith("MS ")]
