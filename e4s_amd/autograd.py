@@ -44,6 +44,18 @@ def styled_conv_backward(rec, dy, num_regions, extras=None):
         else:
             u = K.conv_mfma(gz.contiguous(), wp, cin, w_split=wps, in_scale=d)
         dx, ds = K.scale_dot(u, x, s)
+    elif labels is None and conv.upsample and x.is_contiguous() and cout % 8 == 0 and K.want_bf16x3(b, h, w, 4 * cout, cin):
+        # unmasked up-conv (model.py:287-300 backward; the 128->64->512^2 and 64->32->1024^2 layers): in polyphase form the four output
+        # phases are four 3x3 correlations over the INPUT grid, so with the phases of gz laid side by side in the channel dimension
+        # (e4s_pixel_unshuffle2_f32) the dgrad is ONE 'same' 3x3 convolution with 4*Cout input channels on the forward split-bf16 kernel:
+        # dx = s * conv(unshuffle(gz) * d, flipped Weff^T), ds from the pass that applies s.  (The exact-fp32 dx + ds kernel ran these two
+        # dgrads at ~0.5 / 1.0 ms per image: 36 multiply-adds per input pixel and channel pair on v_mfma_f32_32x32x2_f32.)
+        if "wt_up_fwd" not in pk:
+            wp = pk["w"].flip(1).permute(1, 3, 0, 2).reshape(1, 9, cin, 4 * cout).contiguous()     # [1,9,Cin,(phase,Cout)]
+            pk["wt_up_fwd"] = (wp, K.split_bf16x2(wp))
+        wp, wps = pk["wt_up_fwd"]
+        u = K.conv_mfma(K.pixel_unshuffle2(gz), wp, cin, w_split=wps, in_scale=d.repeat(1, 4).contiguous())
+        dx, ds = K.scale_dot(u, x, s)
     else:
         if "wt" not in pk:
             pk["wt"] = K.pack_taps_bwd(pk["w"])

@@ -125,6 +125,21 @@ __global__ void prelu_bwd_kernel(const float* __restrict__ dy, const float* __re
 
 // ---- strided scatters -------------------------------------------------------------------------------------------
 // out[b, y*s, x*s, c] (+)= in[b, y, x, c]; out is [B, H*s, W*s, C]; zero_fill: the other positions are set to 0
+// out[b][a][c][(py*2+px)*C + ch] = in[b][2a+py][2c+px][ch]: the four output phases of an up-sampling conv side by side in the channel
+// dimension of its input grid (the dgrad of the polyphase form is then ONE 3x3 convolution with 4*Cout input channels)
+__global__ void pixel_unshuffle2_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = C / 4;
+    const int ch = (int)(i % c4);
+    const int ph = (int)((i / c4) & 3);
+    const int64_t pix = i / (4 * c4);                      // (b, a, c) flattened
+    const int cx = (int)(pix % W);
+    const int64_t ba = pix / W;                            // b * H + a
+    const int64_t src = (((ba * 2 + (ph >> 1)) * (2 * W)) + 2 * cx + (ph & 1)) * C + ch * 4;
+    *reinterpret_cast<f32x4*>(out + (pix * 4 + ph) * C + ch * 4) = *reinterpret_cast<const f32x4*>(in + src);
+}
+
 __global__ void strided_scatter_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int s,
                                        int accumulate, int64_t n4) {
     const int C4 = C / 4;
@@ -265,6 +280,14 @@ extern "C" int e4s_prelu_bwd_f32(const float* dy, const float* u, const float* s
     hipLaunchKernelGGL(prelu_bwd_kernel, dim3((C / 64) * ns), dim3(256), 0, as_stream(stream), dy, u, slope, du, ws, npix, C, ns);
     E4S_CHECK_LAUNCH();
     return e4s_reduce_parts_f32(ws, dslope, ns, C, 1.f, stream);
+}
+
+extern "C" int e4s_pixel_unshuffle2_f32(const float* in, float* out, int B, int H, int W, int C, void* stream) {
+    if (C % 4 || B <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+    const int64_t n4 = (int64_t)B * H * W * 4 * (C / 4);
+    hipLaunchKernelGGL(pixel_unshuffle2_kernel, grid1(n4), dim3(256), 0, as_stream(stream), in, out, H, W, C, n4);
+    E4S_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int e4s_strided_scatter_f32(const float* in, float* out, int B, int H, int W, int C, int s, int accumulate,

@@ -885,6 +885,16 @@ def prelu_bwd(dy, u, slope):
     return du, dslope
 
 
+def pixel_unshuffle2(x):
+    """NHWC [B,2H,2W,C] -> [B,H,W,4C]: channel (py*2+px)*C + c of pixel (a, b) = x[2a+py, 2b+px, c]."""
+    b, h2, w2, c = x.shape
+    if h2 % 2 or w2 % 2 or c % 4:
+        raise RuntimeError("pixel_unshuffle2: even H, W and C % 4 == 0")
+    out = torch.empty(b, h2 // 2, w2 // 2, 4 * c, device=x.device, dtype=torch.float32)
+    call("e4s_pixel_unshuffle2_f32", fptr(_f32(x)), fptr(out), b, h2 // 2, w2 // 2, c, stream())
+    return out
+
+
 def strided_scatter(src, s, out=None):
     """out[b, y*s, x*s] (+)= src[b, y, x]; src NHWC [B,H,W,C].  out=None: a zero-inserted [B,H*s,W*s,C] tensor."""
     b, h, w, c = src.shape

@@ -115,6 +115,7 @@ SIGNATURES = {
     "e4s_ema_f32": [c_p, c_p, c_l, c_d, c_p],
     "e4s_adam_step_dev_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_p, c_d, c_d, c_d, c_d, c_p, c_p],
     "e4s_advance_i64": [c_p, c_l, c_p],
+    "e4s_pixel_unshuffle2_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_wino_weights_bytes": [c_i, c_i],
     "e4s_wino_weights_f32": [c_p, c_p, c_i, c_i, c_p],
     "e4s_conv_wino_covers": [c_p],

@@ -305,6 +305,10 @@ int e4s_prelu_f32(const float* u, const float* slope, float* y, int64_t npix, in
 int e4s_prelu_bwd_f32(const float* dy, const float* u, const float* slope, float* du, float* dslope, float* ws,
                       int64_t npix, int C, void* stream);
 int64_t e4s_prelu_bwd_ws_floats(int64_t npix, int C);
+/* in NHWC [B,2H,2W,C] -> out NHWC [B,H,W,4C], out[b,a,c,(py*2+px)*C + ch] = in[b,2a+py,2c+px,ch] (pixel unshuffle): lays the four output
+ * phases of an up-sampling conv side by side in the channel dimension of its input grid, so that the dgrad of the polyphase form
+ * (model.py:287-300 backward) is ONE 3x3 convolution with 4*Cout input channels on e4s_conv_bf16x3_f32.  C % 4 == 0 */
+int e4s_pixel_unshuffle2_f32(const float* in, float* out, int B, int H, int W, int C, void* stream);
 /* out[b, y*s, x*s, :] (+)= in[b, y, x, :], in NHWC [B,H,W,C], out NHWC [B,H*s,W*s,C]; without accumulate the other
  * positions are zero-filled (zero insertion: the stride-2 conv's dgrad; with accumulate: MaxPool2d(1, s)'s backward) */
 int e4s_strided_scatter_f32(const float* in, float* out, int B, int H, int W, int C, int s, int accumulate, void* stream);

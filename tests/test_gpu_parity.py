@@ -1059,6 +1059,55 @@ def test_unmasked_styled_conv_dgrad_on_the_forward_kernels_vs_oracle_f64(cin, co
     assert maxabs(dstyle.view_as(sr), sr.grad) < 3e-4 * ss and maxabs(dstyle, dstyle32) < 3e-4 * ss
 
 
+@pytest.mark.parametrize("cin,cout,res", [(128, 64, 32), (64, 32, 48), (64, 64, 16)])
+def test_unmasked_upconv_dgrad_on_the_forward_kernel_vs_oracle_f64(cin, cout, res, monkeypatch):
+    """Unmasked UP-SAMPLING StyledConv (model.py:287-300) under the split-bf16 policy: the four output phases of gz laid side by side in
+    the channel dimension (e4s_pixel_unshuffle2_f32), then dL/dx = s * conv3x3(that * d, flipped polyphase W^T) on the forward kernel +
+    e4s_scale_dot_f32 -- against the oracle's fp64 autograd of conv_transpose2d + blur, and against the exact-fp32 dx + ds kernel."""
+    from e4s_amd import kernels as K
+    from e4s_amd.autograd import styled_conv_backward
+    from e4s_amd.stylegan2 import StyledConv
+    sd = _styled_sd(cin, cout, True, 29)
+    m = StyledConv(cin, cout, 3, 512, upsample=True, mask_op=False)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(53)
+    b = 2
+    x = torch.randn(b, cin, res, res, generator=g)
+    style = torch.randn(b, 512, generator=g)
+    noise = torch.randn(b, 1, 2 * res, 2 * res, generator=g)
+    wgt = torch.randn(b, cout, 2 * res, 2 * res, generator=g)
+    xd = K.nchw_to_nhwc(x.to(DEV))
+    mod = m.conv.modulation
+    s = K.modulate_vec(style.to(DEV), mod.weight, mod.bias)
+    # pixel unshuffle by itself, bit for bit against the torch view
+    t = torch.randn(2, 6, 10, 8, generator=g).to(DEV)
+    assert torch.equal(K.pixel_unshuffle2(t), t.view(2, 3, 2, 5, 2, 8).permute(0, 1, 3, 2, 4, 5).reshape(2, 3, 5, 32))
+    monkeypatch.setattr(K, "PRECISION", "f32")           # one forward for both backward paths (see the same-resolution test)
+    rec = {}
+    y = m.run_nhwc(xd, s, noise.to(DEV), None, 1, rec=rec)
+    rec.update(layer=m, x=xd, y=y, s=s, labels=None)
+
+    def run(prec):
+        monkeypatch.setattr(K, "PRECISION", prec)
+        dx, ds = styled_conv_backward(rec, K.nchw_to_nhwc(wgt.to(DEV)), 1, {})
+        return K.nhwc_to_nchw(dx), (ds @ mod.weight.detach()) * mod.scale
+
+    dx, dstyle = run("bf16x3")
+    dx32, dstyle32 = run("f32")
+    f64 = torch.float64
+    sd64 = {k: v.to(f64) for k, v in sd.items()}
+    xr = x.to(f64).requires_grad_(True)
+    sr = style.to(f64).requires_grad_(True)
+    yr = orc.styled_conv(sd64, "", xr, sr, None, noise.to(f64), True, False)
+    (yr * wgt.to(f64)).sum().backward()
+    gs, ss = float(xr.grad.abs().max()), float(sr.grad.abs().max())
+    assert maxabs(dx, xr.grad) < 1e-4 * gs, ("split-bf16 forward-kernel up-conv dgrad", maxabs(dx, xr.grad), gs)
+    assert maxabs(dx32, xr.grad) < 1e-4 * gs, ("exact fp32 dx + ds kernel", maxabs(dx32, xr.grad), gs)
+    assert 0 < maxabs(dx, dx32)                                   # another kernel, the same gradient
+    assert maxabs(dstyle.view_as(sr), sr.grad) < 3e-4 * ss and maxabs(dstyle, dstyle32) < 3e-4 * ss
+
+
 @pytest.mark.parametrize("cin,res,masked,with_skip", [(512, 8, True, True), (128, 32, False, True), (512, 4, True, False),
                                                        (32, 32, False, True)])
 def test_torgb_backward_vs_oracle_f64(cin, res, masked, with_skip):

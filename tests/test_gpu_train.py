@@ -77,7 +77,7 @@ def test_encoder_unit_backward_vs_oracle_f64(cin, depth, stride, res, prec, monk
             continue
         # (the same kink flips touch the 9 x Cin weights of ONE output channel of conv1 and that channel's PReLU slope)
         dd = (got.detach().cpu().double() - ref).abs()
-        assert int((dd > 3e-4 * s).sum()) <= 2 * 9 * cin + 2 and float(dd.norm() / ref.norm()) < 2e-3, \
+        assert int((dd > 3e-4 * s).sum()) <= 2 * 9 * cin + 2 and float(dd.norm() / ref.norm()) < 5e-3, \
             (name, float(dd.max()), s, int((dd > 3e-4 * s).sum()), float(dd.norm() / ref.norm()))
 
 

@@ -66,3 +66,19 @@ def test_w_norm_loss_matches_reference_class():
     a.backward()
     b.backward()
     assert torch.allclose(lat.grad, lat2.grad)
+
+
+def test_reference_itself_fails_on_the_branches_net3_refuses():
+    """e4s_amd.networks.Net3.cal_style_codes raises NotImplementedError for start_from_latent_avg=False and learn_in_w=True; so does the
+    reference, less politely (networks.py:145-158: `style_codes` is never assigned; a [bs,R,512] tensor is added to [bs,R,K,512] codes)."""
+    sd = synth.synth_state_dict(256, 13)
+    lat = synth.synth_latent_avg(256)
+    net = ref_shim.build_reference_net3(sd, lat, 256, 13)
+    sv = torch.randn(1, 12, 1280)
+    net.opts.start_from_latent_avg = False
+    with pytest.raises(UnboundLocalError):
+        net.cal_style_codes(sv)
+    net.opts.start_from_latent_avg, net.opts.learn_in_w = True, True
+    net.latent_avg = lat[:1].repeat(1, 1)                 # coach.py:118-119
+    with pytest.raises(RuntimeError):
+        net.cal_style_codes(sv)
