@@ -30,14 +30,23 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int NTHR = 512, BM = 256, BN = 128, TW = 16, TH = 16, HALO_W = TW + 2, HALO = (TH + 2) * HALO_W;
 constexpr int KC = 16;                    // input channels per chunk
-constexpr int ROWB = 80, LO = 32;         // LDS row: 16 hi bf16 | 16 lo bf16 | 16 B pad (16 consecutive rows hit 64 distinct banks)
-constexpr int VMAX = 256, NROW = HALO + VMAX;
+// LDS rows are 64 bytes [16 hi bf16 | 16 lo bf16], UNPADDED; the 16-byte granule index is XORed with (row >> 2) & 3 (round 4; the 80-byte
+// rows of round 3 ran at 37-39 % bank-conflict cycles).  A halo pixel (hy, hx) lives in row hy * 32 + hx: the two 16-lane halves of an
+// MFMA row tile (pixels of two image rows) are then 32 rows apart, so the 16 lanes of every ds_read_b128 group touch 16 different residues
+// mod 16 = 16 different (bank quad, swizzle) pairs for any tap shift -- own-row fragment reads are conflict free.  The 14 unused slots of
+// each 32-row stripe hold the variant rows (18 x 14 = 252 of them).
+constexpr int ROWB = 64, HSTR = 32, VSLOT = HSTR - HALO_W;
+constexpr int VMAX = (TH + 2) * VSLOT, NROW = (TH + 2) * HSTR;
 constexpr int TPS = 3, NSTG = 3;          // taps per stage, stages per chunk
 constexpr int WN = 2, WM = 4, TM = 2, TN = 2;
 constexpr int A_BYTES = NROW * ROWB, B_BYTES = TPS * BN * ROWB;
 constexpr int BJ = TPS * BN * 4 / NTHR;   // 16-byte weight pieces per thread and stage (= 3: one per tap)
 constexpr int MAXR = 16;
-static_assert(BJ == TPS && 2 * NROW <= NSTG * NTHR, "staging split");
+static_assert(BJ == TPS && 2 * (HALO + VMAX) <= NSTG * NTHR, "staging split");
+
+__device__ __forceinline__ int swz(int row, int g) { return row * ROWB + ((g ^ ((row >> 2) & 3)) << 4); }
+__device__ __forceinline__ int halo_row(int h) { return (h / HALO_W) * HSTR + h % HALO_W; }          // LDS row of halo pixel h
+__device__ __forceinline__ int var_row(int v) { return (v / VSLOT) * HSTR + HALO_W + v % VSLOT; }    // LDS row of variant row v
 
 constexpr int OFF_B = 2 * A_BYTES;
 constexpr int OFF_OUT = OFF_B + 2 * B_BYTES;        // int   [BM]    output pixel offset or -1
@@ -59,7 +68,7 @@ __device__ __forceinline__ f32x8 load8(const float* src) {
 }
 
 // a = x * s as hi + lo bf16: hi = rne(x s) (packed convert, re-expanded with a shift / a mask), lo = rne(fma(x, s, -hi))
-__device__ __forceinline__ void scale_split_store(unsigned char* dst, const f32x8 x, const f32x8 s) {
+__device__ __forceinline__ void scale_split_store(unsigned char* dst, unsigned char* dst_lo, const f32x8 x, const f32x8 s) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -78,7 +87,7 @@ __device__ __forceinline__ void scale_split_store(unsigned char* dst, const f32x
         res[2 * j + 1] = r[1];
     }
     *reinterpret_cast<u32x4*>(dst) = hp;
-    *reinterpret_cast<bf16x8*>(dst + LO) = __builtin_convertvector(res, bf16x8);
+    *reinterpret_cast<bf16x8*>(dst_lo) = __builtin_convertvector(res, bf16x8);
 }
 
 __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_params p, const unsigned char* __restrict__ w16,
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
     // weight piece of this thread in a tap's 8 KB run: column tid / 4, 16-byte piece tid % 4
     const size_t wtap = (size_t)nchunk_all * p.Cout * 64, wchunk = (size_t)p.Cout * 64;
     const unsigned char* wb = w16 + ((size_t)cls * 9 * nchunk_all * p.Cout + n0) * 64 + (size_t)c_lo * wchunk + (size_t)tid * 16;
-    const int b_dst = (tid >> 2) * ROWB + (tid & 3) * 16;
+    const int b_dst = swz(tid >> 2, tid & 3);
 
     // ---- loads that do not depend on the label map, issued before the tile analysis so that its two dependent global round trips
     // (labels, then styles) overlap them: stage 0's weights, the x of the own rows among staging items 0 / 1, the d table ----
@@ -242,13 +251,13 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
         for (int tap = 0; tap < 9; ++tap) {
             const int h = (my + tap / 3) * HALO_W + mx + tap % 3;
             const unsigned lab = s_lab[h];
-            int row = h;
-            if (valid && lab != 0xFFu && lab != r) row = HALO + s_base[h] + __popc(s_need[h] & ((1u << r) - 1u));
-            ro[tm][tap] = row * ROWB + kh * 16;
+            int row = halo_row(h);
+            if (valid && lab != 0xFFu && lab != r) row = var_row(s_base[h] + __popc(s_need[h] & ((1u << r) - 1u)));
+            ro[tm][tap] = swz(row, kh);
         }
     }
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) brow[tn] = ((wn * TN + tn) * 32 + li) * ROWB + kh * 16;
+    for (int tn = 0; tn < TN; ++tn) brow[tn] = swz((wn * TN + tn) * 32 + li, kh);
 
     // staging item i of a chunk (fetched during stage i of the previous chunk): LDS row j = (tid + NTHR i) / 2, 8-channel half q
     int a_src[NSTG], a_sty[NSTG], a_dst[NSTG];
@@ -268,19 +277,20 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
         a_dst[i] = -1;
         a_src[i] = a_sty[i] = 0;
         if (h >= 0) {
+            const int lrow = j < HALO ? halo_row(j) : var_row(j - HALO);
             if (r == 0xFFu) {                          // outside the image: zero rows, written once
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int b2 = 0; b2 < 2; ++b2) {
-                    *reinterpret_cast<f32x4*>(sA + b2 * A_BYTES + j * ROWB + q * 16) = z;
-                    *reinterpret_cast<f32x4*>(sA + b2 * A_BYTES + j * ROWB + q * 16 + LO) = z;
+                    *reinterpret_cast<f32x4*>(sA + b2 * A_BYTES + swz(lrow, q)) = z;
+                    *reinterpret_cast<f32x4*>(sA + b2 * A_BYTES + (swz(lrow, q) ^ 32)) = z;
                 }
             } else {
                 const int hy = h / HALO_W, hx = h - hy * HALO_W;
                 const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
                 a_src[i] = (iy * p.Wi + ix) * p.Cin + q * 8;
                 a_sty[i] = (int)r * p.Cin + q * 8;
-                a_dst[i] = j * ROWB + q * 16;
+                a_dst[i] = swz(lrow, q);
             }
         }
     }
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
         if (a_dst[i] >= 0) {
             const bool early = i == 0 || (i == 1 && tid < 2 * (HALO - NTHR / 2));        // own rows fetched above
             const f32x8 x = early ? xe[i < 2 ? i : 0] : load8(xb + a_src[i]);
-            scale_split_store(sA + a_dst[i], x, load8(stab + a_sty[i]));
+            scale_split_store(sA + a_dst[i], sA + (a_dst[i] ^ 32), x, load8(stab + a_sty[i]));
         }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(sB + j * BN * ROWB + b_dst) = pb0[j];
@@ -337,14 +347,13 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     F.h[tn] = *reinterpret_cast<const bf16x8*>(Bt + brow[tn]);
-                    F.l[tn] = *reinterpret_cast<const bf16x8*>(Bt + brow[tn] + LO);
+                    F.l[tn] = *reinterpret_cast<const bf16x8*>(Bt + (brow[tn] ^ 32));
                 }
             };
             auto ldA = [&](AFrag& F, int g) {
                 const int u = g / TM, tm = g - u * TM;
-                const unsigned char* At = Ab + ro[tm][ts * TPS + u];
-                F.h = *reinterpret_cast<const bf16x8*>(At);
-                F.l = *reinterpret_cast<const bf16x8*>(At + LO);
+                F.h = *reinterpret_cast<const bf16x8*>(Ab + ro[tm][ts * TPS + u]);
+                F.l = *reinterpret_cast<const bf16x8*>(Ab + (ro[tm][ts * TPS + u] ^ 32));
             };
             auto mfmas = [&](const AFrag& A, const BFrag& B, int tm) {
 #pragma unroll
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
 #pragma unroll
                 for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(db + j * BN * ROWB) = pb[j];
             }
-            if (a_on) scale_split_store(An + a_dst[ts], pax, pas);
+            if (a_on) scale_split_store(An + a_dst[ts], An + (a_dst[ts] ^ 32), pax, pas);
             __syncthreads();
             ++sg;
         }
@@ -464,7 +473,7 @@ __global__ void split16_kernel(const float* __restrict__ w, unsigned char* __res
     const bf16x8 l = __builtin_convertvector(r, bf16x8);
     unsigned char* dst = out + (((size_t)row * nch + c) * cout + co) * 64 + q * 16;
     *reinterpret_cast<bf16x8*>(dst) = h;
-    *reinterpret_cast<bf16x8*>(dst + LO) = l;
+    *reinterpret_cast<bf16x8*>(dst + 32) = l;
 }
 
 }  // namespace
