@@ -15,9 +15,9 @@
 // that needs more than VMAX = 256 is left to the region-select kernel (flag table + a second, filtered launch).
 //
 // K step: 16 input channels (one v_mfma_f32_32x32x16_bf16 k-step per tap), three taps per pipeline stage, so the halo + variants
-// double-buffer in 2 x 46 KB and the weights in 2 x 30 KB.  Weights come pre-split in the [tap][Cin/16][Cout][16 hi | 16 lo]
-// layout of e4s_split16_bf16x2_f32: a stage's B tile is three contiguous 8 KB runs.
-// Block = 512 threads = 4 x 2 waves of 64 x 64, tile 256 pixels x 128 output channels, one block per CU (156 KB of LDS).
+// double-buffer in 2 x 36 KB and the weights in 2 x 24 KB (64-byte swizzled rows, see ROWB below).  Weights come pre-split in the
+// [tap][Cin/16][Cout][16 hi | 16 lo] layout of e4s_split16_bf16x2_f32: a stage's B tile is three contiguous 8 KB runs.
+// Block = 512 threads = 4 x 2 waves of 64 x 64, tile 256 pixels x 128 output channels, one block per CU (128 KB of LDS).
 #include "common.h"
 
 int e4s_launch_region_select(const e4s_conv_params& p, const int* only_flagged, hipStream_t st);      // conv_bf16x3.hip

@@ -67,6 +67,83 @@ __global__ void conv3x3_small_kernel(const float* __restrict__ x, const float* _
     }
 }
 
+// ---- stem conv, tiled form (round 4): Cin = 3 -> Cout = 64 on 16x16-pixel tiles.  The 18x18x3 halo sits in LDS as float4 pixels, each
+// thread keeps the 27 x 4 weights of its 4 output channels in REGISTERS and walks one tile row: per pixel 9 broadcast ds_read_b128 +
+// 108 FMAs + one 16-byte store (the 16 lanes of a pixel write its 64 channels as 256 contiguous bytes).  stats_ws != NULL: per-(sample,
+// channel, tile) fp64 {sum, sum of squares} of the output in the slot layout of the conv kernels' fused statistics
+// (e4s_instnorm_finalize_f32 adds the slots in order) -- the separate statistics pass over the 268 MB stem output of a batch of 16
+// disappears.  The grid-stride kernel above (weights broadcast from LDS, x from global, 27 + 27 loads per 4 outputs) took 0.25 ms for
+// that batch, 4x its store time.
+__global__ __launch_bounds__(256) void conv3x3_stem_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                           double* __restrict__ stats_ws, int H, int W, int tx_n, int per_img) {
+    __shared__ f32x4 sx[18 * 18];
+    __shared__ double sred[2][16][64];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / per_img, rem = blockIdx.x - b * per_img;
+    const int tyb = rem / tx_n, txb = rem - tyb * tx_n;
+    const int y0 = tyb * 16, x0 = txb * 16;
+    for (int h = tid; h < 324; h += 256) {
+        const int hy = h / 18, hx = h - hy * 18;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            const float* xp = x + (((int64_t)b * H + iy) * W + ix) * 3;
+            v = f32x4{xp[0], xp[1], xp[2], 0.f};
+        }
+        sx[h] = v;
+    }
+    const int g = tid & 15, py = tid >> 4;               // 4 output channels 4g .. 4g+3, tile row py
+    f32x4 wr[27];                                        // wr[(ky*3+kx)*3 + ci][j] = w[4g + j][ci][ky][kx]   (w is [64][3][3][3])
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wr[k * 3 + ci][j] = w[((4 * g + j) * 3 + ci) * 9 + k];
+    __syncthreads();
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    float* yrow = y + (((int64_t)b * H + y0 + py) * W + x0) * 64 + 4 * g;
+#pragma unroll 4
+    for (int px = 0; px < 16; ++px) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 v = sx[(py + ky) * 18 + px + kx];
+                const int k = (ky * 3 + kx) * 3;
+                acc += v[0] * wr[k] + v[1] * wr[k + 1] + v[2] * wr[k + 2];
+            }
+        *reinterpret_cast<f32x4*>(yrow + (int64_t)px * 64) = acc;
+        if (stats_ws) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[j] += (double)acc[j];
+                q[j] += (double)acc[j] * (double)acc[j];
+            }
+        }
+    }
+    if (stats_ws) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sred[0][py][4 * g + j] = s[j];
+            sred[1][py][4 * g + j] = q[j];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {               // tile rows in order: the statistics do not depend on thread timing
+                a += sred[0][r][tid];
+                c += sred[1][r][tid];
+            }
+            double* slot = stats_ws + (((int64_t)b * 64 + tid) * per_img + rem) * 2;
+            slot[0] = a;
+            slot[1] = c;
+        }
+    }
+}
+
 // ---- InstanceNorm statistics: single pass, fp64 partial sums (no cancellation in E[x^2]-mean^2),
 // pixels split over blockIdx.z so the 64-channel early layers still fill the chip ----------------
 __global__ void instnorm_partial_kernel(const float* __restrict__ x, double* __restrict__ ws, int HW, int C, int nsplit) {
@@ -498,6 +575,17 @@ extern "C" int e4s_conv3x3_small_f32(const float* x, const float* w, float* y, i
     int64_t nblk = (n + 255) / 256;
     if (nblk > 4096) nblk = 4096;
     hipLaunchKernelGGL(conv3x3_small_kernel, dim3((unsigned)nblk), dim3(256), smem, as_stream(stream), x, w, y, B, H, W, Cin, Cout);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_conv3x3_stem_f32(const float* x, const float* w, float* y, double* stats_ws, int B, int H, int W, int Cin, int Cout,
+                                    void* stream) {
+    if (!x || !w || !y || Cin != 3 || Cout != 64 || H % 16 || W % 16 || B <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+    const int tx_n = W / 16, per_img = (H / 16) * tx_n;
+    const int64_t blocks = (int64_t)B * per_img;
+    if (blocks >= (1ll << 31)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv3x3_stem_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, w, y, stats_ws, H, W, tx_n, per_img);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -154,8 +154,7 @@ class FSEncoder_PSP(Module):
 
     def encode_nhwc(self, x256, labels, num_regions):
         """x256: NHWC [B,256,256,3]; labels uint8 [B,Hm,Wm].  Returns codes [B,R,1280]."""
-        x = K.conv3x3_small(x256, self.input_layer[0].weight)
-        st, _ = K.instnorm_stats(x)
+        x, st = K.conv3x3_small(x256, self.input_layer[0].weight, want_stats=True)      # statistics from the stem's own epilogue
         x, st_x = K.instnorm_apply(x, st, slope=self.input_layer[2].weight, want_stats=True)
         b = x.shape[0]
         codes = torch.empty(b, num_regions, 256 + 512 + 512, device=x.device, dtype=torch.float32)

@@ -651,11 +651,25 @@ def resize_bilinear_to_nhwc(x, ho, wo):
     return y
 
 
-def conv3x3_small(x, w):
+def conv3x3_small(x, w, want_stats=False):
+    """Stem conv (3x3, pad 1, tiny Cin): x NHWC [B,H,W,Cin], w [Cout,Cin,3,3] -> NHWC [B,H,W,Cout].  Cin = 3, Cout = 64 on maps that are
+    multiples of 16 run on the tiled kernel (e4s_conv3x3_stem_f32); want_stats: (y, InstanceNorm statistics of y [B,Cout,2]), emitted by
+    that kernel's epilogue where it applies, by e4s_instnorm_stats_f32 otherwise."""
     b, h, wd, cin = x.shape
     cout = w.shape[0]
     y = torch.empty(b, h, wd, cout, device=x.device, dtype=torch.float32)
+    if cin == 3 and cout == 64 and h % 16 == 0 and wd % 16 == 0:
+        slots = (h // 16) * (wd // 16)
+        fused = torch.empty(b * cout * slots * 2, device=x.device, dtype=torch.float64) if want_stats else None
+        call("e4s_conv3x3_stem_f32", fptr(x), fptr(_f32(w)), fptr(y), ptr(fused), b, h, wd, cin, cout, stream())
+        if not want_stats:
+            return y
+        stats = torch.empty(b, cout, 2, device=x.device, dtype=torch.float32)
+        call("e4s_instnorm_finalize_f32", ptr(fused), fptr(stats), None, b, h * wd, cout, slots, 1e-5, stream())
+        return y, stats
     call("e4s_conv3x3_small_f32", fptr(x), fptr(w), fptr(y), b, h, wd, cin, cout, stream())
+    if want_stats:
+        return y, instnorm_stats(y)[0]
     return y
 
 

@@ -132,6 +132,7 @@ SIGNATURES = {
     "e4s_const_input_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_resize_bilinear_f32": [c_p, c_p] + [c_i] * 6 + [c_p],
     "e4s_conv3x3_small_f32": [c_p, c_p, c_p] + [c_i] * 5 + [c_p],
+    "e4s_conv3x3_stem_f32": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_p],
     "e4s_instnorm_stats_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "e4s_instnorm_finalize_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "e4s_instnorm_apply_stats_f32": [c_p] * 9 + [c_i] * 5 + [c_p],

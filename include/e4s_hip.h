@@ -472,6 +472,10 @@ int e4s_const_input_f32(const float* x, float* y, int B, int C, int H, int W, vo
 int e4s_resize_bilinear_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
 /* direct 3x3 conv for tiny Cin (input layer 3->64): x NHWC [B,H,W,Cin], w [Cout,Cin,3,3] (reference layout) */
 int e4s_conv3x3_small_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout, void* stream);
+/* the same stem conv on 16x16-pixel tiles for Cin = 3, Cout = 64, H % 16 == W % 16 == 0 (anything else: hipErrorInvalidValue): halo in
+ * LDS, weights in registers; stats_ws != NULL: also the per-(sample, channel, tile) fp64 {sum, sum^2} slots of the OUTPUT
+ * ((H/16)*(W/16) slots per (b, c): B * 64 * slots * 2 doubles) for e4s_instnorm_finalize_f32 */
+int e4s_conv3x3_stem_f32(const float* x, const float* w, float* y, double* stats_ws, int B, int H, int W, int Cin, int Cout, void* stream);
 /* InstanceNorm2d statistics (biased var, eps): stats[b, c] = {mean, rstd}; x NHWC [B,HW,C].
  * pooled (optional) [B,C] = spatial mean of the normalised tensor (what SEModule's avg-pool sees).
  * ws: scratch of e4s_instnorm_ws_doubles(B, HW, C) doubles: fp64 partial sums, one slot per (b, c, pixel split), added

@@ -1417,3 +1417,26 @@ def test_mapping_network_native_vs_module_chain():
     wg = g.get_latent(zg)                                          # differentiable path: the module chain
     assert wg.requires_grad and maxabs(wg, x) < 1e-4 * float(x.abs().max())
     assert tuple(g.mean_latent(64).shape) == (1, 512)
+
+
+@pytest.mark.parametrize("b,h,w", [(2, 256, 256), (3, 112, 112), (1, 16, 48)])
+def test_tiled_stem_conv_and_its_fused_statistics(b, h, w):
+    """e4s_conv3x3_stem_f32 (Cin 3 -> Cout 64 on 16x16 tiles, weights in registers) vs F.conv2d in fp64, its fused InstanceNorm statistics
+    vs the separate statistics pass, and == the grid-stride kernel e4s_conv3x3_small_f32 to rounding (same products, another order)."""
+    import torch.nn.functional as F
+    from e4s_amd import kernels as K
+    from e4s_amd import lib
+    g = torch.Generator().manual_seed(h + b)
+    x = torch.randn(b, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 3, 3, generator=g) * 0.3
+    xd = K.nchw_to_nhwc(x.to(DEV))
+    y, st = K.conv3x3_small(xd, wt.to(DEV), want_stats=True)
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    assert maxabs(K.nhwc_to_nchw(y), ref) < 2e-6 * float(ref.abs().max())
+    st_sep, _ = K.instnorm_stats(y)
+    assert maxabs(st[..., 0], st_sep[..., 0]) < 1e-6 and maxabs(st[..., 1], st_sep[..., 1]) < 1e-5 * float(st_sep[..., 1].max())
+    assert maxabs(st[..., 0], ref.mean((2, 3))) < 1e-5
+    y_old = torch.empty_like(y)
+    lib.call("e4s_conv3x3_small_f32", lib.fptr(xd), lib.fptr(wt.to(DEV)), lib.fptr(y_old), b, h, w, 3, 64, lib.stream())
+    assert maxabs(y, y_old) < 2e-6 * float(ref.abs().max())
+    assert torch.equal(y, K.conv3x3_small(xd, wt.to(DEV)))
