@@ -44,7 +44,7 @@ constexpr int BN = 128, KC = 16, ROWB = 64;
 constexpr int A_PLANE = VROWS * ROWB, A_BYTES = 4 * A_PLANE;        // 36 864
 constexpr int B_PLANE = BN * ROWB, B_BYTES = 4 * B_PLANE;           // 32 768
 constexpr int NITEMS = VROWS * 4;                                   // 576 (V-pixel, 4-channel group) items per chunk
-constexpr int SMEM_WINO = 2 * A_BYTES + 2 * B_BYTES + 2 * BN * 2 * 8;
+constexpr int SMEM_WINO = 2 * A_BYTES + 2 * B_BYTES + 2 * BN * 2 * 8;       // + Cin * 8 bytes of {mean, rstd} when XF == 2 (launcher)
 
 __device__ __forceinline__ int swz(int row, int g) { return row * ROWB + ((g ^ ((row >> 2) & 3)) << 4); }
 
@@ -92,6 +92,8 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     unsigned char* sA = smem;                                  // [2][4 pos][144][64]
     unsigned char* sB = smem + 2 * A_BYTES;                    // [2][4 pos][128][64]
     double* s_st = reinterpret_cast<double*>(sB + 2 * B_BYTES);      // [2 wm][BN][2]
+    float* s_in = reinterpret_cast<float*>(s_st + 2 * BN * 2);       // XF == 2: [Cin][{mean, rstd}] of this sample (read at transform time:
+                                                                     // an item does not carry its statistics across the stage boundary)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     // ---- input-transform items ----
     struct Item {
         f32x4 d[4];
-        f32x4 s0, s1;        // XF == 2: {mean, rstd} of channels c..c+1 / c+2..c+3 interleaved
+        f32x4 s0, s1;        // XF == 2: {mean, rstd} of channels c..c+1 / c+2..c+3 interleaved (filled by item_prep from LDS)
         int dst;             // byte offset of the hi half inside a position plane
         unsigned okmask;     // bit i: d[i] is inside the image
     };
@@ -131,17 +133,17 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
             const size_t off = ok ? ((size_t)iy * p.Wi + ix) * p.Cin + c : (size_t)c;
             I.d[i] = *reinterpret_cast<const f32x4*>(xb + off);
         }
-        if (XF == 2) {
-            const float* st = p.in_stats + ((size_t)tb * p.Cin + c) * 2;
-            I.s0 = *reinterpret_cast<const f32x4*>(st);
-            I.s1 = *reinterpret_cast<const f32x4*>(st + 4);
-        }
         I.dst = swz(v, cq >> 1) + (cq & 1) * 8;
     };
     // padded pixels -> 0 (XF == 2: 0 in the NORMALISED map, i.e. the mean); done once per item, before the per-position parts
-    auto item_prep = [&](Item& I) {
+    auto item_prep = [&](Item& I, int it, int chunk) {      // (it & 3 == lane & 3 for every item a lane ever holds)
         f32x4 fill = {0.f, 0.f, 0.f, 0.f};
-        if (XF == 2) fill = f32x4{I.s0[0], I.s0[2], I.s1[0], I.s1[2]};
+        if (XF == 2) {
+            const int coff = (chunk * KC + (it & 3) * 4) * 2;
+            I.s0 = *reinterpret_cast<const f32x4*>(s_in + coff);
+            I.s1 = *reinterpret_cast<const f32x4*>(s_in + coff + 4);
+            fill = f32x4{I.s0[0], I.s0[2], I.s1[0], I.s1[2]};
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (!(I.okmask & (1u << i))) I.d[i] = fill;
@@ -178,20 +180,15 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     // the LDS image is lane-linear, so the XOR swizzle goes on the SOURCE granule: lane -> row (lane >> 2), granule (lane & 3) ^ f(row) ----
     const size_t u_pos = (size_t)p.Cout * ROWB;                          // bytes per position plane in global memory
     auto u_stage = [&](int ky, int chunk) -> size_t { return ((size_t)ky * nchunk + chunk) * 4 * u_pos; };
-    size_t g_src[4];
-    int g_dst[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int q = wave * 4 + jj, ps = q >> 3, blk = q & 7;
-        const int row = blk * 16 + (lane >> 2);
-        g_src[jj] = ps * u_pos + (size_t)(n0 + row) * ROWB + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
-        g_dst[jj] = ps * B_PLANE + blk * 1024;
-    }
+    // (q >> 3 = wave >> 1 and (row >> 2) & 3 = (lane >> 4) & 3 for all four jj: the four pieces are 1 KB apart on both sides)
+    const int q0 = wave * 4, ps0 = q0 >> 3, blk0 = q0 & 7, row0 = blk0 * 16 + (lane >> 2);
+    const size_t g_src0 = ps0 * u_pos + (size_t)(n0 + row0) * ROWB + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    const int g_dst0 = ps0 * B_PLANE + blk0 * 1024;
     auto glds_stage = [&](unsigned char* Bdst, size_t stage_off) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + stage_off + g_src[jj]),
-                                             (__attribute__((address_space(3))) void*)(Bdst + g_dst[jj]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + stage_off + g_src0 + jj * 1024),
+                                             (__attribute__((address_space(3))) void*)(Bdst + g_dst0 + jj * 1024), 16, 0, 0);
     };
 
     // Roles of a wave in stage sg (global stage counter): LOADER: (wave - 3 sg) & 7 < 3 fetches 64 items of the V group this stage feeds;
@@ -201,6 +198,11 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     Item I;
     I.dst = 0;
     I.okmask = 0;
+    if (XF == 2) {
+        const float* st = p.in_stats + (size_t)tb * p.Cin * 2;
+        for (int i = tid * 4; i < p.Cin * 2; i += NTHR * 4) *reinterpret_cast<f32x4*>(s_in + i) = *reinterpret_cast<const f32x4*>(st + i);
+        __syncthreads();
+    }
     // ---- prologue: V of chunk 0 (all threads), U of stage 0, and the loads of group 0 of chunk 1 for the storers of stage 0 ----
     {
         Item I0, I1;
@@ -208,11 +210,11 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
         const bool two = tid + NTHR < NITEMS;
         if (two) item_load(tid + NTHR, 0, I1);
         glds_stage(sB, u_stage(0, 0));
-        item_prep(I0);
+        item_prep(I0, tid, 0);
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) item_part(sA, I0, ps);
         if (two) {
-            item_prep(I1);
+            item_prep(I1, tid + NTHR, 0);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) item_part(sA, I1, ps);
         }
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                 if (VAR == 4 || VAR == 5) { A1 = A0; B1 = B0; }
                 // the storer consumes last stage's plain loads FIRST: with an LDS-DMA in flight hipcc waits vmcnt(0) at the next use of
                 // any plain load, which would also wait for the DMA issued a moment ago
-                if (STORE) item_prep(I);
+                if (STORE) item_prep(I, lane, chunk + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (more && (VAR < 2 || VAR == 6)) {
                     const int ky_w = ts < 2 ? ts + 1 : 0, ch_w = ts < 2 ? chunk : chunk + 1;
@@ -442,9 +444,10 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
     }
 #endif
     if (p.in_stats) {
-        if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<2>, SMEM_WINO, m2))) return e;
-        hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)tiles), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img,
-                           (int)tiles);
+        if (p.Cin > 1024) return (int)hipErrorInvalidValue;                    // the {mean, rstd} table has 8 KB of LDS
+        if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<2>, SMEM_WINO + 8192, m2))) return e;
+        hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)tiles), dim3(NTHR), SMEM_WINO + p.Cin * 8, as_stream(stream), p, ntn, tx_n,
+                           per_img, (int)tiles);
     } else {
         if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<0>, SMEM_WINO, m0))) return e;
         hipLaunchKernelGGL(conv_wino_kernel<0>, dim3((unsigned)tiles), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img,
