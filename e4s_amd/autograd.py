@@ -24,9 +24,12 @@ def styled_conv_backward(rec, dy, num_regions, extras=None):
     layer = rec["layer"]
     conv, act = layer.conv, layer.activate
     y, s, d, labels = rec["y"], rec["s"], rec["d"], rec["labels"]
-    gz = K.fused_bias_act(dy, None, y, 3, 1, act.negative_slope, act.scale)     # lrelu'(y) * sqrt(2) * dy
-    dd = K.demod_grad(gz, y, rec["noise"], layer.noise.weight, act.bias, act.negative_slope, act.scale, labels,
-                      num_regions) / d                                          # dL/dd  (out_pre = d * c)
+    fused = K.act_bwd_demod(dy, y, rec["noise"], layer.noise.weight, act.bias, act.negative_slope, act.scale, labels, num_regions)
+    if fused is not None:                  # gz = lrelu'(y) * sqrt(2) * dy and d * dL/dd (out_pre = d * c) in one pass over dy and y
+        gz, dd_d = fused
+    else:
+        gz = K.fused_bias_act(dy, None, y, 3, 1, act.negative_slope, act.scale)
+        dd_d = K.demod_grad(gz, y, rec["noise"], layer.noise.weight, act.bias, act.negative_slope, act.scale, labels, num_regions)
     pk = conv.packed()
     x = rec["x"]
     b, h, w, cin = x.shape
@@ -60,8 +63,8 @@ def styled_conv_backward(rec, dy, num_regions, extras=None):
         if "wt" not in pk:
             pk["wt"] = K.pack_taps_bwd(pk["w"])
         dx, ds = K.conv_bwd(gz, pk["wt"], x, s, d, labels, num_regions, 4 if conv.upsample else 1)
-    # d = scale * rsqrt(scale^2 sum_ci s^2 Wsq + eps)  =>  dd/ds_ci = -d^3 s_ci Wsq[co,ci]
-    dd3 = dd * d * d * d
+    # d = scale * rsqrt(scale^2 sum_ci s^2 Wsq + eps)  =>  dd/ds_ci = -d^3 s_ci Wsq[co,ci];  dL/dd = dd_d / d, so dL/dd * d^3 = dd_d * d^2
+    dd3 = dd_d * (d * d)
     # ds - s * (dd3 @ Wsq): the [G,Cout] x [Cout,Cin] contraction on e4s_grouped_linear_t_f32 with the combine fused
     ds = K.grouped_linear_t(dd3.unsqueeze(1), pk["wsq"].unsqueeze(0), -1.0, base=ds.unsqueeze(1),
                             mul=s.unsqueeze(1)).squeeze(1)

@@ -1038,6 +1038,28 @@ def scale_dot(u, x, s):
     return u, ds
 
 
+def act_bwd_demod(dy, y, noise, noise_w, bias, alpha, gain, labels, num_regions):
+    """(gz, dd): gz = dy * lrelu'(y) * gain (fused_bias_act(dy, None, y, 3, 1, alpha, gain)) and dd = demod_grad(gz, y, ...) in ONE pass
+    over dy and y (e4s_act_bwd_demod_f32); None when the channel count is outside the kernel's set."""
+    b, h, w, c = dy.shape
+    if c % 4 or c > 1024 or c < 4 or 256 % (c // 4) or not dy.is_contiguous() or not y.is_contiguous():
+        return None
+    r = num_regions if labels is not None else 1
+    gz = torch.empty_like(dy)
+    dd = torch.empty(b * r, c, device=dy.device, dtype=torch.float32)
+    hm = wm = 0
+    if labels is not None:
+        hm, wm = labels.shape[1:]
+    nb = 0
+    if noise is not None:
+        nb = h * w if noise.shape[0] > 1 else 0
+    L = lib.load()
+    ws = torch.empty(L.e4s_reduce_parts_ws_floats(L.e4s_act_bwd_demod_nsplit(b, h, w, c), dd.numel()), device=dy.device, dtype=torch.float32)
+    call("e4s_act_bwd_demod_f32", fptr(_f32(dy)), fptr(y), fptr(gz), fptr(noise), fptr(noise_w) if noise is not None else None, nb,
+         fptr(bias), float(alpha), float(gain), ptr(labels), hm, wm, r, fptr(dd), fptr(ws), b, h, w, c, stream())
+    return gz, dd
+
+
 def demod_grad(gz, y, noise, noise_w, bias, alpha, gain, labels, num_regions):
     """dL/dd [G, C] for out_pre = d * c (see e4s_demod_grad_f32); the caller divides by d."""
     b, h, w, c = gz.shape

@@ -1440,3 +1440,25 @@ def test_tiled_stem_conv_and_its_fused_statistics(b, h, w):
     lib.call("e4s_conv3x3_small_f32", lib.fptr(xd), lib.fptr(wt.to(DEV)), lib.fptr(y_old), b, h, w, 3, 64, lib.stream())
     assert maxabs(y, y_old) < 2e-6 * float(ref.abs().max())
     assert torch.equal(y, K.conv3x3_small(xd, wt.to(DEV)))
+
+
+@pytest.mark.parametrize("b,h,w,c,masked", [(2, 64, 64, 128, True), (1, 128, 96, 32, False), (2, 16, 16, 512, True), (1, 32, 32, 64, True)])
+def test_fused_activation_backward_and_demod_gradient(b, h, w, c, masked):
+    """e4s_act_bwd_demod_f32 == e4s_fused_bias_act_f32(grad) followed by e4s_demod_grad_f32 (the two passes it replaces): gz bit for bit,
+    dd to summation-order rounding, and dd bit-reproducible."""
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(c + h)
+    dy = torch.randn(b, h, w, c, generator=g).to(DEV)
+    y = torch.randn(b, h, w, c, generator=g).to(DEV)
+    noise = torch.randn(b, 1, h, w, generator=g).to(DEV)
+    nw = torch.tensor([0.3], device=DEV)
+    bias = torch.randn(c, generator=g).to(DEV)
+    labels = None
+    if masked:
+        labels, _ = K.mask_labels(synth.onehot(synth.synth_labels_face(b, 512, seed=3)).to(DEV))
+    gz0 = K.fused_bias_act(dy, None, y, 3, 1, 0.2, 2 ** 0.5)
+    dd0 = K.demod_grad(gz0, y, noise, nw, bias, 0.2, 2 ** 0.5, labels, 12)
+    gz1, dd1 = K.act_bwd_demod(dy, y, noise, nw, bias, 0.2, 2 ** 0.5, labels, 12)
+    assert torch.equal(gz0, gz1)
+    assert maxabs(dd0, dd1) < 2e-5 * float(dd0.abs().max()), maxabs(dd0, dd1)
+    assert torch.equal(dd1, K.act_bwd_demod(dy, y, noise, nw, bias, 0.2, 2 ** 0.5, labels, 12)[1])
