@@ -168,6 +168,31 @@ __global__ void conv_smallcin_bwd_kernel(const float* __restrict__ dy, const flo
     for (int ci = 0; ci < Cin; ++ci) dx[i * Cin + ci] = acc[ci];
 }
 
+// col2im of the GEMM form of the same gradient (large kernels: AlexNet's 11x11 / 4 stem): z[b,oy,ox,(ky*k+kx)*Cin+ci] = dy[b,oy,ox,:] . w[(ky,kx,ci)][:]
+// comes out of ONE 1x1 contraction on the MFMA conv kernel (M = positions, N = k*k*Cin padded to a multiple of 32, K = Cout); here every image
+// pixel adds the <= ceil(k/stride)^2 entries that land on it, in (oy, ox) order.  conv_smallcin_bwd_kernel re-reads dy and the weights per
+// pixel through L1 (0.85 ms at 1024^2); this pair takes ~0.1 ms.
+__global__ void conv_smallcin_col2im_kernel(const float* __restrict__ z, float* __restrict__ dx, int B, int Hi, int Wi, int Cin, int Ho,
+                                            int Wo, int ZC, int k, int stride, int pad, int64_t npix) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const int x = (int)(i % Wi), y = (int)((i / Wi) % Hi), b = (int)(i / ((int64_t)Wi * Hi));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int oy_hi = min((y + pad) / stride, Ho - 1), ox_hi = min((x + pad) / stride, Wo - 1);
+    const int oy_lo = max((y + pad - k + stride) / stride, 0), ox_lo = max((x + pad - k + stride) / stride, 0);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const int ky = y + pad - oy * stride;
+        if (ky < 0 || ky >= k) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const int kx = x + pad - ox * stride;
+            if (kx < 0 || kx >= k) continue;
+            const float* zp = z + (((int64_t)b * Ho + oy) * Wo + ox) * ZC + (ky * k + kx) * Cin;
+            for (int ci = 0; ci < Cin; ++ci) acc[ci] += zp[ci];
+        }
+    }
+    for (int ci = 0; ci < Cin; ++ci) dx[i * Cin + ci] = acc[ci];
+}
+
 // ---- MaxPool2d(3, 2) (torchvision AlexNet features[2], [5]) -----------------------------------------------------
 __global__ void maxpool3s2_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, int Hi,
                                   int Wi, int Ho, int Wo, int C, int64_t n4) {
@@ -535,6 +560,17 @@ extern "C" int e4s_conv_smallcin_bwd_f32(const float* dy, const float* wp, float
     const int64_t npix = (int64_t)B * Hi * Wi;
     hipLaunchKernelGGL(conv_smallcin_bwd_kernel, grid1(npix), dim3(256), 0, as_stream(stream), dy, wp, dx, B, Hi, Wi, Cin, Ho,
                        Wo, Cout, k, stride, pad, npix);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_conv_smallcin_col2im_f32(const float* z, float* dx, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int ZC, int k,
+                                            int stride, int pad, void* stream) {
+    if (!z || !dx || Cin < 1 || Cin > 4 || k < 1 || stride < 1 || ZC < k * k * Cin) return (int)hipErrorInvalidValue;
+    const int64_t npix = (int64_t)B * Hi * Wi;
+    if (npix <= 0) return 0;
+    hipLaunchKernelGGL(conv_smallcin_col2im_kernel, grid1(npix), dim3(256), 0, as_stream(stream), z, dx, B, Hi, Wi, Cin, Ho, Wo, ZC, k,
+                       stride, pad, npix);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -1156,10 +1156,30 @@ def conv_smallcin(x, wp, bias, cout, k, stride, pad, relu=False):
     return y
 
 
+_SMALLCIN_Z = {}
+
+
 def conv_smallcin_bwd(dy, wp, in_shape, k, stride, pad):
+    """Image gradient of conv_smallcin.  Large kernels (AlexNet's 11x11 / 4 stem: k*k*Cin >= 128 columns): GEMM form -- ONE 1x1
+    contraction z = dy . wp^T on the fp32 MFMA conv kernel + a col2im pass (e4s_conv_smallcin_col2im_f32); small kernels: the per-pixel
+    kernel (e4s_conv_smallcin_bwd_f32)."""
     b, hi, wi, cin = in_shape
     _, ho, wo, cout = dy.shape
     dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    ncol = k * k * cin
+    if ncol >= 128 and cout % 32 == 0 and dy.is_contiguous():
+        zc = (ncol + 31) // 32 * 32
+        key = (wp.data_ptr(), wp._version, zc)
+        hit = _SMALLCIN_Z.get(key)
+        if hit is None:
+            wz = torch.zeros(1, 1, zc, cout, device=wp.device, dtype=torch.float32)
+            wz[0, 0, :ncol] = wp                                                  # wp is [k*k*Cin][Cout]: the GEMM's [N][K] matrix
+            _SMALLCIN_Z.clear()
+            _SMALLCIN_Z[key] = hit = (wp, wz)          # the entry HOLDS wp: a freed pack's address + version 0 must not hit it
+        wz = hit[1]
+        z = conv_mfma(_f32(dy), wz, zc, ntaps=1, spatial=False)
+        call("e4s_conv_smallcin_col2im_f32", fptr(z), fptr(dx), b, hi, wi, cin, ho, wo, zc, k, stride, pad, stream())
+        return dx
     call("e4s_conv_smallcin_bwd_f32", fptr(_f32(dy)), fptr(wp), fptr(dx), b, hi, wi, cin, ho, wo, cout, k, stride, pad,
          stream())
     return dx

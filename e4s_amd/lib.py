@@ -115,6 +115,7 @@ SIGNATURES = {
     "e4s_ema_f32": [c_p, c_p, c_l, c_d, c_p],
     "e4s_adam_step_dev_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_p, c_d, c_d, c_d, c_d, c_p, c_p],
     "e4s_advance_i64": [c_p, c_l, c_p],
+    "e4s_conv_smallcin_col2im_f32": [c_p, c_p] + [c_i] * 10 + [c_p],
     "e4s_act_bwd_demod_nsplit": [c_i, c_i, c_i, c_i],
     "e4s_act_bwd_demod_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_pixel_unshuffle2_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],

@@ -536,6 +536,11 @@ int e4s_conv_smallcin_f32(const float* x, const float* wp, const float* bias, fl
                           int Ho, int Wo, int Cout, int k, int stride, int pad, int relu, void* stream);
 int e4s_conv_smallcin_bwd_f32(const float* dy, const float* wp, float* dx, int B, int Hi, int Wi, int Cin, int Ho, int Wo,
                               int Cout, int k, int stride, int pad, void* stream);
+/* second half of the GEMM form of that gradient for large kernels: z NHWC [B,Ho,Wo,ZC] with z[..., (ky*k+kx)*Cin+ci] = dy . w[(ky,kx,ci)]
+ * (one 1x1 contraction on e4s_conv_mfma_f32 with the packed weights as its [ZC][Cout] matrix, ZC = k*k*Cin padded to a multiple of 32);
+ * dx[b,y,x,ci] = the sum of the entries that land on the pixel, in (oy, ox) order */
+int e4s_conv_smallcin_col2im_f32(const float* z, float* dx, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int ZC, int k, int stride,
+                                 int pad, void* stream);
 /* nn.MaxPool2d(3, 2): x NHWC [B,Hi,Wi,C] -> y [B,(Hi-3)/2+1,(Wi-3)/2+1,C] and idx (uint8, same shape): position of the first
  * maximum in the window (ATen's tie rule); the backward routes dy through idx. */
 int e4s_maxpool3s2_f32(const float* x, float* y, uint8_t* idx, int B, int Hi, int Wi, int C, void* stream);
