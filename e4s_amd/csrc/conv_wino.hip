@@ -85,6 +85,14 @@ __global__ void wino_weights_kernel(const float* __restrict__ w9, unsigned char*
 // only instantiate VAR = 0): 1 no input-transform staging, 2 no weight staging, 3 neither, 4 neither and no fragment reads (MFMAs + barriers),
 // 5 MFMAs only (no barriers), 6 everything but the MFMAs, 7 input items loaded but not transformed / stored, 8 transformed / stored but
 // not loaded (stale registers)
+struct WTile {              // one 16x16-pixel x 128-column output tile
+    int n0, tb, ty0, tx0, slot;
+};
+
+// PERSISTENT (round 4, second version): the grid is min(tiles, CUs); block b walks tiles b', b' + G, ... (b' = XCD-remapped b) and the stage
+// pipeline runs straight through the tile boundary -- while the last chunk of tile t is contracted, the V of tile t+1's first chunk is
+// loaded / transformed / stored and its first U stage arrives by DMA, so a tile's prologue is never exposed (it was ~4 us of the 17 us a
+// K = 64 tile takes, ~4 of 34 at K = 128); only the register epilogue (output transform + stores, ~1.5 us of issue) sits between two tiles.
 template <int XF, int VAR = 0>
 __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p, const int ntn, const int tx_n, const int per_img,
                                                          const int ntiles) {
@@ -92,24 +100,30 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     unsigned char* sA = smem;                                  // [2][4 pos][144][64]
     unsigned char* sB = smem + 2 * A_BYTES;                    // [2][4 pos][128][64]
     double* s_st = reinterpret_cast<double*>(sB + 2 * B_BYTES);      // [2 wm][BN][2]
-    float* s_in = reinterpret_cast<float*>(s_st + 2 * BN * 2);       // XF == 2: [Cin][{mean, rstd}] of this sample (read at transform time:
+    float* s_in = reinterpret_cast<float*>(s_st + 2 * BN * 2);       // XF == 2: [2 tile parities][Cin][{mean, rstd}] (read at transform time:
                                                                      // an item does not carry its statistics across the stage boundary)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;
-    const int t = xcd_remap(blockIdx.x, ntiles);
-    // n-major tile order: consecutive ids (one XCD) share a column tile, i.e. one 3 * Cin * 512-byte slab of U in their L2
-    const int nt = t / (ntiles / ntn), mt = t - nt * (ntiles / ntn);
-    const int n0 = nt * BN;
-    const int tb = mt / per_img;
-    const int rem = mt - tb * per_img;
-    const int tyb = rem / tx_n, txb = rem - tyb * tx_n;
-    const int ty0 = tyb * TH, tx0 = txb * TW;
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);
+    const int mtiles = ntiles / ntn;
     const int nchunk = p.Cin / KC;
-    const float* xb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin;
     const unsigned char* ub = reinterpret_cast<const unsigned char*>(p.w);
+    // n-major tile order: consecutive ids (one XCD) share a column tile, i.e. one 3 * Cin * 512-byte slab of U in their L2
+    auto decode = [&](int t) -> WTile {
+        WTile w;
+        const int nt = t / mtiles, mt = t - nt * mtiles;
+        w.n0 = nt * BN;
+        w.tb = mt / per_img;
+        w.slot = mt - w.tb * per_img;
+        const int tyb = w.slot / tx_n;
+        w.ty0 = tyb * TH;
+        w.tx0 = (w.slot - tyb * tx_n) * TW;
+        return w;
+    };
 
     // ---- input-transform items ----
     struct Item {
@@ -118,16 +132,17 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
         int dst;             // byte offset of the hi half inside a position plane
         unsigned okmask;     // bit i: d[i] is inside the image
     };
-    auto item_load = [&](int it, int chunk, Item& I) {
+    auto item_load = [&](const WTile& T, int it, int chunk, Item& I) {
         const int v = it >> 2, cq = it & 3;
         const int hy = v >> 3, j = v & 7;
-        const int iy = ty0 + hy - 1;
+        const int iy = T.ty0 + hy - 1;
         const int c = chunk * KC + cq * 4;
         const bool rowok = (unsigned)iy < (unsigned)p.Hi;
+        const float* xb = p.x + (size_t)T.tb * p.Hi * p.Wi * p.Cin;
         I.okmask = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int ix = tx0 + 2 * j - 1 + i;
+            const int ix = T.tx0 + 2 * j - 1 + i;
             const bool ok = rowok && (unsigned)ix < (unsigned)p.Wi;
             I.okmask |= ok ? (1u << i) : 0u;
             const size_t off = ok ? ((size_t)iy * p.Wi + ix) * p.Cin + c : (size_t)c;
@@ -136,10 +151,10 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
         I.dst = swz(v, cq >> 1) + (cq & 1) * 8;
     };
     // padded pixels -> 0 (XF == 2: 0 in the NORMALISED map, i.e. the mean); done once per item, before the per-position parts
-    auto item_prep = [&](Item& I, int it, int chunk) {      // (it & 3 == lane & 3 for every item a lane ever holds)
+    auto item_prep = [&](Item& I, int it, int chunk, int par) {      // (it & 3 == lane & 3 for every item a lane ever holds)
         f32x4 fill = {0.f, 0.f, 0.f, 0.f};
         if (XF == 2) {
-            const int coff = (chunk * KC + (it & 3) * 4) * 2;
+            const int coff = par * p.Cin * 2 + (chunk * KC + (it & 3) * 4) * 2;
             I.s0 = *reinterpret_cast<const f32x4*>(s_in + coff);
             I.s1 = *reinterpret_cast<const f32x4*>(s_in + coff + 4);
             fill = f32x4{I.s0[0], I.s0[2], I.s1[0], I.s1[2]};
@@ -175,6 +190,14 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
         *reinterpret_cast<u32x2*>(a + I.dst) = u32x2{h01, h23};
         *reinterpret_cast<u32x2*>(a + (I.dst ^ 32)) = u32x2{l01, l23};
     };
+    // the {mean, rstd} table of a tile's sample -> s_in[par] (made visible by the stage barriers that follow)
+    auto load_stats = [&](const WTile& T, int par) {
+        if (XF == 2) {
+            const float* st = p.in_stats + (size_t)T.tb * p.Cin * 2;
+            for (int i = tid * 4; i < p.Cin * 2; i += NTHR * 4)
+                *reinterpret_cast<f32x4*>(s_in + par * p.Cin * 2 + i) = *reinterpret_cast<const f32x4*>(st + i);
+        }
+    };
 
     // ---- weight staging by LDS-DMA: instruction q = wave * 4 + jj of a stage fills the 1 KB (16 rows) block q & 7 of position plane q >> 3;
     // the LDS image is lane-linear, so the XOR swizzle goes on the SOURCE granule: lane -> row (lane >> 2), granule (lane & 3) ^ f(row) ----
@@ -182,44 +205,49 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     auto u_stage = [&](int ky, int chunk) -> size_t { return ((size_t)ky * nchunk + chunk) * 4 * u_pos; };
     // (q >> 3 = wave >> 1 and (row >> 2) & 3 = (lane >> 4) & 3 for all four jj: the four pieces are 1 KB apart on both sides)
     const int q0 = wave * 4, ps0 = q0 >> 3, blk0 = q0 & 7, row0 = blk0 * 16 + (lane >> 2);
-    const size_t g_src0 = ps0 * u_pos + (size_t)(n0 + row0) * ROWB + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    const size_t g_src0 = ps0 * u_pos + (size_t)row0 * ROWB + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
     const int g_dst0 = ps0 * B_PLANE + blk0 * 1024;
-    auto glds_stage = [&](unsigned char* Bdst, size_t stage_off) {
+    auto glds_stage = [&](unsigned char* Bdst, size_t stage_off, int n0) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + stage_off + g_src0 + jj * 1024),
-                                             (__attribute__((address_space(3))) void*)(Bdst + g_dst0 + jj * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(ub + stage_off + (size_t)n0 * ROWB + g_src0 + jj * 1024),
+                (__attribute__((address_space(3))) void*)(Bdst + g_dst0 + jj * 1024), 16, 0, 0);
     };
+
+    if (first >= ntiles) return;
+    WTile cur = decode(first);
+    int t_next = first + G;
+    bool has_next = t_next < ntiles;
+    WTile nxt = decode(has_next ? t_next : first);
 
     // Roles of a wave in stage sg (global stage counter): LOADER: (wave - 3 sg) & 7 < 3 fetches 64 items of the V group this stage feeds;
     // STORER: the loader of stage sg - 1 transforms, splits and stores them, one position per MFMA group, under its own MFMAs.  Group
     // (ts + 1) % 3 of the NEXT chunk's 576 items is loaded in stage ts and stored in stage ts + 1, so chunk c + 1's V is complete at the
-    // barrier that ends chunk c (group 0 of chunk c + 1 is loaded in the last stage of chunk c - 1, or in the prologue).
+    // barrier that ends chunk c (group 0 of chunk c + 1 is loaded in the last stage of chunk c - 1, or in the prologue).  "Next chunk" runs
+    // through the tile boundary: after the last chunk of a tile comes chunk 0 of the block's next tile.
     Item I;
     I.dst = 0;
     I.okmask = 0;
-    if (XF == 2) {
-        const float* st = p.in_stats + (size_t)tb * p.Cin * 2;
-        for (int i = tid * 4; i < p.Cin * 2; i += NTHR * 4) *reinterpret_cast<f32x4*>(s_in + i) = *reinterpret_cast<const f32x4*>(st + i);
-        __syncthreads();
-    }
-    // ---- prologue: V of chunk 0 (all threads), U of stage 0, and the loads of group 0 of chunk 1 for the storers of stage 0 ----
+    // ---- prologue (once per block): V of chunk 0 (all threads), U of stage 0, the loads of group 0 of chunk 1 for the storers of stage 0 ----
+    load_stats(cur, 0);
+    if (XF == 2) __syncthreads();
     {
         Item I0, I1;
-        item_load(tid, 0, I0);
+        item_load(cur, tid, 0, I0);
         const bool two = tid + NTHR < NITEMS;
-        if (two) item_load(tid + NTHR, 0, I1);
-        glds_stage(sB, u_stage(0, 0));
-        item_prep(I0, tid, 0);
+        if (two) item_load(cur, tid + NTHR, 0, I1);
+        glds_stage(sB, u_stage(0, 0), cur.n0);
+        item_prep(I0, tid, 0, 0);
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) item_part(sA, I0, ps);
         if (two) {
-            item_prep(I1, tid + NTHR, 0);
+            item_prep(I1, tid + NTHR, 0, 0);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) item_part(sA, I1, ps);
         }
         const int slot = (wave + 3) & 7;
-        if (nchunk > 1 && slot < 3) item_load(slot * 64 + lane, 1, I);
+        if (slot < 3) item_load(cur, slot * 64 + lane, 1, I);                 // (nchunk >= 2)
     }
     __syncthreads();
 
@@ -232,164 +260,198 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     boff = swz(wn * 32 + li, kh);
 
     f32x16 acc[4][2];
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps)
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ps][tm][r] = 0.f;
-
     struct AF { bf16x8 h[2], l[2]; };
     struct BF { bf16x8 h, l; };
-    unsigned sg = 0;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        const bool have_nc = chunk + 1 < nchunk;
-        const unsigned char* Ab = sA + (chunk & 1) * A_BYTES;
-        unsigned char* An = sA + ((chunk + 1) & 1) * A_BYTES;
+    unsigned sg = 0, cg = 0;         // running stage / chunk counters: the LDS buffer parities continue across tiles
+    int par = 0;                     // parity of the block's tile counter: s_in[par] holds the current tile's statistics
+    for (;;) {
+        if (has_next) load_stats(nxt, par ^ 1);      // read from stage (nchunk - 1, 0) on: >= 3 barriers away (nchunk >= 2)
 #pragma unroll
-        for (int ts = 0; ts < 3; ++ts) {
-            const unsigned char* Bb = sB + (sg & 1) * B_BYTES;
-            unsigned char* Bn = sB + ((sg + 1) & 1) * B_BYTES;
-            const bool more = ts < 2 || have_nc;
-            const bool storer = have_nc && ((wave - 3 * ((int)sg - 1)) & 7) < 3 && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5 && VAR != 7;
-            const int lslot = (wave - 3 * (int)sg) & 7;
-            const int lchunk = ts < 2 ? chunk + 1 : chunk + 2;
-            const bool loader = lslot < 3 && lchunk < nchunk && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5 && VAR != 8;
-            auto ldA = [&](AF& F, int ps) {
+        for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    const unsigned char* a = Ab + ps * A_PLANE;
-                    F.h[tm] = *reinterpret_cast<const bf16x8*>(a + aoff[tm][ts]);
-                    F.l[tm] = *reinterpret_cast<const bf16x8*>(a + (aoff[tm][ts] ^ 32));
-                }
-            };
-            auto ldB = [&](BF& F, int ps) {
-                const unsigned char* b = Bb + ps * B_PLANE;
-                F.h = *reinterpret_cast<const bf16x8*>(b + boff);
-                F.l = *reinterpret_cast<const bf16x8*>(b + (boff ^ 32));
-            };
-            // the MFMA section, with the storer's transform parts folded in (STORE is a compile-time copy: a branch around the VALU
-            // block would pin it outside the MFMA stream)
-            auto body = [&](auto store_tag) {
-                constexpr bool STORE = decltype(store_tag)::value;
-                AF A0, A1;
-                BF B0, B1;
-                ldB(B0, 0);
-                ldA(A0, 0);
-                if (VAR == 4 || VAR == 5) { A1 = A0; B1 = B0; }
-                // the storer consumes last stage's plain loads FIRST: with an LDS-DMA in flight hipcc waits vmcnt(0) at the next use of
-                // any plain load, which would also wait for the DMA issued a moment ago
-                if (STORE) item_prep(I, lane, chunk + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more && (VAR < 2 || VAR == 6)) {
-                    const int ky_w = ts < 2 ? ts + 1 : 0, ch_w = ts < 2 ? chunk : chunk + 1;
-                    glds_stage(Bn, u_stage(ky_w, ch_w));
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    AF& Ac = (ps & 1) ? A1 : A0;
-                    AF& Anx = (ps & 1) ? A0 : A1;
-                    BF& Bc = (ps & 1) ? B1 : B0;
-                    BF& Bnx = (ps & 1) ? B0 : B1;
-                    if (ps + 1 < 4 && VAR != 4 && VAR != 5) {
-                        ldB(Bnx, ps + 1);
-                        ldA(Anx, ps + 1);
+                for (int r = 0; r < 16; ++r) acc[ps][tm][r] = 0.f;
+
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            const bool in_tile = chunk + 1 < nchunk;            // the next chunk belongs to this tile
+            const bool have_nc = in_tile || has_next;
+            const WTile& Tn = in_tile ? cur : nxt;              // owner of the next chunk
+            const int c_n = in_tile ? chunk + 1 : 0;
+            const int par_n = in_tile ? par : par ^ 1;
+            const unsigned char* Ab = sA + (cg & 1) * A_BYTES;
+            unsigned char* An = sA + ((cg + 1) & 1) * A_BYTES;
+#pragma unroll
+            for (int ts = 0; ts < 3; ++ts) {
+                const unsigned char* Bb = sB + (sg & 1) * B_BYTES;
+                unsigned char* Bn = sB + ((sg + 1) & 1) * B_BYTES;
+                const bool more = ts < 2 || have_nc;
+                const bool storer = have_nc && ((wave - 3 * ((int)sg - 1)) & 7) < 3 && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5 && VAR != 7;
+                const int lslot = (wave - 3 * (int)sg) & 7;
+                // the chunk whose group (ts + 1) % 3 is loaded now: the next one (ts < 2) or the one after it (ts == 2)
+                const int lv = ts < 2 ? chunk + 1 : chunk + 2;              // virtual index: >= nchunk = in the next tile
+                const bool l_in = lv < nchunk;
+                const bool l_ok = l_in || (has_next && lv - nchunk < nchunk);
+                const bool loader = lslot < 3 && l_ok && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5 && VAR != 8;
+                auto ldA = [&](AF& F, int ps) {
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) {
+                        const unsigned char* a = Ab + ps * A_PLANE;
+                        F.h[tm] = *reinterpret_cast<const bf16x8*>(a + aoff[tm][ts]);
+                        F.l[tm] = *reinterpret_cast<const bf16x8*>(a + (aoff[tm][ts] ^ 32));
                     }
-                    if (STORE) item_part(An, I, ps);
-                    if (VAR != 6) {
-                        acc[ps][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[0], Bc.h, acc[ps][0], 0, 0, 0);
-                        acc[ps][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[1], Bc.h, acc[ps][1], 0, 0, 0);
-                        acc[ps][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[0], Bc.l, acc[ps][0], 0, 0, 0);
-                        acc[ps][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[1], Bc.l, acc[ps][1], 0, 0, 0);
-                        acc[ps][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[0], Bc.h, acc[ps][0], 0, 0, 0);
-                        acc[ps][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[1], Bc.h, acc[ps][1], 0, 0, 0);
-                    } else {
-                        asm volatile("" ::"v"(Ac.h[0]), "v"(Ac.l[0]), "v"(Ac.h[1]), "v"(Ac.l[1]), "v"(Bc.h), "v"(Bc.l));
-                    }
-                    if (STORE) {
-                        // this position's transform + split + stores (~40 VALU, 2 DS writes) and the next group's 6 fragment reads go
-                        // between the six MFMAs
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                            __builtin_amdgcn_sched_group_barrier(0x306, 9, 0);      // then up to 9 VALU / SALU / DS
-                        }
+                };
+                auto ldB = [&](BF& F, int ps) {
+                    const unsigned char* b = Bb + ps * B_PLANE;
+                    F.h = *reinterpret_cast<const bf16x8*>(b + boff);
+                    F.l = *reinterpret_cast<const bf16x8*>(b + (boff ^ 32));
+                };
+                // the MFMA section, with the storer's transform parts folded in (STORE is a compile-time copy: a branch around the VALU
+                // block would pin it outside the MFMA stream)
+                auto body = [&](auto store_tag) {
+                    constexpr bool STORE = decltype(store_tag)::value;
+                    AF A0, A1;
+                    BF B0, B1;
+                    ldB(B0, 0);
+                    ldA(A0, 0);
+                    if (VAR == 4 || VAR == 5) { A1 = A0; B1 = B0; }
+                    // the storer consumes last stage's plain loads FIRST: with an LDS-DMA in flight hipcc waits vmcnt(0) at the next use of
+                    // any plain load, which would also wait for the DMA issued a moment ago
+                    if (STORE) item_prep(I, lane, c_n, par_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && (VAR < 2 || VAR == 6)) {
+                        if (ts < 2) glds_stage(Bn, u_stage(ts + 1, chunk), cur.n0);
+                        else glds_stage(Bn, u_stage(0, c_n), Tn.n0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        AF& Ac = (ps & 1) ? A1 : A0;
+                        AF& Anx = (ps & 1) ? A0 : A1;
+                        BF& Bc = (ps & 1) ? B1 : B0;
+                        BF& Bnx = (ps & 1) ? B0 : B1;
+                        if (ps + 1 < 4 && VAR != 4 && VAR != 5) {
+                            ldB(Bnx, ps + 1);
+                            ldA(Anx, ps + 1);
+                        }
+                        if (STORE) item_part(An, I, ps);
+                        if (VAR != 6) {
+                            acc[ps][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[0], Bc.h, acc[ps][0], 0, 0, 0);
+                            acc[ps][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[1], Bc.h, acc[ps][1], 0, 0, 0);
+                            acc[ps][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[0], Bc.l, acc[ps][0], 0, 0, 0);
+                            acc[ps][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[1], Bc.l, acc[ps][1], 0, 0, 0);
+                            acc[ps][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[0], Bc.h, acc[ps][0], 0, 0, 0);
+                            acc[ps][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[1], Bc.h, acc[ps][1], 0, 0, 0);
+                        } else {
+                            asm volatile("" ::"v"(Ac.h[0]), "v"(Ac.l[0]), "v"(Ac.h[1]), "v"(Ac.l[1]), "v"(Bc.h), "v"(Bc.l));
+                        }
+                        if (STORE) {
+                            // this position's transform + split + stores (~40 VALU, 2 DS writes) and the next group's 6 fragment reads go
+                            // between the six MFMAs
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x306, 9, 0);      // then up to 9 VALU / SALU / DS
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                if (storer) {
+                    body(std::true_type{});
+                } else {
+                    if (loader) item_load(l_in ? cur : nxt, ((ts + 1) % 3) * 192 + lslot * 64 + lane, l_in ? lv : lv - nchunk, I);
+                    body(std::false_type{});
+                    if (VAR == 7 && loader) asm volatile("" ::"v"(I.d[0]), "v"(I.d[1]), "v"(I.d[2]), "v"(I.d[3]));
                 }
-            };
-            if (storer) {
-                body(std::true_type{});
-            } else {
-                if (loader) item_load(((ts + 1) % 3) * 192 + lslot * 64 + lane, lchunk, I);
-                body(std::false_type{});
-                if (VAR == 7 && loader) asm volatile("" ::"v"(I.d[0]), "v"(I.d[1]), "v"(I.d[2]), "v"(I.d[3]));
+                if (VAR != 5) __syncthreads();
+                ++sg;
             }
-            if (VAR != 5) __syncthreads();
-            ++sg;
+            ++cg;
         }
-    }
 
-    // ---- epilogue: output transform in registers, bias, activation, statistics, NHWC stores ----
-    {
-        const int co = n0 + wn * 32 + li;
-        const float bsv = p.bias ? p.bias[co] : 0.f;
-        const float slp = (p.act == 2) ? p.slope[co] : p.alpha;
-        const float gain = (p.act == 1) ? p.gain : 1.f;
-        const bool do_act = p.act != 0;
-        const bool stats = p.stats_ws != nullptr;
-        double st_s = 0.0, st_q = 0.0;
-        float* yb = p.y + (size_t)tb * p.Ho * p.Wo * p.Cout;
+        // ---- epilogue of the tile: output transform in registers, bias, activation, statistics, NHWC stores ----
+        {
+            const int co = cur.n0 + wn * 32 + li;
+            const float bsv = p.bias ? p.bias[co] : 0.f;
+            const float slp = (p.act == 2) ? p.slope[co] : p.alpha;
+            const float gain = (p.act == 1) ? p.gain : 1.f;
+            const bool do_act = p.act != 0;
+            const bool stats = p.stats_ws != nullptr;
+            double st_s = 0.0, st_q = 0.0;
+            float* yb = p.y + (size_t)cur.tb * p.Ho * p.Wo * p.Cout;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+            for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float y0[4], y1[4];
+                for (int g = 0; g < 4; ++g) {
+                    float y0[4], y1[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * g + i;
-                    const float m0 = acc[0][tm][r], m1 = acc[1][tm][r], m2 = acc[2][tm][r], m3 = acc[3][tm][r];
-                    float a = (m0 + m1) + m2 + bsv;
-                    float b = (m1 - m2) - m3 + bsv;
-                    if (do_act) {
-                        a = (a > 0.f ? a : a * slp) * gain;
-                        b = (b > 0.f ? b : b * slp) * gain;
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;
+                        const float m0 = acc[0][tm][r], m1 = acc[1][tm][r], m2 = acc[2][tm][r], m3 = acc[3][tm][r];
+                        float a = (m0 + m1) + m2 + bsv;
+                        float b = (m1 - m2) - m3 + bsv;
+                        if (do_act) {
+                            a = (a > 0.f ? a : a * slp) * gain;
+                            b = (b > 0.f ? b : b * slp) * gain;
+                        }
+                        y0[i] = a;
+                        y1[i] = b;
+                        if (stats) {
+                            st_s += (double)a + (double)b;
+                            st_q += (double)a * (double)a + (double)b * (double)b;
+                        }
                     }
-                    y0[i] = a;
-                    y1[i] = b;
-                    if (stats) {
-                        st_s += (double)a + (double)b;
-                        st_q += (double)a * (double)a + (double)b * (double)b;
-                    }
+                    quad_transpose4(y0[0], y0[1], y0[2], y0[3], li);
+                    quad_transpose4(y1[0], y1[1], y1[2], y1[3], li);
+                    const int m = wm * 64 + tm * 32 + (li & 3) + 8 * g + 4 * kh;
+                    const int oy = cur.ty0 + (m >> 3), ox = cur.tx0 + 2 * (m & 7);
+                    float* dst = yb + ((size_t)oy * p.Wo + ox) * p.Cout + (co - (li & 3));
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{y0[0], y0[1], y0[2], y0[3]};
+                    *reinterpret_cast<f32x4*>(dst + p.Cout) = f32x4{y1[0], y1[1], y1[2], y1[3]};
                 }
-                quad_transpose4(y0[0], y0[1], y0[2], y0[3], li);
-                quad_transpose4(y1[0], y1[1], y1[2], y1[3], li);
-                const int m = wm * 64 + tm * 32 + (li & 3) + 8 * g + 4 * kh;
-                const int oy = ty0 + (m >> 3), ox = tx0 + 2 * (m & 7);
-                float* dst = yb + ((size_t)oy * p.Wo + ox) * p.Cout + (co - (li & 3));
-                *reinterpret_cast<f32x4*>(dst) = f32x4{y0[0], y0[1], y0[2], y0[3]};
-                *reinterpret_cast<f32x4*>(dst + p.Cout) = f32x4{y1[0], y1[1], y1[2], y1[3]};
+            }
+            if (stats) {
+                st_s += __shfl_xor(st_s, 32, 64);
+                st_q += __shfl_xor(st_q, 32, 64);
+                if (kh == 0) {
+                    const int col = wn * 32 + li;
+                    s_st[(wm * BN + col) * 2] = st_s;
+                    s_st[(wm * BN + col) * 2 + 1] = st_q;
+                }
+                __syncthreads();
+                if (tid < BN) {
+                    const double a = s_st[tid * 2] + s_st[(BN + tid) * 2];
+                    const double q = s_st[tid * 2 + 1] + s_st[(BN + tid) * 2 + 1];
+                    double* slot = p.stats_ws + (((size_t)cur.tb * p.Cout + cur.n0 + tid) * p.stats_slots + cur.slot) * 2;
+                    slot[0] = a;
+                    slot[1] = q;
+                }
+                // (the next write of s_st is a whole tile of barriers away)
             }
         }
-        if (stats) {
-            st_s += __shfl_xor(st_s, 32, 64);
-            st_q += __shfl_xor(st_q, 32, 64);
-            if (kh == 0) {
-                const int col = wn * 32 + li;
-                s_st[(wm * BN + col) * 2] = st_s;
-                s_st[(wm * BN + col) * 2 + 1] = st_q;
-            }
-            __syncthreads();
-            if (tid < BN) {
-                const double a = s_st[tid * 2] + s_st[(BN + tid) * 2];
-                const double q = s_st[tid * 2 + 1] + s_st[(BN + tid) * 2 + 1];
-                double* slot = p.stats_ws + (((size_t)tb * p.Cout + n0 + tid) * p.stats_slots + (tyb * tx_n + txb)) * 2;
-                slot[0] = a;
-                slot[1] = q;
-            }
+        if (!has_next) break;
+        cur = nxt;
+        par ^= 1;
+        t_next += G;
+        has_next = t_next < ntiles;
+        if (has_next) nxt = decode(t_next);
+    }
+}
+
+int wino_num_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (!cus[dev & 63]) {
+        hipDeviceProp_t prop;
+        cus[dev & 63] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        if (const char* g = getenv("E4S_WINO_GRID")) {          // testing aid: fewer blocks, so that small shapes walk several tiles per block
+            const int v = atoi(g);
+            if (v > 0) cus[dev & 63] = v;
         }
     }
+    return cus[dev & 63];
 }
 
 bool wino_covers(const e4s_conv_params& p) {
@@ -427,6 +489,8 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
     if (tiles > 0x7fffffff) return (int)hipErrorInvalidValue;
     static std::atomic<uint64_t> m0{0}, m2{0};
     int e;
+    const int ncu = wino_num_cus();
+    const int64_t grid = tiles < ncu ? tiles : ncu;                               // persistent: one block per CU
 #ifdef E4S_ABLATIONS
     {
         static std::atomic<uint64_t> mv[9];
@@ -434,7 +498,7 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
         const int var = ev ? atoi(ev) : 0;
         const void* fn = nullptr;
 #define WV(V) case V: fn = (const void*)conv_wino_kernel<0, V>; if ((e = e4s_ensure_dyn_smem(fn, SMEM_WINO, mv[V]))) return e; \
-              hipLaunchKernelGGL((conv_wino_kernel<0, V>), dim3((unsigned)tiles), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img, (int)tiles); \
+              hipLaunchKernelGGL((conv_wino_kernel<0, V>), dim3((unsigned)grid), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img, (int)tiles); \
               E4S_CHECK_LAUNCH(); return 0;
         switch (p.in_stats ? 0 : var) {
             WV(1) WV(2) WV(3) WV(4) WV(5) WV(6) WV(7) WV(8)
@@ -444,13 +508,13 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
     }
 #endif
     if (p.in_stats) {
-        if (p.Cin > 1024) return (int)hipErrorInvalidValue;                    // the {mean, rstd} table has 8 KB of LDS
-        if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<2>, SMEM_WINO + 8192, m2))) return e;
-        hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)tiles), dim3(NTHR), SMEM_WINO + p.Cin * 8, as_stream(stream), p, ntn, tx_n,
+        if (p.Cin > 1024) return (int)hipErrorInvalidValue;                    // the two {mean, rstd} tables have 16 KB of LDS
+        if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<2>, SMEM_WINO + 16384, m2))) return e;
+        hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)grid), dim3(NTHR), SMEM_WINO + p.Cin * 16, as_stream(stream), p, ntn, tx_n,
                            per_img, (int)tiles);
     } else {
         if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<0>, SMEM_WINO, m0))) return e;
-        hipLaunchKernelGGL(conv_wino_kernel<0>, dim3((unsigned)tiles), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img,
+        hipLaunchKernelGGL(conv_wino_kernel<0>, dim3((unsigned)grid), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img,
                            (int)tiles);
     }
     E4S_CHECK_LAUNCH();

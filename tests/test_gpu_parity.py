@@ -1327,7 +1327,9 @@ def test_f32_conv_split_k_small_maps(cin, cout, h, w, stride):
 
 @pytest.mark.parametrize("b,h,w,cin,cout,mode", [(2, 32, 32, 512, 512, "in_prelu"), (2, 32, 32, 512, 512, "stats"), (1, 16, 48, 64, 128, "plain"),
                                                  (3, 64, 32, 64, 256, "in_prelu"), (1, 128, 128, 128, 128, "stats"),
-                                                 (2, 16, 16, 96, 128, "bias_lrelu")])
+                                                 (2, 16, 16, 96, 128, "bias_lrelu"),
+                                                 # more tiles than CUs: the persistent blocks walk 2-3 tiles each, across samples
+                                                 (3, 256, 256, 64, 128, "in_prelu"), (5, 128, 128, 128, 128, "stats"), (9, 96, 96, 32, 256, "plain")])
 def test_winograd_f23_conv_vs_fp64(b, h, w, cin, cout, mode):
     """e4s_conv_wino_bf16x3_f32 (Winograd F(2,3) along the rows, split-bf16 MFMAs) vs F.conv2d in fp64 on the same operands: plain,
     with the InstanceNorm folded into the input transform + PReLU epilogue (the encoder unit's first conv, helpers.py:128-133), with the
