@@ -536,7 +536,11 @@ def main():
                                     "bf16x3": "encoder stride-1 3x3 convs: 3 bf16 MFMAs per product on hi/lo-split "
                                               "fp32 operands, fp32 accumulate; everything else exact fp32",
                                     "auto": "as bf16x3 where the launch fills the chip (this batch), else exact fp32"
-                                    }[K.PRECISION], "parallelism": f"image-parallel x{world}" + (
+                                    }[K.PRECISION],
+                      "encoder_convs": ("Winograd F(2,3) along the rows on the same split-bf16 MFMAs (e4s_conv_wino_bf16x3_f32: 1.5x fewer "
+                                        "MFMAs; fp32 transforms with +-1, 1/2 coefficients) where a launch has >= 128 tiles, direct "
+                                        "split-bf16 kernel otherwise" if (K.WINO and K.PRECISION != "f32") else "direct kernels"),
+                      "parallelism": f"image-parallel x{world}" + (
                           (", RCCL all_gather of the " + ("fp32 [B,3,H,W]" if args.gather_fp32 else "uint8 [B,H,W,3]")
                            + " outputs" + ("" if args.sync_gather else " overlapped with the next step"))
                           if multi else "") + (" [forced collectives on a world of one rank]" if multi and world == 1 else "")}}

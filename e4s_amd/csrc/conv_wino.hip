@@ -85,8 +85,8 @@ __global__ void wino_weights_kernel(const float* __restrict__ w9, unsigned char*
 // only instantiate VAR = 0): 1 no input-transform staging, 2 no weight staging, 3 neither, 4 neither and no fragment reads (MFMAs + barriers),
 // 5 MFMAs only (no barriers), 6 everything but the MFMAs, 7 input items loaded but not transformed / stored, 8 transformed / stored but
 // not loaded (stale registers)
-struct WTile {              // one 16x16-pixel x 128-column output tile
-    int n0, tb, ty0, tx0, slot;
+struct WTile {              // one 16x16-pixel x 128-column output tile (x one K split: input-channel chunks [c_lo, c_hi))
+    int n0, tb, ty0, tx0, slot, ks, c_lo, c_hi;
 };
 
 // PERSISTENT (round 4, second version): the grid is min(tiles, CUs); block b walks tiles b', b' + G, ... (b' = XCD-remapped b) and the stage
@@ -95,7 +95,10 @@ struct WTile {              // one 16x16-pixel x 128-column output tile
 // K = 64 tile takes, ~4 of 34 at K = 128); only the register epilogue (output transform + stores, ~1.5 us of issue) sits between two tiles.
 template <int XF, int VAR = 0>
 __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p, const int ntn, const int tx_n, const int per_img,
-                                                         const int ntiles) {
+                                                         const int ntiles, const int ksplit, const int cper) {
+    // ksplit > 1 (launches of <= 128 tiles: batch-1 latency runs, the 16x16 maps): the 16-channel chunks of a tile are divided over ksplit
+    // consecutive tile ids; each writes its raw partial OUTPUT (the output transform is linear) to p.splitk_ws[ks] and e4s_splitk_epilogue
+    // adds the slabs in order and applies bias / activation (no fused statistics then: the caller runs the separate pass)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                                  // [2][4 pos][144][64]
     unsigned char* sB = smem + 2 * A_BYTES;                    // [2][4 pos][128][64]
@@ -109,12 +112,16 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     const int wm = wave >> 2, wn = wave & 3;
     const int G = gridDim.x;
     const int first = xcd_remap(blockIdx.x, G);
-    const int mtiles = ntiles / ntn;
+    const int mtiles = ntiles / (ntn * ksplit);
     const int nchunk = p.Cin / KC;
     const unsigned char* ub = reinterpret_cast<const unsigned char*>(p.w);
     // n-major tile order: consecutive ids (one XCD) share a column tile, i.e. one 3 * Cin * 512-byte slab of U in their L2
-    auto decode = [&](int t) -> WTile {
+    auto decode = [&](int t0) -> WTile {
         WTile w;
+        const int t = t0 / ksplit;
+        w.ks = t0 - t * ksplit;
+        w.c_lo = w.ks * cper;
+        w.c_hi = min(w.c_lo + cper, nchunk);
         const int nt = t / mtiles, mt = t - nt * mtiles;
         w.n0 = nt * BN;
         w.tb = mt / per_img;
@@ -234,20 +241,20 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     if (XF == 2) __syncthreads();
     {
         Item I0, I1;
-        item_load(cur, tid, 0, I0);
+        item_load(cur, tid, cur.c_lo, I0);
         const bool two = tid + NTHR < NITEMS;
-        if (two) item_load(cur, tid + NTHR, 0, I1);
-        glds_stage(sB, u_stage(0, 0), cur.n0);
-        item_prep(I0, tid, 0, 0);
+        if (two) item_load(cur, tid + NTHR, cur.c_lo, I1);
+        glds_stage(sB, u_stage(0, cur.c_lo), cur.n0);
+        item_prep(I0, tid, cur.c_lo, 0);
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) item_part(sA, I0, ps);
         if (two) {
-            item_prep(I1, tid + NTHR, 0, 0);
+            item_prep(I1, tid + NTHR, cur.c_lo, 0);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) item_part(sA, I1, ps);
         }
         const int slot = (wave + 3) & 7;
-        if (slot < 3) item_load(cur, slot * 64 + lane, 1, I);                 // (nchunk >= 2)
+        if (slot < 3) item_load(cur, slot * 64 + lane, cur.c_lo + 1, I);      // (every split holds >= 2 chunks)
     }
     __syncthreads();
 
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     unsigned sg = 0, cg = 0;         // running stage / chunk counters: the LDS buffer parities continue across tiles
     int par = 0;                     // parity of the block's tile counter: s_in[par] holds the current tile's statistics
     for (;;) {
-        if (has_next) load_stats(nxt, par ^ 1);      // read from stage (nchunk - 1, 0) on: >= 3 barriers away (nchunk >= 2)
+        if (has_next) load_stats(nxt, par ^ 1);      // read from the last chunk's first stage on: >= 3 barriers away (>= 2 chunks per tile)
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
@@ -273,11 +280,11 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ps][tm][r] = 0.f;
 
-        for (int chunk = 0; chunk < nchunk; ++chunk) {
-            const bool in_tile = chunk + 1 < nchunk;            // the next chunk belongs to this tile
+        for (int chunk = cur.c_lo; chunk < cur.c_hi; ++chunk) {
+            const bool in_tile = chunk + 1 < cur.c_hi;          // the next chunk belongs to this tile
             const bool have_nc = in_tile || has_next;
             const WTile& Tn = in_tile ? cur : nxt;              // owner of the next chunk
-            const int c_n = in_tile ? chunk + 1 : 0;
+            const int c_n = in_tile ? chunk + 1 : nxt.c_lo;
             const int par_n = in_tile ? par : par ^ 1;
             const unsigned char* Ab = sA + (cg & 1) * A_BYTES;
             unsigned char* An = sA + ((cg + 1) & 1) * A_BYTES;
@@ -289,9 +296,10 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                 const bool storer = have_nc && ((wave - 3 * ((int)sg - 1)) & 7) < 3 && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5 && VAR != 7;
                 const int lslot = (wave - 3 * (int)sg) & 7;
                 // the chunk whose group (ts + 1) % 3 is loaded now: the next one (ts < 2) or the one after it (ts == 2)
-                const int lv = ts < 2 ? chunk + 1 : chunk + 2;              // virtual index: >= nchunk = in the next tile
-                const bool l_in = lv < nchunk;
-                const bool l_ok = l_in || (has_next && lv - nchunk < nchunk);
+                const int lv = ts < 2 ? chunk + 1 : chunk + 2;              // >= cur.c_hi: in the next tile
+                const bool l_in = lv < cur.c_hi;
+                const int lc = l_in ? lv : nxt.c_lo + (lv - cur.c_hi);      // its chunk index in its own tile
+                const bool l_ok = l_in || (has_next && lc < nxt.c_hi);
                 const bool loader = lslot < 3 && l_ok && VAR != 1 && VAR != 3 && VAR != 4 && VAR != 5 && VAR != 8;
                 auto ldA = [&](AF& F, int ps) {
 #pragma unroll
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                 if (storer) {
                     body(std::true_type{});
                 } else {
-                    if (loader) item_load(l_in ? cur : nxt, ((ts + 1) % 3) * 192 + lslot * 64 + lane, l_in ? lv : lv - nchunk, I);
+                    if (loader) item_load(l_in ? cur : nxt, ((ts + 1) % 3) * 192 + lslot * 64 + lane, lc, I);
                     body(std::false_type{});
                     if (VAR == 7 && loader) asm volatile("" ::"v"(I.d[0]), "v"(I.d[1]), "v"(I.d[2]), "v"(I.d[3]));
                 }
@@ -373,13 +381,14 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
         // ---- epilogue of the tile: output transform in registers, bias, activation, statistics, NHWC stores ----
         {
             const int co = cur.n0 + wn * 32 + li;
-            const float bsv = p.bias ? p.bias[co] : 0.f;
+            const bool raw = ksplit > 1;
+            const float bsv = (p.bias && !raw) ? p.bias[co] : 0.f;
             const float slp = (p.act == 2) ? p.slope[co] : p.alpha;
             const float gain = (p.act == 1) ? p.gain : 1.f;
-            const bool do_act = p.act != 0;
-            const bool stats = p.stats_ws != nullptr;
+            const bool do_act = p.act != 0 && !raw;
+            const bool stats = p.stats_ws != nullptr && !raw;
             double st_s = 0.0, st_q = 0.0;
-            float* yb = p.y + (size_t)cur.tb * p.Ho * p.Wo * p.Cout;
+            float* yb = (raw ? p.splitk_ws + (size_t)cur.ks * ((size_t)p.B * p.Ho * p.Wo * p.Cout) : p.y) + (size_t)cur.tb * p.Ho * p.Wo * p.Cout;
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
@@ -454,9 +463,24 @@ int wino_num_cus() {
     return cus[dev & 63];
 }
 
+// split-K policy (the plain kernel's, on 16-channel chunks): only when the tiles alone leave most CUs idle; every split keeps >= 2 chunks
+void wino_split(const e4s_conv_params& p, int64_t tiles, int& ksplit, int& cper) {
+    const int nchunk = p.Cin / KC;
+    ksplit = 1;
+    cper = nchunk;
+    if (tiles > 128 || nchunk < 4) return;
+    int want = (int)((256 + tiles - 1) / tiles);
+    if (want > nchunk / 2) want = nchunk / 2;
+    if (want < 2) return;
+    const int c = (nchunk + want - 1) / want, k = (nchunk + c - 1) / c;
+    if (k < 2 || nchunk - (k - 1) * c < 2) return;
+    ksplit = k;
+    cper = c;
+}
+
 bool wino_covers(const e4s_conv_params& p) {
     return p.istride == 1 && p.ostride == 1 && p.ntaps == 9 && p.ncls == 1 && !p.labels && !p.rows && !p.in_scale && !p.out_scale &&
-           !p.noise && p.y_cstride == 0 && !p.splitk_ws && p.Hi == p.Ho && p.Wi == p.Wo && p.Ha == p.Ho && p.Wa == p.Wo && p.Hi % TH == 0 &&
+           !p.noise && p.y_cstride == 0 && p.Hi == p.Ho && p.Wi == p.Wo && p.Ha == p.Ho && p.Wa == p.Wo && p.Hi % TH == 0 &&
            p.Wi % TW == 0 && p.Cin % KC == 0 && p.Cin >= 2 * KC && p.Cout % BN == 0 && p.B > 0 &&
            (p.stats_ws == nullptr || p.stats_slots == (p.Hi / TH) * (p.Wi / TW));
 }
@@ -479,13 +503,25 @@ extern "C" int e4s_wino_weights_f32(const float* w9, void* out, int Cout, int Ci
 
 extern "C" int e4s_conv_wino_covers(const e4s_conv_params* p) { return p && wino_covers(*p) ? 1 : 0; }
 
+/* floats of p->splitk_ws the launch needs (0: no split-K; then stats_ws is honoured) */
+extern "C" int64_t e4s_conv_wino_ws_floats(const e4s_conv_params* pp) {
+    if (!pp || !wino_covers(*pp)) return 0;
+    const e4s_conv_params& p = *pp;
+    int ksplit, cper;
+    wino_split(p, (int64_t)p.B * (p.Hi / TH) * (p.Wi / TW) * (p.Cout / BN), ksplit, cper);
+    return ksplit > 1 ? (int64_t)ksplit * p.B * p.Ho * p.Wo * p.Cout : 0;
+}
+
 extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     if (!pp) return (int)hipErrorInvalidValue;
     const e4s_conv_params& p = *pp;
     if (!p.x || !p.w || !p.y || !wino_covers(p)) return (int)hipErrorInvalidValue;
     if (p.act == 2 && !p.slope) return (int)hipErrorInvalidValue;
     const int tx_n = p.Wi / TW, per_img = (p.Hi / TH) * tx_n, ntn = p.Cout / BN;
-    const int64_t tiles = (int64_t)p.B * per_img * ntn;
+    int ksplit, cper;
+    wino_split(p, (int64_t)p.B * per_img * ntn, ksplit, cper);
+    if (ksplit > 1 && !p.splitk_ws) return (int)hipErrorInvalidValue;
+    const int64_t tiles = (int64_t)p.B * per_img * ntn * ksplit;
     if (tiles > 0x7fffffff) return (int)hipErrorInvalidValue;
     static std::atomic<uint64_t> m0{0}, m2{0};
     int e;
@@ -498,7 +534,7 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
         const int var = ev ? atoi(ev) : 0;
         const void* fn = nullptr;
 #define WV(V) case V: fn = (const void*)conv_wino_kernel<0, V>; if ((e = e4s_ensure_dyn_smem(fn, SMEM_WINO, mv[V]))) return e; \
-              hipLaunchKernelGGL((conv_wino_kernel<0, V>), dim3((unsigned)grid), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img, (int)tiles); \
+              hipLaunchKernelGGL((conv_wino_kernel<0, V>), dim3((unsigned)grid), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img, (int)tiles, ksplit, cper); \
               E4S_CHECK_LAUNCH(); return 0;
         switch (p.in_stats ? 0 : var) {
             WV(1) WV(2) WV(3) WV(4) WV(5) WV(6) WV(7) WV(8)
@@ -511,12 +547,13 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
         if (p.Cin > 1024) return (int)hipErrorInvalidValue;                    // the two {mean, rstd} tables have 16 KB of LDS
         if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<2>, SMEM_WINO + 16384, m2))) return e;
         hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)grid), dim3(NTHR), SMEM_WINO + p.Cin * 16, as_stream(stream), p, ntn, tx_n,
-                           per_img, (int)tiles);
+                           per_img, (int)tiles, ksplit, cper);
     } else {
         if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<0>, SMEM_WINO, m0))) return e;
         hipLaunchKernelGGL(conv_wino_kernel<0>, dim3((unsigned)grid), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img,
-                           (int)tiles);
+                           (int)tiles, ksplit, cper);
     }
     E4S_CHECK_LAUNCH();
+    if (ksplit > 1) return e4s_splitk_epilogue(p, ksplit, as_stream(stream));      // ordered slab sum + bias / activation (conv_bf16x3.hip)
     return 0;
 }

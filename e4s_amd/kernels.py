@@ -422,13 +422,20 @@ WINO = os.environ.get("E4S_WINO", "1") == "1"        # policy switch of the Wino
 
 
 def wino_eligible(b, h, w, cin, cout):
-    """Shapes e4s_conv_wino_bf16x3_f32 covers, and whether the launch fills the chip (one 16x16-pixel x 128-column tile per block)."""
+    """Shapes e4s_conv_wino_bf16x3_f32 covers, and whether the launch fills the chip (one 16x16-pixel x 128-column tile per block; launches
+    of <= 128 tiles split the input-channel chunks over blocks, csrc/conv_wino.hip:wino_split)."""
     if not WINO or PRECISION == "f32":
         return False
     if h % 16 or w % 16 or cin % 16 or cin < 32 or cout % 128:
         return False
+    if PRECISION == "bf16x3":
+        return True
     tiles = b * (h // 16) * (w // 16) * (cout // 128)
-    return PRECISION == "bf16x3" or tiles >= BF16X3_MIN_BLOCKS
+    if tiles >= BF16X3_MIN_BLOCKS:
+        return True
+    nchunk = cin // 16
+    split = min(nchunk // 2, -(-256 // tiles)) if nchunk >= 4 else 1
+    return tiles * max(split, 1) >= 64
 
 
 def wino_weights(w9):
@@ -459,15 +466,21 @@ def conv_wino(x, u, cout, *, in_stats=None, bias=None, slope=None, act=0, alpha=
     p.act, p.alpha, p.gain = act, alpha, gain
     p.in_stats = fptr(in_stats)
     fused = None
-    if want_stats:
-        if act != 0:
-            raise RuntimeError("conv_wino: output statistics are those of the raw conv output (act = 0)")
+    if want_stats and act != 0:
+        raise RuntimeError("conv_wino: output statistics are those of the raw conv output (act = 0)")
+    nws = lib.load().e4s_conv_wino_ws_floats(ctypes.byref(p))            # split-K slabs (few-tile launches)
+    skws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
+    p.splitk_ws = fptr(skws)
+    if want_stats and not nws:
         slots = (h // 16) * (w // 16)
         fused = torch.empty(b * cout * slots * 2, device=x.device, dtype=torch.float64)
         p.stats_ws, p.stats_slots = ptr(fused), slots
     call("e4s_conv_wino_bf16x3_f32", ctypes.byref(p), stream())
     if fused is None:
-        return y
+        if not want_stats:
+            return y
+        stats, pooled = instnorm_stats(y, want_pooled=True)              # split launch: the separate statistics pass
+        return y, (stats, se_gate(pooled, se[0], se[1]) if se is not None else pooled)
     stats = torch.empty(b, cout, 2, device=x.device, dtype=torch.float32)
     pooled = torch.empty(b, cout, device=x.device, dtype=torch.float32)
     if se is not None:

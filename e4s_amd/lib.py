@@ -122,6 +122,7 @@ SIGNATURES = {
     "e4s_wino_weights_bytes": [c_i, c_i],
     "e4s_wino_weights_f32": [c_p, c_p, c_i, c_i, c_p],
     "e4s_conv_wino_covers": [c_p],
+    "e4s_conv_wino_ws_floats": [c_p],
     "e4s_conv_wino_bf16x3_f32": [c_p, c_p],
     "e4s_adam_multi_dev_f32": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_d, c_d, c_d, c_d, c_p],
     "e4s_ema_multi_f32": [c_i, c_p, c_p, c_p, c_d, c_p],
@@ -186,7 +187,7 @@ SIGNATURES = {
 }
 
 INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats", "e4s_conv_region_ws_floats", "e4s_lpips_layer_ws_doubles", "e4s_conv_mfma_ws_floats",
-                "e4s_cosine_ws_doubles", "e4s_colsum_ws_floats", "e4s_scale_dot_ws_floats", "e4s_wino_weights_bytes"}       # size queries: return a count, not an error code
+                "e4s_cosine_ws_doubles", "e4s_colsum_ws_floats", "e4s_scale_dot_ws_floats", "e4s_wino_weights_bytes", "e4s_conv_wino_ws_floats"}       # size queries: return a count, not an error code
 
 _lib = None
 

@@ -395,12 +395,14 @@ int e4s_ema_multi_f32(int count, float* const* dst, const float* const* src, con
  * e4s_wino_weights_f32: w9 [9][Cout][Cin] (tap-packed, e4s_pack_taps_f32) -> the kernel's transformed, hi/lo-split operand
  * (e4s_wino_weights_bytes(Cout, Cin) bytes, opaque).
  * e4s_conv_wino_bf16x3_f32: p->x / p->y NHWC, p->w = that operand; covered: istride = ostride = 1, ntaps 9, ncls 1, H % 16 == W % 16 == 0,
- * Cin % 16 == 0 (>= 32), Cout % 128 == 0, no styles / labels / noise / plan / split-K / y_cstride; honoured: in_stats (InstanceNorm folded
+ * Cin % 16 == 0 (>= 32), Cout % 128 == 0, no styles / labels / noise / plan / y_cstride; launches of <= 128 tiles split the input channels over blocks (p->splitk_ws:
+ * e4s_conv_wino_ws_floats floats; stats_ws is ignored then); honoured: in_stats (InstanceNorm folded
  * into the input transform), bias, act (0 none, 1 leaky * gain, 2 PReLU with p->slope), stats_ws / stats_slots (per-tile {sum, sum^2} of the
  * output as e4s_conv_bf16x3_f32 emits them).  e4s_conv_wino_covers: 1 if the launch would be accepted.  Everything else: hipErrorInvalidValue. */
 int64_t e4s_wino_weights_bytes(int Cout, int Cin);
 int e4s_wino_weights_f32(const float* w9, void* out, int Cout, int Cin, void* stream);
 int e4s_conv_wino_covers(const e4s_conv_params* p);
+int64_t e4s_conv_wino_ws_floats(const e4s_conv_params* p);   /* split-K slabs for p->splitk_ws (launches of <= 128 tiles); 0: none */
 int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* p, void* stream);
 /* Exact up-sampling StyledConv on the split-bf16 matrix-core path (csrc/upconv_bf16x3.hip): conv_transpose2d(stride 2) +
  * Blur (src/models/stylegan2/model.py:287-300, 206-213) + NoiseInjection + FusedLeakyReLU (:396-404) in one kernel, one style
