@@ -24,10 +24,12 @@
 // U of the current and the next stage (4 positions x 128 channels x 64-byte rows).  Rows are 64 bytes WITHOUT padding; the 16-byte granule
 // index is XORed with (row >> 2) & 3, which makes every ds_read_b128 fragment read conflict free (the lane groups of a wave64 b128 read
 // hold rows r, r+12, r+20, r+24 (mod 4 classes) whose (row >> 2) & 3 differ) -- vertical taps shift a fragment by 8 rows and keep that.
-// The input transform runs on the way into LDS: a work item = (V-pixel, 4 channels): four 16-byte loads, [InstanceNorm folded in: the
-// mean cancels in the three differences], 16 values split to hi / lo, eight 8-byte LDS stores.  The 576 items of chunk c+1 are spread
-// over the three stages of chunk c, three waves per stage, rotating through the eight waves (the staging wave's MFMAs run under its SIMD
-// partner's).
+// Weights arrive by LDS-DMA (global_load_lds_dwordx4; the DMA image is lane-linear, so the swizzle is applied to the SOURCE granule).
+// The input transform runs on the way into LDS, one stage behind its loads: a work item = (V-pixel, 4 channels): four 16-byte loads in
+// stage s; in stage s+1, folded between the storer wave's own MFMAs: [InstanceNorm from a {mean, rstd} table in LDS: the mean cancels in
+// the three differences], 16 values split to hi / lo, eight 8-byte LDS stores.  The 576 items of chunk c+1 are spread over the three
+// stages of chunk c, three waves per stage, rotating through the eight.
+// Persistent (grid = min(tiles, CUs); the pipeline runs through the tile boundary) and split-K for launches of <= 128 tiles.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
