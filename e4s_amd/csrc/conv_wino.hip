@@ -318,8 +318,9 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                 };
                 // the MFMA section, with the storer's transform parts folded in (STORE is a compile-time copy: a branch around the VALU
                 // block would pin it outside the MFMA stream)
-                auto body = [&](auto store_tag) {
+                auto body = [&](auto store_tag, auto load_tag) {
                     constexpr bool STORE = decltype(store_tag)::value;
+                    constexpr bool LOAD = decltype(load_tag)::value;
                     AF A0, A1;
                     BF B0, B1;
                     ldB(B0, 0);
@@ -345,6 +346,8 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                             ldA(Anx, ps + 1);
                         }
                         if (STORE) item_part(An, I, ps);
+                        // the loader's address arithmetic + four 16-byte loads ride between the first group's MFMAs instead of in front of them
+                        if (LOAD && ps == 0) item_load(l_in ? cur : nxt, ((ts + 1) % 3) * 192 + lslot * 64 + lane, lc, I);
                         if (VAR != 6) {
                             acc[ps][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[0], Bc.h, acc[ps][0], 0, 0, 0);
                             acc[ps][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[1], Bc.h, acc[ps][1], 0, 0, 0);
@@ -364,15 +367,23 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                                 __builtin_amdgcn_sched_group_barrier(0x306, 9, 0);      // then up to 9 VALU / SALU / DS
                             }
                         }
+                        if (LOAD && ps == 0) {
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x126, 12, 0);     // then up to 12 VALU / SALU / VMEM-read / DS-read
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
                 if (storer) {
-                    body(std::true_type{});
+                    body(std::true_type{}, std::false_type{});
+                } else if (loader) {
+                    body(std::false_type{}, std::true_type{});
+                    if (VAR == 7) asm volatile("" ::"v"(I.d[0]), "v"(I.d[1]), "v"(I.d[2]), "v"(I.d[3]));
                 } else {
-                    if (loader) item_load(l_in ? cur : nxt, ((ts + 1) % 3) * 192 + lslot * 64 + lane, lc, I);
-                    body(std::false_type{});
-                    if (VAR == 7 && loader) asm volatile("" ::"v"(I.d[0]), "v"(I.d[1]), "v"(I.d[2]), "v"(I.d[3]));
+                    body(std::false_type{}, std::false_type{});
                 }
                 if (VAR != 5) __syncthreads();
                 ++sg;
