@@ -4,6 +4,7 @@ under a live process group / eager and GRAPH-CAPTURED data-parallel G steps (buc
 bit for bit to the collective-free computation; (b) bench.py's own main() launched the way the driver launches N ranks."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -11,6 +12,24 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(cmd, timeout=900):
+    """Run a one-rank job on a fresh rendezvous port; one retry (a port can be taken between the probe and the rendezvous)."""
+    p = None
+    for _ in range(2):
+        p = subprocess.run(cmd, env=_env(_free_port()), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+        if p.returncode == 0:
+            break
+    return p
 
 
 def _env(port):
@@ -21,8 +40,7 @@ def _env(port):
 
 
 def test_world1_nccl_collectives_gather_and_graph_captured_ddp_step():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_world1_worker.py")], env=_env(29541), cwd=ROOT,
-                       capture_output=True, text=True, timeout=900)
+    p = _run([sys.executable, os.path.join(ROOT, "tests", "nccl_world1_worker.py")])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("NCCL_WORLD1 ")][-1]
     res = json.loads(line[len("NCCL_WORLD1 "):])
@@ -38,8 +56,7 @@ def test_world1_nccl_bench_main_runs_the_multi_rank_path():
     """bench.py under the driver's launch protocol (RANK / WORLD_SIZE / MASTER_* in the environment) with one rank and forced
     collectives: init_process_group('nccl', device_id=...), GraphedFaceSwap captured in thread_local mode, OverlappedGather of the uint8
     images on RCCL's stream, barrier, MAX all-reduce of the time, the JSON line."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--steps-only"],
-                       env=_env(29543), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    p = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--steps-only"])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 50 and "forced collectives" in line["config"]["parallelism"], line
