@@ -447,3 +447,42 @@ def test_train_iteration_forgets_targets_per_batch_and_refuses_steps_it_cannot_c
         p.requires_grad = False
     with pytest.raises(RuntimeError, match="capturable"):
         it.graphed_g_step(img, img)
+
+
+def test_winograd_f23_row_algebra_of_conv_wino_hip():
+    """The arithmetic csrc/conv_wino.hip implements, restated in fp64 torch and checked against F.conv2d: pairs of output columns, the four
+    positions V0..V3 / U0..U3, the three vertical taps as separate contractions, out = (M0+M1+M2, M1-M2-M3); and the InstanceNorm fold of
+    its input transform (padded pixels take the MEAN so that they are zero in the normalised map; the mean cancels in V0, V2, V3)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    b, cin, cout, h, w = 2, 5, 7, 6, 8
+    x = torch.randn(b, cin, h, w, generator=g, dtype=torch.float64) * 1.5 + 0.7
+    wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64)
+    mu = x.mean((2, 3), keepdim=True)
+    rs = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False, keepdim=True) + 1e-5)
+
+    def wino(x, fold):
+        # halo with the kernel's padding rule: 0, or the per-channel mean when the normalisation is folded in
+        fill = mu if fold else torch.zeros_like(mu)
+        xp = fill.expand(b, cin, h + 2, w + 2).clone()
+        xp[:, :, 1:-1, 1:-1] = x
+        out = torch.zeros(b, cout, h, w, dtype=torch.float64)
+        for j in range(w // 2):
+            d = [xp[:, :, :, 2 * j + i] for i in range(4)]                      # columns 2j-1 .. 2j+2 of every halo row: [b, cin, h+2]
+            if fold:
+                v = [(d[0] - d[2]) * rs[..., 0], ((d[1] - mu[..., 0]) + (d[2] - mu[..., 0])) * rs[..., 0], (d[2] - d[1]) * rs[..., 0],
+                     (d[1] - d[3]) * rs[..., 0]]
+            else:
+                v = [d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]]
+            m = [torch.zeros(b, cout, h, dtype=torch.float64) for _ in range(4)]
+            for ky in range(3):
+                g0, g1, g2 = wt[:, :, ky, 0], wt[:, :, ky, 1], wt[:, :, ky, 2]
+                u = [g0, ((g0 + g2) + g1) * 0.5, ((g0 + g2) - g1) * 0.5, g2]
+                for p in range(4):
+                    m[p] += torch.einsum("bcy,kc->bky", v[p][:, :, ky:ky + h], u[p])        # V_p[y + ky - 1] . U_p[ky]
+            out[:, :, :, 2 * j] = (m[0] + m[1]) + m[2]
+            out[:, :, :, 2 * j + 1] = (m[1] - m[2]) - m[3]
+        return out
+
+    assert float((wino(x, False) - F.conv2d(x, wt, padding=1)).abs().max()) < 1e-12
+    assert float((wino(x, True) - F.conv2d((x - mu) * rs, wt, padding=1)).abs().max()) < 1e-11
