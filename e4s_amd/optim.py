@@ -44,7 +44,7 @@ class FusedAdam(torch.optim.Optimizer):
                 d["lr"].fill_(float(group["lr"]))
                 d["lr_host"] = float(group["lr"])
             hyper = (tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"]))
-            if d["hyper"] is not None and d["hyper"] != hyper:
+            if d.get("captured") and d["hyper"] is not None and d["hyper"] != hyper:
                 raise RuntimeError("FusedAdam: betas / eps / weight_decay changed after a step was captured; re-capture the GraphedStep")
 
     def _flat_steps(self, d, plist, device):
@@ -106,6 +106,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if not capturing:
                     self.sync_hyper()
                 d["hyper"] = (tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"]))
+                if capturing:
+                    d["captured"] = True          # these values are now baked into a graph's kernel arguments
                 with_state = [p for p in group["params"] if p in self.state and "exp_avg" in self.state[p]]
                 flat = self._flat_steps(d, with_state, dev)
                 if len(live) == len(with_state):
