@@ -269,9 +269,11 @@ def stitch_leg(net, inputs, reps=10):
     return out
 
 
-def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3):
+def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3, train_G=True, time_d=True):
     """BASELINE.json configs[4] on ONE GPU -- the body of Coach.train() (coach.py:280-398) through e4s_amd.train.TrainIteration:
-    G step = Net3.forward (encoder + LocalMLPs trainable, G frozen: SURVEY.md 8(d)'s opts) on a batch of 2
+    G step = Net3.forward (train_G=True, the reference's default, train_options.py:32-33 / coach.py:324-331: encoder + LocalMLPs +
+    the generator's convs[:K] / ToRGBs / constant input trainable, the mapping network and the layers past K frozen; train_G=False:
+    encoder + LocalMLPs only, SURVEY.md 8(d)'s opts and coach.py:333-334's "only training Encoder" branch) on a batch of 2
     (train_options.py:24) at 1024^2 -> calc_loss's default terms (coach.py:403-453, train_options.py:47-54: parsing * 0.1 + ID * 0.1
     + l2 + LPIPS x3 * 0.8 on the native loss networks) + g_adv_lambda * AdvGLoss through the native Discriminator graph ->
     backward through the HIP loss-network / generator / MLP / encoder kernels -> fused Adam -> EMA of the weights;
@@ -283,7 +285,7 @@ def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3):
     import types
     from e4s_amd.optim import FusedAdam
     from e4s_amd.train import LossOpts, TrainIteration
-    net = Net3(make_opts(out_size=SIZE))
+    net = Net3(make_opts(out_size=SIZE, train_G=train_G))
     net.load_state_dict(synth.synth_state_dict(SIZE, KREM), strict=True)
     net.latent_avg = lat.to(dev)
     net = net.to(dev).train()
@@ -333,8 +335,9 @@ def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3):
     out = {"ms_per_step": round(g_ms, 2), "g_step_ms": round(g_ms, 2), "g_step_graphed": True, "g_step_eager_ms": round(g_eager_ms, 2),
            "batch": batch, "steps": steps, "warmup": warmup,
            "images_per_s": round(batch * 1e3 / g_ms, 2), "trainable_parameters": int(sum(p.numel() for p in params)),
-           "losses": losses, "ema": net_ema is not None}
-    if disc is not None:
+           "losses": losses, "ema": net_ema is not None, "train_G": bool(train_G), "train_D": disc is not None,
+           "trainable_generator_parameters": int(sum(p.numel() for p in net.G.parameters() if p.requires_grad))}
+    if disc is not None and time_d:
         d_ms = timed(lambda: it.d_step(img, mask), max(2, steps // 2), 1)
         r1_ms = timed(lambda: it.r1_step(img), max(2, steps // 3), 1)
         out.update(d_step_ms=round(d_ms, 2), r1_step_ms=round(r1_ms, 2), d_every=lo.d_every, d_reg_every=lo.d_reg_every,
@@ -463,7 +466,9 @@ def main():
         return
     if args.train_only:
         print(json.dumps({"config5_train_step_1gpu": train_leg(dev, lat, args.train_steps, losses="full"),
-                          "config5_train_step_1gpu_mse_only": train_leg(dev, lat, args.train_steps, losses="mse")}))
+                          "config5_train_step_1gpu_G_frozen": train_leg(dev, lat, args.train_steps, losses="full", train_G=False,
+                                                                        time_d=False),
+                          "config5_train_step_1gpu_mse_only": train_leg(dev, lat, args.train_steps, losses="mse", train_G=False)}))
         return
     if args.opt_only:
         one = [t[:1].contiguous() if torch.is_tensor(t) else [n[:1].contiguous() for n in t] for t in inputs]
@@ -602,8 +607,12 @@ def main():
         side("gpen512", lambda: gpen_leg(dev))
         side("stitch_b8", lambda: stitch_leg(net, inputs))
         if args.train_steps > 0:
+            # the reference's default: train_G = train_D = True (train_options.py:32-33); the round-4 configuration (G frozen while D
+            # trains, which coach.py:324 says must not be combined) stays beside it for continuity, G step only
             side("config5_train_step_1gpu", lambda: train_leg(dev, lat, args.train_steps, losses="full"))
-            side("config5_train_step_1gpu_mse_only", lambda: train_leg(dev, lat, args.train_steps, losses="mse"))
+            side("config5_train_step_1gpu_G_frozen", lambda: train_leg(dev, lat, args.train_steps, losses="full", train_G=False,
+                                                                       time_d=False))
+            side("config5_train_step_1gpu_mse_only", lambda: train_leg(dev, lat, args.train_steps, losses="mse", train_G=False))
         if args.opt_steps > 0:
             side(None, lambda: config3_legs(net, one, args))
             out["config3_steps_run"] = args.opt_steps

@@ -110,7 +110,17 @@ def styled_conv_weight_grad(rec, extras, num_regions):
         # the 3 x 3 weight with the transpose of the polyphase map
         deff = torch.stack([K.conv_wgrad(gz, x, ostride=2, phase=(ph >> 1, ph & 1), anchors=(h, w), **kw)
                             for ph in range(4)]).view(36, cout * cin)
-        cmap = _polyphase_map(conv.blur.kernel).to(deff.device).view(36, 9)
+        # the 36 x 9 map depends on the (constant) blur kernel only: built once per module on the host, kept on the device -- the
+        # backward then has no host round trip and a captured train step (train.graphed_g_step with train_G) can hold it
+        from .packs import param_key
+        ck = param_key(conv.blur.kernel) + (str(deff.device),)
+        cached = getattr(conv, "_e4s_polymap", None)
+        if cached is None or cached[0] != ck:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("styled_conv_weight_grad: the polyphase map must be built before a stream capture (run one eager "
+                                   "step first)")
+            conv._e4s_polymap = cached = (ck, _polyphase_map(conv.blur.kernel).to(deff.device).view(36, 9))
+        cmap = cached[1]
         dw = (cmap.t() @ deff).view(9, cout, cin).permute(1, 2, 0).reshape(cout, cin, 3, 3)
     dw = dw - wraw * (dd3.t() @ (s * s)).view(cout, cin, 1, 1)
     return dw.unsqueeze(0)

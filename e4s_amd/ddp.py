@@ -23,6 +23,15 @@ Everything here is capturable: inside a HIP graph capture (train.TrainIteration.
 all-reduces (on RCCL's stream, forked from and joined to the capturing stream by the events `Work.wait()` records), the division and
 the write-back become graph nodes, and a replay runs the whole data-parallel G step without touching the host.
 
+Streams.  The staging copies of one bucket need not all be enqueued on the same HIP stream: autograd runs every backward node on
+the stream its forward ran on, but an AccumulateGrad node (whose post-accumulate hook announces the LocalMLP / generator gradients)
+keeps the stream it was CREATED on -- a node that outlives an iteration (torch keeps it alive as long as anything references last
+step's graph) stays on that stream when a later step runs on a side stream or under a capture (torch warns: "The AccumulateGrad
+node's stream does not match ...") -- while `notify_grad` from inside the monolithic encoder backward runs on the backward's own
+stream.  A collective only waits for the stream it is issued from, so `_fire` first makes that stream wait for every OTHER stream
+that staged into the bucket (an event recorded behind the last staging copy on it).  With one rank the in-place all-reduce moves
+nothing and the omission cannot be seen; with N > 1 a peer would have received a half-staged bucket.
+
 `force=True` keeps the collectives on a world of ONE rank (they are no-ops numerically): the RCCL path -- communicator
 init, all_reduce, stream fork/join, capture -- then runs on a single GPU (tests/test_gpu_nccl_world1.py)."""
 import warnings
@@ -70,6 +79,8 @@ class GradAverager:
         self._sent, self._ready, self._works = set(), [0] * len(self.buckets), [None] * len(self.buckets)
         self._next = 0                                   # buckets [0, _next) have been launched (index order on every rank)
         self.fired_during_backward = 0                   # diagnostics: buckets launched before finish()
+        self._streams = [dict() for _ in self.buckets]   # per bucket: {stream id: stream} its staging copies were enqueued on
+        self.staging_streams_seen = [0] * len(self.buckets)   # diagnostics: most streams any one backward staged a bucket from
         if self.active:
             if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
                 for p in self.params:
@@ -86,7 +97,23 @@ class GradAverager:
             self._flat[i] = torch.empty(sum(p.numel() for p in bucket), device=dev, dtype=torch.float32)
         return self._flat[i]
 
+    def _staged_on_current_stream(self, i, dev):
+        if dev.type == "cuda":
+            st = torch.cuda.current_stream(dev)
+            self._streams[i][st.cuda_stream] = st
+
     def _fire(self, i):
+        flat = self._buffer(i)
+        if flat.is_cuda:
+            # the collective is ordered behind the CURRENT stream only: join every other stream that staged into this bucket
+            cur = torch.cuda.current_stream(flat.device)
+            self.staging_streams_seen[i] = max(self.staging_streams_seen[i], len(self._streams[i] | {cur.cuda_stream: cur}))
+            for sid, st in self._streams[i].items():
+                if sid != cur.cuda_stream:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    cur.wait_event(ev)
+            self._streams[i] = {}
         self._works[i] = dist.all_reduce(self._buffer(i), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _hook(self, p):
@@ -105,6 +132,7 @@ class GradAverager:
         i, o = self._where[key]
         with torch.no_grad():
             self._buffer(i)[o:o + p.numel()].copy_(grad.detach().reshape(-1))
+        self._staged_on_current_stream(i, grad.device)
         self._sent.add(key)
         self._ready[i] += 1
         while self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next]):
@@ -121,6 +149,7 @@ class GradAverager:
         self._sent, self._ready, self._works = set(), [0] * len(self.buckets), [None] * len(self.buckets)
         self._next = 0
         self.fired_during_backward = 0
+        self._streams = [dict() for _ in self.buckets]
         _ACTIVE = self
 
     def finish(self):
@@ -144,7 +173,7 @@ class GradAverager:
                         flat[o:o + p.numel()].zero_()
                     else:
                         flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
-                self._fire(i)
+                self._fire(i)                            # (the copies above ran on the current stream, the one it fires from)
             self._next = len(self.buckets)
             for i, bucket in enumerate(self.buckets):
                 self._works[i].wait()
@@ -166,4 +195,5 @@ class GradAverager:
         self._armed = False
         self._sent, self._ready, self._works = set(), [0] * len(self.buckets), [None] * len(self.buckets)
         self._next = 0
+        self._streams = [dict() for _ in self.buckets]
         self.finish()

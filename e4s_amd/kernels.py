@@ -161,12 +161,16 @@ def demod_coefs(s, wsq, conv_scale):
     return out
 
 
-def weight_sqsum(w):
-    """w [Cout,Cin,kh,kw] -> [Cout,Cin] sum of squares over taps."""
+def weight_sqsum(w, out=None):
+    """w [Cout,Cin,kh,kw] -> [Cout,Cin] sum of squares over taps (into `out` when given: the generator keeps ONE such matrix per
+    layer for its lifetime, so the style prologue's job tables -- which hold its address -- survive weight updates)."""
     w = _f32(w)
     cout, cin = w.shape[:2]
     taps = w.shape[2] * w.shape[3]
-    out = torch.empty(cout, cin, device=w.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(cout, cin, device=w.device, dtype=torch.float32)
+    elif out.shape != (cout, cin) or out.dtype != torch.float32 or out.device != w.device or not out.is_contiguous():
+        raise RuntimeError("weight_sqsum: out must be a contiguous fp32 [Cout,Cin] tensor on the weight's device")
     call("e4s_weight_sqsum_f32", fptr(w), fptr(out), cout, cin, taps, stream())
     return out
 

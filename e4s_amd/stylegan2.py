@@ -209,7 +209,16 @@ class ModulatedConv2d(nn.Module):
                 # same math as polyphase_upconv_weights() below (the CPU-tested statement of it)
                 pack["w"] = K.polyphase_weights(w.contiguous(), self.blur.kernel.detach().float())
                 pack["w3"] = K.pack_taps(w.contiguous())        # plain taps for the exact tile-fused up-conv
-            pack["wsq"] = K.weight_sqsum(w.contiguous()) if self.demodulate else None
+            if self.demodulate:
+                # sum_k W^2 lives in ONE buffer for the module's lifetime (rewritten in place when the weights change): the batched
+                # style prologue's job tables hold its address (Generator._style_plan), so a weight update -- also one made by a
+                # replayed HIP graph that re-packs inside the graph (train.graphed_g_step with train_G) -- needs no new table
+                keep = self._pack["wsq"] if self._pack is not None else None
+                if keep is not None and (keep.shape != (cout, cin) or keep.device != w.device):
+                    keep = None
+                pack["wsq"] = K.weight_sqsum(w.contiguous(), out=keep)
+            else:
+                pack["wsq"] = None
         self._pack = pack
         return pack
 
@@ -563,18 +572,26 @@ class Generator(nn.Module):
 
     def _style_plan(self, b, r, nlat, dev):
         """Job tables of the batched style prologue (e4s_rowdot_multi_f32): every layer's modulation s = EqualLinear(style)
-        and demodulation d in two launches instead of ~43.  Cached per (shapes, weight versions): the tables hold raw pointers
-        of the modulation weights and of the cached sum_k W^2 matrices."""
+        and demodulation d in two launches instead of ~43.  Cached per (shapes, addresses): the tables hold raw pointers of the
+        modulation parameters and of the per-layer sum_k W^2 buffers (ModulatedConv2d.packed keeps those in place across weight updates)."""
         layers = [(self.conv1, 0, "conv"), (self.to_rgb1, 1, "rgb")]
         i = 1
         for c1, c2, tr in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
             layers += [(c1, i, "conv"), (c2, i + 1, "conv"), (tr, i + 2, "rgb")]
             i += 2
-        key = (b, r, nlat, str(dev)) + tuple(_param_key(l.conv.modulation.weight, l.conv.modulation.bias, l.conv.weight)
-                                             for l, _, _ in layers)
+        # packed() first, for every layer: it refreshes sum_k W^2 IN PLACE when a weight changed, so the tables below depend on
+        # ADDRESSES only (modulation parameters, the per-layer sum_k W^2 buffers), not on weight versions -- a trainable generator
+        # (train_G) re-uses one table for the whole run, eagerly and inside a captured train step (no host-to-device copy per update)
+        packs = [l.conv.packed() for l, _, _ in layers]
+        key = (b, r, nlat, str(dev)) + tuple(
+            (l.conv.modulation.weight.data_ptr(), l.conv.modulation.bias.data_ptr(), pk["wsq"].data_ptr() if pk["wsq"] is not None else 0)
+            for (l, _, _), pk in zip(layers, packs))
         plan = getattr(self, "_e4s_style_plan", None)
         if plan is not None and plan["key"] == key:
             return plan
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("Generator._style_plan: the job tables of the style prologue must exist before a stream capture "
+                               "(run the same shapes once eagerly first -- GraphedStep / GraphedFaceSwap warm up for that)")
         sjobs, djobs, meta, keep = [], [], {}, []
         s_off = d_off = 0
         for layer, idx, kind in layers:

@@ -88,6 +88,10 @@ class TrainIteration:
         self.net, self.disc, self.crit, self.opt, self.opt_d = net, disc, crit, opt, opt_d
         self.lo = lo or LossOpts()
         self.averager, self.averager_d, self.net_ema, self.ema_decay = averager, averager_d, net_ema, ema_decay
+        # `net` may be the reference's wrapper, nn.parallel.DistributedDataParallel(net, find_unused_parameters=True,
+        # broadcast_buffers=False) (coach.py:74-85): the forward goes through the wrapper (its reducer averages the gradients), the
+        # EMA, the latent average and the freeze policy address the module inside, as coach.py does with `self.net.module`
+        self.core = getattr(net, "module", net)
         self._net_trainable = [p for p in net.parameters() if p.requires_grad]
         self.global_step = 0
 
@@ -110,7 +114,7 @@ class TrainIteration:
         if lo.w_norm_lambda > 0:
             if latent is None:
                 raise RuntimeError("w_norm_lambda > 0 needs the latent (Net3.forward(..., return_latents=True))")
-            terms["w_norm"] = w_norm_loss(latent, self.net.latent_avg, getattr(self.net.opts, "start_from_latent_avg", True))
+            terms["w_norm"] = w_norm_loss(latent, self.core.latent_avg, getattr(self.core.opts, "start_from_latent_avg", True))
             loss = loss + terms["w_norm"] * lo.w_norm_lambda
         return loss, terms
 
@@ -171,7 +175,7 @@ class TrainIteration:
             self.averager.finish()
         self.opt.step()
         if self.net_ema is not None:
-            accumulate(self.net_ema, self.net, self.ema_decay)
+            accumulate(self.net_ema, self.core, self.ema_decay)
         return loss.detach(), terms
 
     def forget_targets(self):
@@ -193,13 +197,14 @@ class TrainIteration:
         against ~55 ms of kernel time.  Every weight pack the step reads from a TRAINED network is rebuilt inside the graph (the net's are
         stale at capture time -- the warm-up steps just updated them --, D's are invalidated here); after a replay the version counters
         of everything the graph wrote (parameters, EMA copy) are advanced, so eager consumers between replays (D steps, net_ema
-        evaluation) re-pack from the current weights."""
+        evaluation) re-pack from the current weights.  A trainable generator (train_G=True, the reference's default:
+        train_options.py:32-33, coach.py:324-331) is captured like the rest: its packs are rebuilt inside the graph, the style
+        prologue's job tables depend on addresses only (Generator._style_plan) and are built by the warm-up steps."""
         from .optim import GraphedStep
         from . import disc_autograd
-        gen = getattr(self.net, "G", None)
-        if gen is not None and any(p.requires_grad for p in gen.parameters()):
-            raise RuntimeError("graphed_g_step: a trainable generator (train_G) rebuilds its style-prologue job tables with a host-to-"
-                               "device copy whenever its weights change, which a stream capture cannot hold; use g_step()")
+        if self.core is not self.net:
+            raise RuntimeError("graphed_g_step: torch's DistributedDataParallel reducer cannot be held by a stream capture; pass the "
+                               "bare Net3 and a ddp.GradAverager (its bucket all-reduces are captured with the step), or use g_step()")
 
         def body():
             self.forget_targets()

@@ -1,7 +1,7 @@
 """RCCL on the one GPU that is reachable (VERDICT r3 'missing' 1-2, 'next' 5): a world of ONE rank on backend "nccl" with the
 collectives forced on, in subprocesses -- (a) tests/nccl_world1_worker.py: gather / overlapped gather / a face-swap graph captured
-under a live process group / eager and GRAPH-CAPTURED data-parallel G steps (bucket all-reduces inside the HIP graph), each equal
-bit for bit to the collective-free computation; (b) bench.py's own main() launched the way the driver launches N ranks."""
+under a live process group / eager and GRAPH-CAPTURED data-parallel G steps (bucket all-reduces inside the HIP graph) / torch's own
+DistributedDataParallel around Net3, each equal bit for bit to the collective-free computation; (b) bench.py's own main() launched the way the driver launches N ranks."""
 import json
 import os
 import socket
@@ -23,13 +23,10 @@ def _free_port():
 
 
 def _run(cmd, timeout=900):
-    """Run a one-rank job on a fresh rendezvous port; one retry (a port can be taken between the probe and the rendezvous)."""
-    p = None
-    for _ in range(2):
-        p = subprocess.run(cmd, env=_env(_free_port()), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
-        if p.returncode == 0:
-            break
-    return p
+    """Run a one-rank job on a fresh rendezvous port.  No retry: round 4 answered one unexplained failure of this file with a second
+    attempt; round 5 made the worker say WHAT differs, stress-ran it (tools/nccl_world1_stress.py, profiles/r05_nccl_world1_stress.json)
+    and took the retry out -- a failure here is a defect to be read, not a transient to be absorbed."""
+    return subprocess.run(cmd, env=_env(_free_port()), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
 
 
 def _env(port):
@@ -40,26 +37,20 @@ def _env(port):
 
 
 KEYS = ("gather_outputs_equal", "overlapped_gather_equal", "overlapped_gather_works_were_real", "graphed_swap_equal_eager",
-        "graphed_swap_gather_equal", "averager_active", "eager_averaged_step_equal", "graphed_averaged_step_equal")
-
-
-def _worker_once():
-    p = _run([sys.executable, os.path.join(ROOT, "tests", "nccl_world1_worker.py")])
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    line = [ln for ln in p.stdout.splitlines() if ln.startswith("NCCL_WORLD1 ")][-1]
-    return json.loads(line[len("NCCL_WORLD1 "):])
+        "graphed_swap_gather_equal", "averager_active", "eager_averaged_step_equal", "graphed_averaged_step_equal", "torch_ddp_step_equal")
 
 
 def test_world1_nccl_collectives_gather_and_graph_captured_ddp_step():
-    res = _worker_once()
+    """train_G=True in the data-parallel sections (the reference's default): GradAverager eager / captured, and torch's own
+    DistributedDataParallel(find_unused_parameters=True, broadcast_buffers=False) around Net3 as coach.py:74-85 wraps it."""
+    p = _run([sys.executable, os.path.join(ROOT, "tests", "nccl_world1_worker.py")])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("NCCL_WORLD1 ")][-1]
+    res = json.loads(line[len("NCCL_WORLD1 "):])
     print(res)
-    if not all(res.get(k) is True for k in KEYS):
-        # seen once in ~8 runs inside the full suite, never in isolation and never twice: a second attempt separates a transient of the
-        # box from a defect (which fails again); both results go into the message
-        first, res = res, _worker_once()
-        print("second attempt:", res)
-        assert all(res.get(k) is True for k in KEYS), (first, res)
-    assert res["backend"] == "nccl"
+    bad = [k for k in KEYS if res.get(k) is not True]
+    assert not bad, (bad, res["diffs"], res)
+    assert res["backend"] == "nccl" and res["train_G"] is True
     assert res["buckets_fired_during_backward"] >= 1, res          # at least one all-reduce left while the backward was still running
 
 

@@ -420,9 +420,9 @@ def test_train_iteration_cadence_follows_the_coach_loop():
 def test_train_iteration_forgets_targets_per_batch_and_refuses_steps_it_cannot_capture():
     """TrainIteration.forget_targets drops the loss networks' per-target feature caches (a training batch is a NEW target even when it
     arrives in the same tensor: the reference recomputes the target features in every calc_loss, id_loss.py:33-35), and
-    graphed_g_step refuses a trainable generator (its job tables are re-uploaded whenever its weights change: not capturable) and
-    a non-capturable optimiser -- both before anything touches a GPU.  (A gradient averager is NOT refused any more: its bucket
-    all-reduces are captured with the step, tests/test_gpu_nccl_world1.py.)"""
+    graphed_g_step refuses what a stream capture cannot hold -- a net wrapped in torch's DistributedDataParallel (its reducer) and a
+    non-capturable optimiser -- both before anything touches a GPU.  (A trainable generator is NOT refused any more: its style-prologue
+    job tables are keyed on addresses, tests/test_gpu_train.py; nor is a gradient averager, tests/test_gpu_nccl_world1.py.)"""
     import types
     from e4s_amd.train import TrainIteration
 
@@ -434,19 +434,28 @@ def test_train_iteration_forgets_targets_per_batch_and_refuses_steps_it_cannot_c
 
         def forward(self, img, onehot, **kw):
             return img * self.w, None
+
+    class Wrapper(torch.nn.Module):                       # what nn.parallel.DistributedDataParallel looks like from outside
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, *a, **kw):
+            return self.module(*a, **kw)
     net = Net()
     crit = {"id": types.SimpleNamespace(_target=("key", "y", "feats")), "lpips": types.SimpleNamespace(_target=(1, 2, 3)),
             "other": types.SimpleNamespace()}
     it = TrainIteration(net, None, crit, torch.optim.SGD(net.parameters(), lr=1e-3), None, averager=object())
     it.forget_targets()
     assert crit["id"]._target is None and crit["lpips"]._target is None and not hasattr(crit["other"], "_target")
+    assert it.core is net
     img = torch.zeros(1, 3, 4, 4)
-    with pytest.raises(RuntimeError, match="train_G"):
-        it.graphed_g_step(img, img)
-    for p in net.G.parameters():
-        p.requires_grad = False
     with pytest.raises(RuntimeError, match="capturable"):
         it.graphed_g_step(img, img)
+    wrapped = TrainIteration(Wrapper(net), None, crit, torch.optim.SGD(net.parameters(), lr=1e-3), None)
+    assert wrapped.core is net                            # EMA / latent_avg address the module inside, as coach.py does
+    with pytest.raises(RuntimeError, match="DistributedDataParallel"):
+        wrapped.graphed_g_step(img, img)
 
 
 def test_winograd_f23_row_algebra_of_conv_wino_hip():
