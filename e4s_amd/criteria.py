@@ -244,7 +244,7 @@ class Backbone(Module):
         n0 = K.instnorm_apply(stem["c0"], st0)
         dn0, _ = K.prelu_bwd(dx, n0, prelu0.weight.detach())
         dc0 = K.norm_bwd_frozen(dn0, st0)
-        return K.conv_smallcin_bwd(dc0, _smallcin_pack(conv0), tuple(stem["x112"].shape), 3, 1, 1)
+        return K.conv_smallcin_bwd(dc0, _smallcin_pack(conv0), tuple(stem["x112"].shape), 3, 1, 1, cache=_smallcin_cache(conv0))
 
     def forward(self, x, multi_scale=False):
         """model_irse.py:44-69: NCHW [B,3,112,112] -> list of l2-normalised feature rows."""
@@ -257,8 +257,14 @@ class Backbone(Module):
 def _smallcin_pack(conv):
     key = param_key(conv.weight)
     if getattr(conv, "_e4s_small", None) is None or conv._e4s_small[0] != key:
-        conv._e4s_small = (key, K.pack_smallcin(conv.weight))
+        conv._e4s_small = (key, K.pack_smallcin(conv.weight), {})      # the dict: derived images of this pack (conv_smallcin_bwd's GEMM form)
     return conv._e4s_small[1]
+
+
+def _smallcin_cache(conv):
+    """The per-pack cache handed to K.conv_smallcin_bwd (lives and dies with the pack of THIS conv)."""
+    _smallcin_pack(conv)
+    return conv._e4s_small[2]
 
 
 class _IDLossFn(torch.autograd.Function):
@@ -433,7 +439,7 @@ class AlexNet(Module):
         d2, _ = K.prelu_bwd(dist_bwd(1, K.maxpool3s2_bwd(dp2, tape["i2"], tuple(f2.shape))), f2, zero[192])
         dp1 = K.conv_mfma(d2, _pack(_transposed(L[3])), 64, ntaps=25, spatial=False)
         d1, _ = K.prelu_bwd(dist_bwd(0, K.maxpool3s2_bwd(dp1, tape["i1"], tuple(f1.shape))), f1, zero[64])
-        dx0 = K.conv_smallcin_bwd(d1, _smallcin_pack(L[0]), tape["x0"], 11, 4, 2)
+        dx0 = K.conv_smallcin_bwd(d1, _smallcin_pack(L[0]), tape["x0"], 11, 4, 2, cache=_smallcin_cache(L[0]))
         scale, _ = self._affine()
         return K.adaptive_pool_bwd(dx0, img_shape, scale=scale, dx_acc=dimg)
 
@@ -648,7 +654,7 @@ class unet(Module):
             da = _conv3x3(K.relu_bwd(g, rec["f"]), _transposed(t2), cout)
             du = K.relu_bwd(da, rec["a"])
             if i == 0:
-                return K.conv_smallcin_bwd(du, _smallcin_pack(t1), rec["x_shape"], 3, 1, 1)
+                return K.conv_smallcin_bwd(du, _smallcin_pack(t1), rec["x_shape"], 3, 1, 1, cache=_smallcin_cache(t1))
             dp = _conv3x3(du, _transposed(t1), cin)
             d = K.maxpool2_bwd(dp, tape[i - 1]["idx"], tuple(tape[i - 1]["f"].shape))
 

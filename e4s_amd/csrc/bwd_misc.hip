@@ -37,7 +37,10 @@ __global__ void demod_grad_kernel(const float* __restrict__ gz, const float* __r
     for (int p = p0 + pg; p < p1; p += NPG) {
         const int yy = p / W, xx = p - yy * W;
         int lab = 0;
-        if (labels) lab = labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
+        if (labels) {
+            lab = labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
+            lab = lab < R ? lab : R - 1;                    // never index the LDS table with a label outside [0, R)
+        }
         const int64_t idx = ((int64_t)b * HW + p) * C + c;
         const float yv = y[idx];
         const float z = yv > 0.f ? yv * inv_pos : yv * inv_neg;
@@ -87,6 +90,10 @@ __global__ __launch_bounds__(256) void act_bwd_demod_kernel(const float* __restr
         if (labels) {
             const int yy = p / W, xx = p - yy * W;
             lab = labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
+            // a label outside [0, R) (a 255 "ignore" value, a num_regions mismatch) must not index the LDS table: its pixels still get
+            // their gz, their demodulation-gradient term goes to the last region's slot (e4s_mask_labels never produces such labels;
+            // the forward kernels clamp the same way)
+            lab = lab < R ? lab : R - 1;
         }
         if (lab != cur) {
             mine[cur * c4n] += acc;

@@ -147,7 +147,10 @@ __global__ void paste_kernel(const uint8_t* __restrict__ face, const uint8_t* __
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         // two rounded products and a rounded sum, as numpy evaluates it (no fused multiply-add)
-        const float v = __fadd_rn(__fmul_rn((float)face[i * 3 + c], m), __fmul_rn((float)target[i * 3 + c], im));
+        // (plain operators of THIS translation unit, which is under `fp contract(off)`; __fmul_rn / __fadd_rn are header inlines parsed
+        // before the pragma and were fused into one FMA -- see csrc/stitch.hip)
+        const float pf = (float)face[i * 3 + c] * m, pt = (float)target[i * 3 + c] * im;
+        const float v = pf + pt;
         out[i * 3 + c] = (uint8_t)v;
     }
 }

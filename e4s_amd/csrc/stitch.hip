@@ -14,11 +14,18 @@
 #include "common.h"
 
 // Every fp32 expression in this file restates an operation ORDER of OpenCV / numpy (one rounding per operation).  hipcc's default
-// -ffp-contract=fast may fuse a*b+c into one FMA, and __fmul_rn / __fadd_rn are plain operators in this ROCm's headers
-// (__clang_hip_math.h:271), so contraction is switched off for the whole translation unit.
+// -ffp-contract=fast-honor-pragmas may fuse a*b+c into one FMA, so contraction is switched off for the whole translation unit --
+// and the arithmetic goes through the helpers BELOW the pragma, not through __fmul_rn / __fadd_rn: those are plain operators in this
+// ROCm's headers (__clang_hip_math.h:271) whose inline bodies were parsed BEFORE the pragma, so they carry the `contract` flag and
+// `add_rn(a, mul_rn(b, 6.f))` compiled to v_fmamk_f32 (one rounding instead of two).  That was round 4's "unexplained 4 ulp"
+// between e4s_pyrup_f32 and the numpy statement of cv2.pyrUp (found in round 5 by reading the ISA for v_fmamk_f32, not only v_fma_f32).
 #pragma clang fp contract(off)
 
 namespace {
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }     // one IEEE rounding each, never fused (see above)
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
@@ -161,13 +168,13 @@ __global__ void pyrdown_kernel(const T* __restrict__ src, T* __restrict__ dst, i
         for (int j = 0; j < 5; ++j) {
             const T* rp = s + (int64_t)ys[j] * W * C;
             // row[x] = src[2x]*6 + (src[2x-1] + src[2x+1])*4 + src[2x-2] + src[2x+2]
-            const float a = __fmul_rn(ld(rp + (int64_t)xs[2] * C), 6.f);
-            const float b4 = __fmul_rn(__fadd_rn(ld(rp + (int64_t)xs[1] * C), ld(rp + (int64_t)xs[3] * C)), 4.f);
-            row[j] = __fadd_rn(__fadd_rn(__fadd_rn(a, b4), ld(rp + (int64_t)xs[0] * C)), ld(rp + (int64_t)xs[4] * C));
+            const float a = mul_rn(ld(rp + (int64_t)xs[2] * C), 6.f);
+            const float b4 = mul_rn(add_rn(ld(rp + (int64_t)xs[1] * C), ld(rp + (int64_t)xs[3] * C)), 4.f);
+            row[j] = add_rn(add_rn(add_rn(a, b4), ld(rp + (int64_t)xs[0] * C)), ld(rp + (int64_t)xs[4] * C));
         }
         // dst = (row2*6 + (row1 + row3)*4 + row0 + row4) * (1/256)
-        const float v = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(row[2], 6.f), __fmul_rn(__fadd_rn(row[1], row[3]), 4.f)), row[0]), row[4]);
-        dst[i] = (T)__fmul_rn(v, 1.f / 256.f);
+        const float v = add_rn(add_rn(add_rn(mul_rn(row[2], 6.f), mul_rn(add_rn(row[1], row[3]), 4.f)), row[0]), row[4]);
+        dst[i] = (T)mul_rn(v, 1.f / 256.f);
     }
 }
 
@@ -179,14 +186,14 @@ __device__ __forceinline__ float up_row(const float* rp, int x2, int w, int C) {
     const bool odd = x2 & 1;
     if (x == 0) {                                           // pyramids.cpp: t0 = src[x]*6 + src[x+cn]*2, t1 = (src[x] + src[x+cn])*4
         const float s0 = rp[0], s1 = rp[(int64_t)(w > 1 ? 1 : 0) * C];
-        return odd ? __fmul_rn(__fadd_rn(s0, s1), 4.f) : __fadd_rn(__fmul_rn(s0, 6.f), __fmul_rn(s1, 2.f));
+        return odd ? mul_rn(add_rn(s0, s1), 4.f) : add_rn(mul_rn(s0, 6.f), mul_rn(s1, 2.f));
     }
     if (x == w - 1) {                                       // t0 = src[sx-cn] + src[sx]*7, t1 = src[sx]*8
         const float sm = rp[(int64_t)(x - 1) * C], s0 = rp[(int64_t)x * C];
-        return odd ? __fmul_rn(s0, 8.f) : __fadd_rn(sm, __fmul_rn(s0, 7.f));
+        return odd ? mul_rn(s0, 8.f) : add_rn(sm, mul_rn(s0, 7.f));
     }
     const float sm = rp[(int64_t)(x - 1) * C], s0 = rp[(int64_t)x * C], sp = rp[(int64_t)(x + 1) * C];
-    return odd ? __fmul_rn(__fadd_rn(s0, sp), 4.f) : __fadd_rn(__fadd_rn(sm, __fmul_rn(s0, 6.f)), sp);
+    return odd ? mul_rn(add_rn(s0, sp), 4.f) : add_rn(add_rn(sm, mul_rn(s0, 6.f)), sp);
 }
 
 __global__ void pyrup_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w, int C, int64_t n) {
@@ -202,12 +209,12 @@ __global__ void pyrup_f32_kernel(const float* __restrict__ src, float* __restric
     const int ym = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yp = y < h - 1 ? y + 1 : h - 1;
     float v;
     if (y2 & 1) {
-        v = __fmul_rn(__fadd_rn(up_row(s + (int64_t)y * w * C, x2, w, C), up_row(s + (int64_t)yp * w * C, x2, w, C)), 4.f);
+        v = mul_rn(add_rn(up_row(s + (int64_t)y * w * C, x2, w, C), up_row(s + (int64_t)yp * w * C, x2, w, C)), 4.f);
     } else {
-        v = __fadd_rn(__fadd_rn(up_row(s + (int64_t)ym * w * C, x2, w, C), __fmul_rn(up_row(s + (int64_t)y * w * C, x2, w, C), 6.f)),
+        v = add_rn(add_rn(up_row(s + (int64_t)ym * w * C, x2, w, C), mul_rn(up_row(s + (int64_t)y * w * C, x2, w, C), 6.f)),
                       up_row(s + (int64_t)yp * w * C, x2, w, C));
     }
-    dst[i] = __fmul_rn(v, 1.f / 64.f);
+    dst[i] = mul_rn(v, 1.f / 64.f);
 }
 
 __global__ void u8_to_f32_kernel(const uint8_t* __restrict__ s, float* __restrict__ d, int64_t n) {
@@ -224,10 +231,10 @@ __global__ void lap_level_kernel(const T* __restrict__ a, const float* __restric
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float la = ld(a + i), lb = ld(b + i);
-    if (ua) { la = __fsub_rn(la, ua[i]); lb = __fsub_rn(lb, ub[i]); }
+    if (ua) { la = sub_rn(la, ua[i]); lb = sub_rn(lb, ub[i]); }
     const float gm = m[i];
-    const float ls = __fadd_rn(__fmul_rn(la, gm), __fmul_rn(lb, __fsub_rn(1.f, gm)));
-    out[i] = acc ? __fadd_rn(acc[i], ls) : ls;
+    const float ls = add_rn(mul_rn(la, gm), mul_rn(lb, sub_rn(1.f, gm)));
+    out[i] = acc ? add_rn(acc[i], ls) : ls;
 }
 
 // np.uint8(np.clip(img, 0, 255)) (multi_band_blending.py:73-74)

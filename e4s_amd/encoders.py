@@ -43,7 +43,7 @@ def _conv3x3(x, conv, cout, in_stats=None, want_stats=False, **kw):
     normalisation (helpers.py:128-131) is folded into the split-bf16 kernel's halo staging, or runs as its own pass
     (e4s_instnorm_apply_f32; the same two fp32 operations per element) in front of the fp32 kernel."""
     w = _pack3x3(conv)
-    if K.wino_eligible(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout) and set(kw) <= {"bias", "slope", "act", "alpha", "gain", "se"} \
+    if K.wino_eligible(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout, in_stats=in_stats is not None) and set(kw) <= {"bias", "slope", "act", "alpha", "gain", "se"} \
             and not (want_stats and kw.get("act", 0) != 0):
         # Winograd F(2,3) along the rows: 1.5x fewer MFMAs than the direct split-bf16 kernel (csrc/conv_wino.hip)
         if getattr(conv, "_e4s_wino", None) is None or conv._e4s_wino[0] != conv._e4s_pack[0]:

@@ -425,12 +425,15 @@ def split16_bf16x2(w):
 WINO = os.environ.get("E4S_WINO", "1") == "1"        # policy switch of the Winograd F(2,3) kernel (encoders._conv3x3)
 
 
-def wino_eligible(b, h, w, cin, cout):
+def wino_eligible(b, h, w, cin, cout, in_stats=False):
     """Shapes e4s_conv_wino_bf16x3_f32 covers, and whether the launch fills the chip (one 16x16-pixel x 128-column tile per block; launches
-    of <= 128 tiles split the input-channel chunks over blocks, csrc/conv_wino.hip:wino_split)."""
+    of <= 128 tiles split the input-channel chunks over blocks, csrc/conv_wino.hip:wino_split).  in_stats: the launch folds an
+    InstanceNorm into its input transform, whose {mean, rstd} tables live in LDS: Cin <= 1024 (the launcher refuses more)."""
     if not WINO or PRECISION == "f32":
         return False
     if h % 16 or w % 16 or cin % 16 or cin < 32 or cout % 128:
+        return False
+    if in_stats and cin > 1024:
         return False
     if PRECISION == "bf16x3":
         return True
@@ -1173,13 +1176,12 @@ def conv_smallcin(x, wp, bias, cout, k, stride, pad, relu=False):
     return y
 
 
-_SMALLCIN_Z = {}
-
-
-def conv_smallcin_bwd(dy, wp, in_shape, k, stride, pad):
+def conv_smallcin_bwd(dy, wp, in_shape, k, stride, pad, cache=None):
     """Image gradient of conv_smallcin.  Large kernels (AlexNet's 11x11 / 4 stem: k*k*Cin >= 128 columns): GEMM form -- ONE 1x1
     contraction z = dy . wp^T on the fp32 MFMA conv kernel + a col2im pass (e4s_conv_smallcin_col2im_f32); small kernels: the per-pixel
-    kernel (e4s_conv_smallcin_bwd_f32)."""
+    kernel (e4s_conv_smallcin_bwd_f32).  cache: a dict owned by whoever owns `wp` (the module's weight pack), where the zero-padded GEMM
+    image of wp is kept -- per pack, not per process: two loss networks alternating no longer evict each other, and a pack that dies takes
+    its image with it."""
     b, hi, wi, cin = in_shape
     _, ho, wo, cout = dy.shape
     dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
@@ -1187,12 +1189,13 @@ def conv_smallcin_bwd(dy, wp, in_shape, k, stride, pad):
     if ncol >= 128 and cout % 32 == 0 and dy.is_contiguous():
         zc = (ncol + 31) // 32 * 32
         key = (wp.data_ptr(), wp._version, zc)
-        hit = _SMALLCIN_Z.get(key)
-        if hit is None:
+        hit = cache.get("wz") if cache is not None else None
+        if hit is None or hit[0] != key:
             wz = torch.zeros(1, 1, zc, cout, device=wp.device, dtype=torch.float32)
             wz[0, 0, :ncol] = wp                                                  # wp is [k*k*Cin][Cout]: the GEMM's [N][K] matrix
-            _SMALLCIN_Z.clear()
-            _SMALLCIN_Z[key] = hit = (wp, wz)          # the entry HOLDS wp: a freed pack's address + version 0 must not hit it
+            hit = (key, wz)
+            if cache is not None:
+                cache["wz"] = hit
         wz = hit[1]
         z = conv_mfma(_f32(dy), wz, zc, ntaps=1, spatial=False)
         call("e4s_conv_smallcin_col2im_f32", fptr(z), fptr(dx), b, hi, wi, cin, ho, wo, zc, k, stride, pad, stream())

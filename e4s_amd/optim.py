@@ -60,6 +60,11 @@ class FusedAdam(torch.optim.Optimizer):
                     ok = False
                     break
         if not ok:
+            if d.get("captured"):
+                # a GraphedStep holds the OLD flat tensor (and the exp_avg / exp_avg_sq addresses) in its kernel arguments: re-packing
+                # here would leave its replays advancing and reading freed memory without any error
+                raise RuntimeError("FusedAdam: the optimiser state changed after a step was captured (load_state_dict, or a parameter "
+                                   "that first received a gradient); re-capture the GraphedStep")
             vals = []
             for p in plist:
                 st = self.state[p].get("step", 0)
@@ -70,6 +75,20 @@ class FusedAdam(torch.optim.Optimizer):
                 self.state[p]["step"] = flat[i:i + 1]
             d["flat"] = flat
         return flat
+
+    def captured_state_ptrs(self):
+        """Addresses a captured step has baked into its kernel arguments: per group the flat step tensor, per parameter exp_avg /
+        exp_avg_sq (GraphedStep compares them before every replay)."""
+        out = []
+        for gi, group in enumerate(self.param_groups):
+            d = self._dev.get(gi)
+            out.append(d["flat"].data_ptr() if d is not None and d.get("flat") is not None else 0)
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "exp_avg" in st:
+                    out.append(st["exp_avg"].data_ptr())
+                    out.append(st["exp_avg_sq"].data_ptr())
+        return tuple(out)
 
     def written_tensors(self):
         """Every tensor step() writes through raw pointers (GraphedStep advances their version counters after a replay)."""
@@ -170,9 +189,13 @@ class GraphedStep:
                 self.loss = body()
         self.flags = flags
         self._written = list(opt.written_tensors()) + list(also_written)
+        self._state_ptrs = opt.captured_state_ptrs()
 
     def step(self):
         self.opt.sync_hyper()                                   # a changed group["lr"] reaches the replay through device memory
+        if self.opt.captured_state_ptrs() != self._state_ptrs:
+            raise RuntimeError("GraphedStep: the optimiser's state tensors are not the ones this step was captured with "
+                               "(load_state_dict / new state after the capture); re-capture the GraphedStep")
         self.graph.replay()
         self.steps_done += 1
         torch.autograd.graph.increment_version(self._written)

@@ -516,12 +516,27 @@ class Generator(nn.Module):
         latent_in = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
         return self.get_latent(latent_in).mean(0, keepdim=True)
 
+    def _style_is_canonical(self):
+        """PixelNorm followed by EqualLinear(activation='fused_lrelu') layers only (model.py:489-497) -- checked once per module."""
+        ok = getattr(self, "_e4s_style_ok", None)
+        if ok is None:
+            mods = list(self.style)
+            ok = (len(mods) >= 2 and isinstance(mods[0], PixelNorm)
+                  and all(isinstance(m, EqualLinear) and m.activation == "fused_lrelu" and m.bias is not None for m in mods[1:]))
+            self._e4s_style_ok = ok
+        return ok
+
     def get_latent(self, input):
         """The mapping network z -> w (model.py:489-497, 570-574: PixelNorm + n_mlp x EqualLinear(lr_mul, fused_lrelu)) on the native
         kernels (e4s_pixelnorm_f32 + one e4s_grouped_linear_f32 per layer, leaky-ReLU gain folded into scale and bias) for ROCm inputs
         that need no gradient (Net3 freezes G.style, networks.py:68-70); otherwise the module chain as written (differentiable ATen)."""
         if input.is_cuda and input.ndim == 2 and not (torch.is_grad_enabled() and (
                 input.requires_grad or any(p.requires_grad for p in self.style.parameters()))):
+            # the native chain restates exactly this structure; anything else (a swapped-in layer) takes the module chain below.
+            # NOTE the result carries no autograd history here: callers that want gradients of G.style enable requires_grad BEFORE the
+            # call (then the ATen chain runs; both paths agree to 1e-6, tests/test_gpu_parity.py::test_mapping_network_native_vs_module_chain)
+            if not self._style_is_canonical():
+                return self.style(input)
             with torch.no_grad():
                 w = K.pixelnorm(input.to(torch.float32).contiguous())
                 for lin in list(self.style)[1:]:

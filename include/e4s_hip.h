@@ -254,7 +254,7 @@ int64_t e4s_conv_wgrad_ws_floats(const e4s_conv_wgrad_params* p);
 int e4s_pack_taps_bwd_f32(const float* w, float* wt, int ncls, int cout, int cin, void* stream);
 /* FusedLeakyReLU backward and dL/dd of a StyledConv in one pass over dy and y (both NHWC [B,H,W,C]): gz = dy * lrelu'(y) * gain (what
  * e4s_fused_bias_act_f32(act 3, grad 1) writes) and dd as e4s_demod_grad_f32 computes it from that gz -- without re-reading gz and y.
- * C in {32 ... 1024} with 256 % (C/4) == 0; ws: e4s_reduce_parts_ws_floats(e4s_act_bwd_demod_nsplit(B, H, W, C), B * R * C) floats */
+ * C a multiple of 4 in [4, 1024] with 256 % (C/4) == 0 (else hipErrorInvalidValue); labels >= R are counted in region R - 1; ws: e4s_reduce_parts_ws_floats(e4s_act_bwd_demod_nsplit(B, H, W, C), B * R * C) floats */
 int e4s_act_bwd_demod_nsplit(int B, int H, int W, int C);
 int e4s_act_bwd_demod_f32(const float* dy, const float* y, float* gz, const float* noise, const float* noise_w, int64_t noise_bstride,
                           const float* bias, float alpha, float gain, const uint8_t* labels, int Hm, int Wm, int R, float* dd, float* ws,

@@ -169,6 +169,14 @@ def test_graphed_step_reads_the_learning_rate_from_device_memory():
     og.param_groups[0]["betas"] = (0.5, 0.999)
     with pytest.raises(RuntimeError, match="re-capture"):
         gs.step()
+    # a state reload after the capture swaps the step / exp_avg tensors the graph's kernel arguments point to -- refused, not
+    # replayed on freed memory
+    og.param_groups[0]["betas"] = (0.9, 0.999)
+    gs.step()
+    import copy
+    og.load_state_dict(copy.deepcopy(og.state_dict()))
+    with pytest.raises(RuntimeError, match="re-capture"):
+        gs.step()
 
 
 def test_optimisation_step_gradients_are_bit_reproducible():

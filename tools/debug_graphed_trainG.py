@@ -1,0 +1,79 @@
+"""Bisect harness (round 5): TrainIteration.graphed_g_step vs the eager loop with a trainable generator, per kind of generator parameter.
+For each variant: 2 eager warm-up steps + 2 replays vs 4 eager steps at 256^2, l2 loss, batch 2; prints per variant the first tensors
+that differ after the warm-ups (must be none) and after each replay."""
+import copy
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("E4S_ALLOW_UNINITIALIZED_LOSS_NETS", "1")
+import torch  # noqa: E402
+
+from e4s_amd import kernels as K, synth  # noqa: E402
+from e4s_amd.networks import Net3  # noqa: E402
+from e4s_amd.optim import FusedAdam  # noqa: E402
+from e4s_amd.options import make_opts  # noqa: E402
+from e4s_amd.train import LossOpts, TrainIteration  # noqa: E402
+
+dev = torch.device("cuda", 0)
+size, b = 256, 2
+K.PRECISION = os.environ.get("DBG_PRECISION", "f32")
+tmpl = Net3(make_opts(out_size=size, train_G=True))
+tmpl.load_state_dict(synth.synth_state_dict(size, 13), strict=True)
+tmpl.latent_avg = synth.synth_latent_avg(size).to(dev)
+tmpl = tmpl.to(dev)
+img = synth.synth_image(b, size, seed=9, tag="w1_img").to(dev)
+mask = synth.onehot(synth.synth_labels_face(b, 512, seed=50)).to(dev)
+
+
+def build(only):
+    n3 = copy.deepcopy(tmpl).train()
+    if only is not None:
+        for name, p in n3.named_parameters():
+            if name.startswith("G.") and p.requires_grad and not any(s in name for s in only):
+                p.requires_grad = False
+    params = [p for p in n3.parameters() if p.requires_grad]
+    opt = FusedAdam(params, lr=1e-4, capturable=True)
+    lo = LossOpts(face_parsing_lambda=0.0, id_lambda=0.0, lpips_lambda=0.0)
+    return TrainIteration(n3, None, {}, opt, None, lo=lo), n3
+
+
+def diff(na, nb):
+    out = []
+    for (name, p), (_, q) in zip(na.named_parameters(), nb.named_parameters()):
+        if not torch.equal(p, q):
+            out.append((name, float((p - q).abs().max())))
+    return out
+
+
+variants = [("none (G frozen by filter)", ["@@"]), ("modulation", ["modulation"]), ("conv.weight of convs (wgrad)", ["convs.0.conv.weight", "convs.1.conv.weight", "conv1.conv.weight"]),
+            ("noise.weight", ["noise.weight"]), ("activate.bias", ["activate.bias"]), ("to_rgb", ["to_rgb"]), ("input", ["input.input"]),
+            ("all", None)]
+sel = os.environ.get("DBG_VARIANTS")
+for vname, only in variants:
+    if sel and vname.split()[0] not in sel.split(","):
+        continue
+    ite, ne = build(only)
+    losses_e = []
+    for _ in range(4):
+        l, _ = ite.g_step(img, mask, randomize_noise=False)
+        losses_e.append(float(l))
+    itg, ng = build(only)
+    gs = itg.graphed_g_step(img, mask, warmup=2, randomize_noise=False)
+    # state after the 2 warm-ups must equal the eager twin after 2 steps: rebuild an eager twin for that
+    it2, n2 = build(only)
+    for _ in range(2):
+        it2.g_step(img, mask, randomize_noise=False)
+    d_w = diff(n2, ng)
+    l3 = float(gs.step())
+    it2.g_step(img, mask, randomize_noise=False)
+    d_1 = diff(n2, ng)
+    l4 = float(gs.step())
+    d_2 = diff(ne, ng)
+    torch.cuda.synchronize()
+    print(json.dumps({"variant": vname, "trainable_G": sum(1 for n, p in ng.named_parameters() if n.startswith("G.") and p.requires_grad),
+                      "eager_losses": losses_e, "graphed_losses_3_4": [l3, l4], "diff_after_warmups": d_w[:4], "n_after_warmups": len(d_w),
+                      "diff_after_replay1": d_1[:6], "n_after_replay1": len(d_1), "diff_after_replay2": d_2[:6], "n_after_replay2": len(d_2)}), flush=True)
+    del gs, itg, ng, ite, ne, it2, n2
