@@ -142,6 +142,7 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
     weights: the real ones are downloads); "mse": the l2 term alone.  graphed: the whole step (forward, losses, backward, Adam with
     its step count on the device) replayed as one HIP graph (e4s_amd.optim.GraphedStep)."""
     import types
+    from e4s_amd.train import mse_loss
     driven, dm, target, tm, sm, _noise = one
     for p in net.parameters():
         p.requires_grad = False
@@ -166,7 +167,7 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
     def body():
         codes = net.cal_style_codes(latent)
         img, _, _ = net.gen_img(None, codes, tm, randomize_noise=True)
-        loss = torch.nn.functional.mse_loss(img, target)
+        loss = mse_loss(img, target)            # (F.mse_loss's semaphore memset must not sit in the captured step: e4s_amd.train.mse_loss)
         if lpips is not None:
             terms = os.environ.get("E4S_BENCH_TERMS", "lpips,id,parsing").split(",")      # debugging aid: subset of the terms
             if "lpips" in terms:

@@ -176,7 +176,7 @@ class GeneratorFn(torch.autograd.Function):
             if want(mod.weight):                                             # s = style @ Wm^T * scale + bias
                 give(mod.weight, (ds_total.t() @ style_rows(rec)) * mod.scale)
             if want(mod.bias):
-                give(mod.bias, ds_total.sum(0))
+                give(mod.bias, K.batch_sum(ds_total.contiguous()))
 
         for rec in reversed(tape):
             layer = rec["layer"]
@@ -188,7 +188,7 @@ class GeneratorFn(torch.autograd.Function):
                 if want(layer.conv.weight):                                     # ws = scale * w * s
                     give(layer.conv.weight, (layer.conv.scale * (dws * rec["s"].unsqueeze(1)).sum(0)).view(1, 3, -1, 1, 1))
                 if want(layer.bias):
-                    give(layer.bias, dskip.sum((0, 2, 3)).view(1, 3, 1, 1))
+                    give(layer.bias, K.channel_sum(dskip).view(1, 3, 1, 1))
                 add_style_grad(rec, ds)
                 if rec["has_skip"]:                     # Upsample backward = FIR-downsample of the incoming grad
                     k4 = layer.upsample.kernel
@@ -209,10 +209,12 @@ class GeneratorFn(torch.autograd.Function):
             if extras is not None:
                 gz = extras["gz"]
                 if want(layer.activate.bias):
-                    give(layer.activate.bias, gz.sum((0, 1, 2)))
+                    # native ordered sums, not ATen's global reduce (whose semaphore memset must not end up in a captured train step:
+                    # kernels.sum_all)
+                    give(layer.activate.bias, K.colsum(gz))
                 if want(layer.noise.weight):
                     nz = rec["noise"]                                           # [Bn,1,H,W]
-                    give(layer.noise.weight, (gz.sum(-1) * nz[:, 0]).sum().view(1))
+                    give(layer.noise.weight, K.sum_all(gz.sum(-1) * nz[:, 0]).view(1))
                 if train_w:
                     give(conv.weight, styled_conv_weight_grad(rec, extras, r))
             add_style_grad(rec, ds)

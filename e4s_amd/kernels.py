@@ -794,6 +794,19 @@ def colsum(x):
     return out
 
 
+def sum_all(x):
+    """0-dim sum of every element on the native ordered two-level column sum (bit-reproducible).  Also the reason it exists: ATen's large
+    reductions allocate a semaphore buffer and clear it with hipMemsetAsync -- captured into a HIP graph that is a MEMSET NODE, and memset
+    nodes misbehave on replay on this ROCm (round 3: the region plan's memsets faulted, profiles/r03a_plan_fault_ab.json; round 5: a
+    captured train step with `gz.sum((0, 1, 2))` in it came back with its loss scalar zeroed, profiles/r05_graphed_trainG_bisect.json).
+    Nothing this library captures issues a memset."""
+    x = _f32(x)
+    n = x.numel()
+    if n % 4 == 0 and n // 4 > 64:
+        return colsum(x.view(-1, 4)).sum()                 # the last 4 values: a single-block ATen reduce (no semaphores)
+    return x.sum()
+
+
 def adam_step(p, grad, m, v, lr, beta1, beta2, eps, weight_decay, step):
     """torch.optim.Adam's update of one fp32 tensor, in place, as ONE kernel."""
     call("e4s_adam_step_f32", fptr(p), fptr(_f32(grad)), fptr(m), fptr(v), p.numel(), float(lr), float(beta1), float(beta2),

@@ -42,6 +42,31 @@ def accumulate(model1, model2, decay=0.999):
         K.ema_multi_(dst, src, decay)
 
 
+class _MseFn(torch.autograd.Function):
+    """F.mse_loss (mean reduction) with the sum on the native ordered column sum: bit-reproducible, and free of the hipMemsetAsync that
+    ATen's global reduce issues for its semaphores (a memset NODE in a captured step; kernels.sum_all says why that matters here)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        d = a.detach() - b.detach()
+        ctx.save_for_backward(d)
+        ctx.need = (a.requires_grad, b.requires_grad)
+        return K.sum_all(d * d) / d.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        d, = ctx.saved_tensors
+        ga = d * (g * (2.0 / d.numel()))
+        return (ga if ctx.need[0] else None), (-ga if ctx.need[1] else None)
+
+
+def mse_loss(input, target):
+    """nn.MSELoss() of coach.py:147 / F.mse_loss of scripts/optimization.py:95 on device tensors of one shape."""
+    if input.shape != target.shape or not input.is_cuda:
+        return F.mse_loss(input, target)
+    return _MseFn.apply(input, target)
+
+
 def adv_g_loss(fake_pred):
     """AdvGLoss, adv_loss.py:8-16."""
     return F.softplus(-fake_pred).mean()
@@ -105,7 +130,7 @@ class TrainIteration:
             terms["id"] = self.crit["id"](recon, img)[0]
             loss = loss + terms["id"] * lo.id_lambda
         if lo.l2_lambda > 0:
-            terms["l2"] = F.mse_loss(recon, img)
+            terms["l2"] = mse_loss(recon, img)
             loss = loss + terms["l2"] * lo.l2_lambda
         if lo.lpips_lambda > 0 and "lpips" in self.crit:
             # the three adaptive_avg_pool2d scales of coach.py:425-434, pooled inside the networks' first pass

@@ -272,13 +272,15 @@ def _graphed_equals_eager(size, lpips_sizes, steps):
     noise = [n.to(DEV) for n in synth.synth_noise(size)]
     sv = (torch.randn(1, 12, 1280, generator=g) * 0.1).to(DEV)
 
+    from e4s_amd.train import mse_loss          # the l2 term as bench.py's captured config-3 step computes it (no ATen global reduce)
+
     def run(graphed):
         latent = sv.clone().requires_grad_(True)
         opt = FusedAdam([latent], lr=1e-2, capturable=True)
 
         def body():
             img, _, _ = net.gen_img(None, net.cal_style_codes(latent), mask, noise=noise)
-            loss = torch.nn.functional.mse_loss(img, target) + 0.8 * lp.forward_pooled(img, target, lpips_sizes) \
+            loss = mse_loss(img, target) + 0.8 * lp.forward_pooled(img, target, lpips_sizes) \
                 + 0.1 * idl(img, target)[0] + 0.1 * fpl(img, target)[0]
             loss.backward()
             opt.step()
@@ -354,3 +356,25 @@ def test_plan_path_replays_in_a_graph_with_other_masks_than_the_captured_one(mon
             torch.cuda.synchronize()
             assert torch.equal(out, e), f"plan-path graph replay {rep} differs from the eager launch"
     assert int(flags.item()) == 0
+
+
+def test_native_mse_and_sum_all_vs_torch():
+    """e4s_amd.train.mse_loss / kernels.sum_all (ordered native sums instead of ATen's global reduce, whose semaphore memset must stay out
+    of captured steps): value and both gradients vs torch in fp64, bit-reproducible, odd sizes fall back to ATen."""
+    from e4s_amd import kernels as K
+    from e4s_amd.train import mse_loss
+    g = torch.Generator().manual_seed(2)
+    for shape in ((2, 3, 256, 256), (1, 3, 64, 64), (3, 5, 7)):
+        a = torch.randn(shape, generator=g).to(DEV).requires_grad_(True)
+        b = torch.randn(shape, generator=g).to(DEV).requires_grad_(True)
+        l = mse_loss(a, b)
+        (l * 3.0).backward()
+        a64, b64 = a.detach().double().cpu().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+        l64 = torch.nn.functional.mse_loss(a64, b64)
+        (l64 * 3.0).backward()
+        assert abs(float(l) - float(l64)) < 2e-6 * float(l64)
+        assert float((a.grad.cpu().double() - a64.grad).abs().max()) < 1e-6 * float(a64.grad.abs().max())
+        assert float((b.grad.cpu().double() - b64.grad).abs().max()) < 1e-6 * float(b64.grad.abs().max())
+        assert torch.equal(mse_loss(a.detach(), b.detach()), l.detach())
+        x = a.detach()
+        assert abs(float(K.sum_all(x)) - float(x.double().sum())) < 1e-3
