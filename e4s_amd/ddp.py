@@ -80,6 +80,8 @@ class GradAverager:
         self._next = 0                                   # buckets [0, _next) have been launched (index order on every rank)
         self.fired_during_backward = 0                   # diagnostics: buckets launched before finish()
         self._streams = [dict() for _ in self.buckets]   # per bucket: {stream id: stream} its staging copies were enqueued on
+        self._fire_stream = None                         # the stream arm() ran on: every bucket of this backward is issued from it
+        self.fire_log = []                               # diagnostics: (bucket, filled from another stream?, that stream capturing?)
         self.staging_streams_seen = [0] * len(self.buckets)   # diagnostics: most streams any one backward staged a bucket from
         if self.active:
             if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
@@ -105,15 +107,27 @@ class GradAverager:
     def _fire(self, i):
         flat = self._buffer(i)
         if flat.is_cuda:
-            # the collective is ordered behind the CURRENT stream only: join every other stream that staged into this bucket
+            # Every bucket is issued from ONE stream -- the stream arm() was called on (the caller's; the capturing stream inside a
+            # capture) -- whichever stream the hook that filled it happens to run on:
+            #  * the collective is ordered behind the stream it is issued from only, so that stream first joins every stream that staged
+            #    into the bucket (an event recorded behind the last staging copy on each);
+            #  * torch decides per collective, from the CURRENT stream's capture status, whether the Work goes to the process group's
+            #    watchdog thread; a Work whose end event was recorded inside a capture must never get there (the watchdog's hipEventQuery
+            #    then fails with hipErrorCapturedEvent and takes the process down -- the failure round 4 saw once in ~8 runs and retried).
+            #    Issued from the capturing stream, the status is always "active".
             cur = torch.cuda.current_stream(flat.device)
-            self.staging_streams_seen[i] = max(self.staging_streams_seen[i], len(self._streams[i] | {cur.cuda_stream: cur}))
+            fs = self._fire_stream if self._fire_stream is not None else cur
+            self.fire_log.append((i, cur.cuda_stream != fs.cuda_stream, bool(torch.cuda.is_current_stream_capturing())))
+            self.staging_streams_seen[i] = max(self.staging_streams_seen[i], len(self._streams[i] | {fs.cuda_stream: fs}))
             for sid, st in self._streams[i].items():
-                if sid != cur.cuda_stream:
+                if sid != fs.cuda_stream:
                     ev = torch.cuda.Event()
                     ev.record(st)
-                    cur.wait_event(ev)
+                    fs.wait_event(ev)
             self._streams[i] = {}
+            with torch.cuda.stream(fs):
+                self._works[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return
         self._works[i] = dist.all_reduce(self._buffer(i), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _hook(self, p):
@@ -150,6 +164,9 @@ class GradAverager:
         self._next = 0
         self.fired_during_backward = 0
         self._streams = [dict() for _ in self.buckets]
+        dev = self.params[0].device if self.params else None
+        self._fire_stream = torch.cuda.current_stream(dev) if (dev is not None and dev.type == "cuda") else None
+        self.fire_log = []
         _ACTIVE = self
 
     def finish(self):
@@ -196,4 +213,5 @@ class GradAverager:
         self._sent, self._ready, self._works = set(), [0] * len(self.buckets), [None] * len(self.buckets)
         self._next = 0
         self._streams = [dict() for _ in self.buckets]
+        self._fire_stream = None
         self.finish()

@@ -262,6 +262,8 @@ class GraphedFaceSwap:
             # with a process group up (N > 1) other threads of this process (the RCCL watchdog) may touch the HIP
             # runtime while the capture runs: only this thread's calls are policed then
             mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+            from .shard import quiesce_before_capture
+            quiesce_before_capture()
             with K.flag_sink(self.flags):
                 with torch.cuda.graph(self.graph, capture_error_mode=mode):
                     self.out = face_swap_core(self.net, *self.static, noise=self.noise)

@@ -184,6 +184,8 @@ class GraphedStep:
         if capture_error_mode is None:       # a live process group's watchdog thread polls events: "global" would fail the capture
             import torch.distributed as dist
             capture_error_mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        from .shard import quiesce_before_capture
+        quiesce_before_capture()                                # (a live "nccl" group: its watchdog's list is empty before the capture)
         with K.flag_sink(flags):                                # this thread's mask checks accumulate here instead of syncing
             with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
                 self.loss = body()

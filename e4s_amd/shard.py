@@ -32,6 +32,24 @@ def collectives_active(group=None):
     return dist.get_world_size(group) > 1 or _FORCE
 
 
+def quiesce_before_capture(device=None):
+    """Call right before a stream capture while a process group on backend "nccl" is alive.  The group's watchdog thread polls the end
+    events of the EAGER collectives still in its list (every ~100 ms) and drops the completed ones; the capture that follows puts RCCL's
+    stream into capture mode, and an event query that reaches the runtime at that moment is one more thing that can go wrong in a region
+    where nothing may (a hipErrorCapturedEvent in the watchdog terminates the process).  Completing everything and giving the watchdog two
+    of its periods leaves its list empty before the capture starts.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    try:
+        if dist.get_backend() != "nccl":
+            return
+    except Exception:       # noqa: BLE001
+        return
+    import time
+    torch.cuda.synchronize(device)
+    time.sleep(0.25)
+
+
 def shard_range(n, world, rank):
     """Contiguous balanced split of n items: the first n % world ranks get one extra."""
     base, extra = divmod(n, world)

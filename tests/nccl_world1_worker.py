@@ -88,7 +88,12 @@ def fresh_net(train_g, mode):
 
 masks = [synth.onehot(synth.synth_labels_face(b, 512, seed=50 + i)).to(dev) for i in range(3)]
 
+def mark(what):
+    print(f"W1 iter {it} {what}", flush=True)          # a crash (watchdog abort) is then located by the last line printed
+
+
 for it in range(args.repeat):
+    mark("gather")
     # ---- shard.gather_outputs / OverlappedGather on RCCL -----------------------------------------------------------------------
     if "gather" in sections:
         g = torch.Generator().manual_seed(1 + it)
@@ -104,6 +109,7 @@ for it in range(args.repeat):
 
     # ---- GraphedFaceSwap captured while a process group (and its watchdog thread) is alive, gather submitted per step -------------
     if "swap" in sections:
+        mark("swap")
         net = fresh_net(0, "eval")
         drv = synth.synth_image(b, size, seed=3, tag="w1_d").to(dev)
         tgt = synth.synth_image(b, size, seed=3, tag="w1_t").to(dev)
@@ -150,6 +156,7 @@ for it in range(args.repeat):
     res["trainable_tensors"] = len([p for p in net0.parameters() if p.requires_grad])
 
     if "ddp_eager" in sections:
+        mark("ddp_eager")
         it1, net1, avg1, ema1 = build(True)
         flag("averager_active", bool(avg1.active) and len(avg1.buckets) > 2)
         loss1, _ = it1.g_step(img_t, mask_t, randomize_noise=False)
@@ -165,8 +172,14 @@ for it in range(args.repeat):
         del it1, net1, avg1, ema1
 
     if "ddp_graphed" in sections:
+        mark("ddp_graphed")
         it2, net2, avg2, ema2 = build(True)
         gs = it2.graphed_g_step(img_t, mask_t, warmup=2, randomize_noise=False)  # steps 1-2 eager, 3-4 replayed: all-reduces inside the graph
+        mark("ddp_graphed captured")
+        # (fire_log of the CAPTURE cycle: was any bucket filled from a stream other than the one it is issued from, and was that stream
+        # part of the capture?)
+        res["capture_fills_from_other_stream"] = sum(1 for _, other, _ in avg2.fire_log if other)
+        res["capture_fills_from_non_capturing_stream"] = sum(1 for _, _, cap in avg2.fire_log if not cap)
         gs.step()
         loss2 = gs.step()
         gs.validate()
@@ -186,6 +199,7 @@ for it in range(args.repeat):
         del gs, it2, net2, avg2, ema2
 
     if "torch_ddp" in sections:
+        mark("torch_ddp")
         # coach.py:74-85: nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], output_device=local_rank,
         # broadcast_buffers=False, find_unused_parameters=True) -- torch's reducer over the monolithic EncoderFn / GeneratorFn nodes
         from torch.nn.parallel import DistributedDataParallel as DDP
@@ -200,6 +214,7 @@ for it in range(args.repeat):
         del it3, net3, ema3
     del it0, net0, ema0
 
+mark("done")
 res["diffs"] = res["diffs"][:40]
 dist.barrier()
 dist.destroy_process_group()

@@ -31,8 +31,9 @@ mask = synth.onehot(synth.synth_labels_face(b, 512, seed=50)).to(dev)
 def build(only):
     n3 = copy.deepcopy(tmpl).train()
     if only is not None:
+        keep = only if callable(only) else (lambda name: any(s in name for s in only))
         for name, p in n3.named_parameters():
-            if name.startswith("G.") and p.requires_grad and not any(s in name for s in only):
+            if name.startswith("G.") and p.requires_grad and not keep(name):
                 p.requires_grad = False
     params = [p for p in n3.parameters() if p.requires_grad]
     opt = FusedAdam(params, lr=1e-4, capturable=True)
@@ -48,8 +49,21 @@ def diff(na, nb):
     return out
 
 
-variants = [("none (G frozen by filter)", ["@@"]), ("modulation", ["modulation"]), ("conv.weight of convs (wgrad)", ["convs.0.conv.weight", "convs.1.conv.weight", "conv1.conv.weight"]),
+def is_convw(name, lo=0, hi=99):
+    if name == "G.conv1.conv.weight":
+        return lo <= -1
+    if name.startswith("G.convs.") and name.endswith(".conv.weight"):
+        return lo <= int(name.split(".")[2]) <= hi
+    return False
+
+
+variants = [("none (G frozen by filter)", ["@@"]), ("modulation", ["modulation"]),
+            ("convw_low conv.weight of conv1, convs.0, convs.1", lambda n: is_convw(n, -1, 1)),
+            ("convw_all conv.weight of every styled conv", lambda n: is_convw(n, -1)),
+            ("convw_2_7", lambda n: is_convw(n, 2, 7)), ("convw_up even convs (up-convs)", lambda n: is_convw(n, 0) and int(n.split(".")[2]) % 2 == 0),
+            ("convw_plain odd convs", lambda n: is_convw(n, 0) and int(n.split(".")[2]) % 2 == 1),
             ("noise.weight", ["noise.weight"]), ("activate.bias", ["activate.bias"]), ("to_rgb", ["to_rgb"]), ("input", ["input.input"]),
+            ("allbut_convw", lambda n: not is_convw(n, -1)), ("allbut_rgb", lambda n: "to_rgb" not in n),
             ("all", None)]
 sel = os.environ.get("DBG_VARIANTS")
 for vname, only in variants:

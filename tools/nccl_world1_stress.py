@@ -65,7 +65,10 @@ def main():
         out = [ln for ln in p.stdout.splitlines() if ln.startswith("NCCL_WORLD1 ")]
         if p.returncode != 0 or not out:
             summary["crashes"] += 1
-            rec = {"proc": i, "returncode": p.returncode, "stderr_tail": p.stderr[-3000:], "stdout_tail": p.stdout[-500:]}
+            marks = [ln for ln in p.stdout.splitlines() if ln.startswith("W1 ")]
+            what = [ln for ln in p.stderr.splitlines() if "what():" in ln or "HIP error" in ln]
+            rec = {"proc": i, "returncode": p.returncode, "last_mark": marks[-1] if marks else None, "error_lines": what[:4],
+                   "stderr_tail": p.stderr[-1500:]}
         else:
             res = json.loads(out[-1][len("NCCL_WORLD1 "):])
             summary["iterations"] += res["repeat"]
