@@ -7,8 +7,9 @@ for config 5 (`train_G=True`), the gradients of every generator / LocalMLP param
 e4s_demod_grad_f32, e4s_torgb_bwd_*_f32, e4s_upfirdn2d_f32, e4s_fused_bias_act_f32), including the transposed
 contractions of the style prologue's chain rule and of the LocalMLP backward (e4s_grouped_linear_t_f32,
 e4s_grouped_outer_f32); every split reduction adds its partial sums in a fixed order, so gradients are bit-reproducible.
-Conv weight gradients (config 5) run on the fp32-MFMA weight-gradient kernel (e4s_conv_wgrad_f32); only the tiny
-modulation-weight / polyphase-fold outer products are plain matmuls on [G,C]-sized operands.
+Conv weight gradients (config 5) run on the fp32-MFMA weight-gradient kernel (e4s_conv_wgrad_f32); the modulation-weight and
+demodulation outer products on e4s_grouped_outer_f32, the fold of the polyphase gradients on e4s_polyphase_fold_f32, the bias / noise-strength
+sums on the ordered native column sums -- no library GEMM and no ATen global reduction (whose semaphore memset must not enter a captured step).
 """
 import math
 
@@ -73,24 +74,6 @@ def styled_conv_backward(rec, dy, num_regions, extras=None):
     return dx, ds
 
 
-def _polyphase_map(blur_kernel):
-    """C[ph, e, k] with Weff[ph][e] = sum_k C[ph,e,k] W[k]  (same linear map as e4s_polyphase_weights_f32 /
-    stylegan2.polyphase_upconv_weights): C = kflip[ky - ty + 1, kx - tx + 1], ty = py - 2(ey - 1)."""
-    kf = torch.flip(blur_kernel.detach().float().cpu(), [0, 1])
-    cmap = torch.zeros(4, 9, 9)
-    for py in range(2):
-        for px in range(2):
-            for ey in range(3):
-                for ex in range(3):
-                    ty, tx = py - 2 * (ey - 1), px - 2 * (ex - 1)
-                    for ky in range(3):
-                        for kx in range(3):
-                            jy, jx = ky - ty + 1, kx - tx + 1
-                            if 0 <= jy < 4 and 0 <= jx < 4:
-                                cmap[py * 2 + px, ey * 3 + ex, ky * 3 + kx] = kf[jy, jx]
-    return cmap
-
-
 def styled_conv_weight_grad(rec, extras, num_regions):
     """dL/d(conv.weight) [1,Cout,Cin,3,3] of one fused StyledConv (config 5, train_G=True).
     out_pre = d * sum W s x:  dW = (gz*d)^T (s*x shifted)  [the contraction over all pixels: e4s_conv_wgrad_f32, region
@@ -109,20 +92,11 @@ def styled_conv_weight_grad(rec, extras, num_regions):
         # gradient w.r.t. the 4 x 9 polyphase kernels (one e4s_conv_wgrad_f32 call per output phase), folded back onto
         # the 3 x 3 weight with the transpose of the polyphase map
         deff = torch.stack([K.conv_wgrad(gz, x, ostride=2, phase=(ph >> 1, ph & 1), anchors=(h, w), **kw)
-                            for ph in range(4)]).view(36, cout * cin)
-        # the 36 x 9 map depends on the (constant) blur kernel only: built once per module on the host, kept on the device -- the
-        # backward then has no host round trip and a captured train step (train.graphed_g_step with train_G) can hold it
-        from .packs import param_key
-        ck = param_key(conv.blur.kernel) + (str(deff.device),)
-        cached = getattr(conv, "_e4s_polymap", None)
-        if cached is None or cached[0] != ck:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("styled_conv_weight_grad: the polyphase map must be built before a stream capture (run one eager "
-                                   "step first)")
-            conv._e4s_polymap = cached = (ck, _polyphase_map(conv.blur.kernel).to(deff.device).view(36, 9))
-        cmap = cached[1]
-        dw = (cmap.t() @ deff).view(9, cout, cin).permute(1, 2, 0).reshape(cout, cin, 3, 3)
-    dw = dw - wraw * (dd3.t() @ (s * s)).view(cout, cin, 1, 1)
+                            for ph in range(4)])                              # [4, 9, Cout, Cin]
+        dw = K.polyphase_fold(deff, conv.blur.kernel, cout, cin)              # native transpose of the polyphase map (no library GEMM)
+    # through the demodulation: - W * ((dd d^3)^T s^2); the [Cout, G] x [G, Cin] contraction on e4s_grouped_outer_f32 (one group, the
+    # G rows as its batch): like every reduction of a captured step, native and ordered (kernels.sum_all)
+    dw = dw - wraw * K.grouped_outer(dd3.unsqueeze(1).contiguous(), (s * s).unsqueeze(1).contiguous(), 1.0)[0].view(cout, cin, 1, 1)
     return dw.unsqueeze(0)
 
 
@@ -174,7 +148,8 @@ class GeneratorFn(torch.autograd.Function):
             else:
                 dlat[:, 0, rec["idx"]] += dstyle
             if want(mod.weight):                                             # s = style @ Wm^T * scale + bias
-                give(mod.weight, (ds_total.t() @ style_rows(rec)) * mod.scale)
+                give(mod.weight, K.grouped_outer(ds_total.unsqueeze(1).contiguous(), style_rows(rec).unsqueeze(1).contiguous(),
+                                                 mod.scale)[0])
             if want(mod.bias):
                 give(mod.bias, K.batch_sum(ds_total.contiguous()))
 

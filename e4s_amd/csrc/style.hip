@@ -153,6 +153,47 @@ __global__ void polyphase_weights_kernel(const float* __restrict__ w, const floa
     }
 }
 
+// The TRANSPOSE of polyphase_weights_kernel (config 5, train_G: the weight gradient of an up-sampling StyledConv arrives as the gradient of
+// its 4 x 9 polyphase kernels, one e4s_conv_wgrad_f32 call per output phase): deff [4*9][Cout][Cin] -> dw [Cout][Cin][9] with
+//   dw[k] = sum_{ph, e} C[ph, e, k] * deff[ph * 9 + e],   C[ph, e, k] = kflip[jy][jx] where W[ky][kx] enters E[ty][tx] (same index algebra).
+// One thread per (co, ci), every term added in a fixed order.  (Was a [9 x 36] x [36 x Cout*Cin] library GEMM.)
+__global__ void polyphase_fold_kernel(const float* __restrict__ deff, const float* __restrict__ k4, float* __restrict__ dw, int cout,
+                                      int cin) {
+    const int64_t n = (int64_t)cout * cin;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float kf[16], acc[9];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) kf[t] = k4[15 - t];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+#pragma unroll
+        for (int ey = 0; ey < 3; ++ey) {
+#pragma unroll
+            for (int ex = 0; ex < 3; ++ex) {
+                const int ty = py - 2 * (ey - 1), tx = px - 2 * (ex - 1);
+                const float g = deff[((int64_t)(ph * 9 + ey * 3 + ex)) * n + i];
+#pragma unroll
+                for (int jy = 0; jy < 4; ++jy) {
+                    const int ky = ty + jy - 1;
+                    if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        const int kx = tx + jx - 1;
+                        if (kx < 0 || kx > 2) continue;
+                        acc[ky * 3 + kx] += kf[jy * 4 + jx] * g;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw[i * 9 + t] = acc[t];
+}
+
 // [Cout,Cin,kh*kw] -> [kh*kw][Cout][Cin]
 __global__ void pack_taps_kernel(const float* __restrict__ w, float* __restrict__ out, int64_t n, int taps) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,6 +206,14 @@ __global__ void pack_taps_kernel(const float* __restrict__ w, float* __restrict_
 extern "C" int e4s_polyphase_weights_f32(const float* w, const float* k4, float* out, int cout, int cin, void* stream) {
     const int64_t n = (int64_t)cout * cin;
     hipLaunchKernelGGL(polyphase_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, k4, out, cout, cin);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e4s_polyphase_fold_f32(const float* deff, const float* k4, float* dw, int cout, int cin, void* stream) {
+    if (!deff || !k4 || !dw || cout <= 0 || cin <= 0) return (int)hipErrorInvalidValue;
+    const int64_t n = (int64_t)cout * cin;
+    hipLaunchKernelGGL(polyphase_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), deff, k4, dw, cout, cin);
     E4S_CHECK_LAUNCH();
     return 0;
 }

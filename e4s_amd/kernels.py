@@ -194,6 +194,17 @@ def polyphase_weights(w, blur_kernel):
     return out
 
 
+def polyphase_fold(deff, blur_kernel, cout, cin):
+    """Gradient of the 4 x 9 polyphase kernels [36, Cout, Cin] (contiguous) -> gradient of the 3x3 weight [Cout, Cin, 3, 3]: the transpose of
+    polyphase_weights."""
+    deff = _f32(deff)
+    if deff.numel() != 36 * cout * cin:
+        raise RuntimeError("polyphase_fold: deff must hold 4 * 9 * Cout * Cin values")
+    dw = torch.empty(cout, cin, 3, 3, device=deff.device, dtype=torch.float32)
+    call("e4s_polyphase_fold_f32", fptr(deff), fptr(_f32(blur_kernel)), fptr(dw), cout, cin, stream())
+    return dw
+
+
 def rgb_weights(w, s, scale):
     """ws[g,c,ci] = scale*w[c,ci]*s[g,ci]; w [3,Cin]."""
     g, cin = s.shape

@@ -66,6 +66,7 @@ SIGNATURES = {
     "e4s_weight_sqsum_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_pack_taps_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
     "e4s_polyphase_weights_f32": [c_p, c_p, c_p, c_i, c_i, c_p],
+    "e4s_polyphase_fold_f32": [c_p, c_p, c_p, c_i, c_i, c_p],
     "e4s_rgb_weights_f32": [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "e4s_mask_labels": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_region_plan": [c_p] + [c_i] * 8 + [c_p, c_p, c_p, c_p, c_i, c_i, c_p],

@@ -83,6 +83,9 @@ int e4s_weight_sqsum_f32(const float* w, float* wsq, int cout, int cin, int taps
  *     (conv_transpose2d stride 2 + Blur pad (1,1), model.py:287-300) -> out [4 phases][9][Cout][Cin] */
 int e4s_pack_taps_f32(const float* w, float* out, int cout, int cin, int taps, void* stream);
 int e4s_polyphase_weights_f32(const float* w, const float* k4, float* out, int cout, int cin, void* stream);
+/* the transpose of e4s_polyphase_weights_f32 (weight gradient of an up-sampling StyledConv, model.py:287-300 under autograd):
+ * deff [4 phases * 9][Cout][Cin] (gradient of the polyphase kernels) -> dw [Cout][Cin][9] (gradient of the 3x3 weight) */
+int e4s_polyphase_fold_f32(const float* deff, const float* k4, float* dw, int cout, int cin, void* stream);
 
 /* ws[g, c, ci] = scale * w[c, ci] * s[g, ci]   (ToRGB: demodulate=False, model.py:417) */
 int e4s_rgb_weights_f32(const float* w, const float* s, float* ws, int G, int cin, float scale, void* stream);

@@ -1464,3 +1464,24 @@ def test_fused_activation_backward_and_demod_gradient(b, h, w, c, masked):
     assert torch.equal(gz0, gz1)
     assert maxabs(dd0, dd1) < 2e-5 * float(dd0.abs().max()), maxabs(dd0, dd1)
     assert torch.equal(dd1, K.act_bwd_demod(dy, y, noise, nw, bias, 0.2, 2 ** 0.5, labels, 12)[1])
+
+
+def test_polyphase_fold_is_the_transpose_of_polyphase_weights():
+    """e4s_polyphase_fold_f32 (weight gradient of an up-sampling StyledConv: the gradients of the 4 x 9 polyphase kernels folded back onto
+    the 3x3 weight) vs the fp64 transpose of stylegan2.polyphase_upconv_weights (the CPU-tested statement of the polyphase map), and the
+    adjoint identity <P(w), g> == <w, P^T(g)> against the forward kernel."""
+    from e4s_amd import kernels as K
+    from e4s_amd.stylegan2 import make_kernel, polyphase_upconv_weights
+    g = torch.Generator().manual_seed(21)
+    cout, cin = 12, 20
+    k4 = make_kernel([1, 3, 3, 1]) * 4
+    w = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    deff = torch.randn(4, 9, cout, cin, generator=g, dtype=torch.float64)
+    (polyphase_upconv_weights(w, k4.double()) * deff).sum().backward()
+    got = K.polyphase_fold(deff.float().to(DEV), k4.to(DEV), cout, cin)
+    assert got.shape == (cout, cin, 3, 3)
+    assert maxabs(got, w.grad) < 1e-5 * float(w.grad.abs().max())
+    pw = K.polyphase_weights(w.detach().float().to(DEV), k4.to(DEV))
+    lhs = float((pw.double().cpu() * deff).sum())
+    rhs = float((w.detach() * got.double().cpu()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
