@@ -40,8 +40,9 @@ def styled_conv_backward(rec, dy, num_regions, extras=None):
         # exact-fp32 dx + ds kernel ran the 64->64@512^2 / 32->32@1024^2 dgrads of the optimisation step at 0.69 / 0.71 ms, the forward
         # kernels take ~0.1); ds = sum_p x * (the same contraction) leaves the pass that applies s
         if "wt_fwd" not in pk:
-            wp = K.pack_taps(conv.weight.detach()[0].float().flip(2, 3).transpose(0, 1).contiguous())      # [1,9,Cin,Cout]
-            pk["wt_fwd"] = (wp, K.split_bf16x2(wp))
+            wp = K.pack_taps(conv.weight.detach()[0].float().flip(2, 3).transpose(0, 1).contiguous(),
+                             out=conv._buf("wt_fwd", (1, 9, cin, cout), x.device))                          # [1,9,Cin,Cout]
+            pk["wt_fwd"] = (wp, K.split_bf16x2(wp, out=conv._buf("wt_fwd_split", (1, 9, cin, cout), x.device)))
         wp, wps = pk["wt_fwd"]
         if cout == 32 and cin % 32 == 0:
             u = K.conv_c32(gz.contiguous(), wps, cin, in_scale=d)
@@ -56,14 +57,14 @@ def styled_conv_backward(rec, dy, num_regions, extras=None):
         # dgrads at ~0.5 / 1.0 ms per image: 36 multiply-adds per input pixel and channel pair on v_mfma_f32_32x32x2_f32.)
         if "wt_up_fwd" not in pk:
             wp = pk["w"].flip(1).permute(1, 3, 0, 2).reshape(1, 9, cin, 4 * cout).contiguous()     # [1,9,Cin,(phase,Cout)]
-            pk["wt_up_fwd"] = (wp, K.split_bf16x2(wp))
+            keep = conv._buf("wt_up_fwd", tuple(wp.shape), wp.device)
+            keep.copy_(wp)
+            pk["wt_up_fwd"] = (keep, K.split_bf16x2(keep, out=conv._buf("wt_up_fwd_split", tuple(wp.shape), wp.device)))
         wp, wps = pk["wt_up_fwd"]
         u = K.conv_mfma(K.pixel_unshuffle2(gz), wp, cin, w_split=wps, in_scale=d.repeat(1, 4).contiguous())
         dx, ds = K.scale_dot(u, x, s)
     else:
-        if "wt" not in pk:
-            pk["wt"] = K.pack_taps_bwd(pk["w"])
-        dx, ds = K.conv_bwd(gz, pk["wt"], x, s, d, labels, num_regions, 4 if conv.upsample else 1)
+        dx, ds = K.conv_bwd(gz, conv.bwd_taps(), x, s, d, labels, num_regions, 4 if conv.upsample else 1)
     # d = scale * rsqrt(scale^2 sum_ci s^2 Wsq + eps)  =>  dd/ds_ci = -d^3 s_ci Wsq[co,ci];  dL/dd = dd_d / d, so dL/dd * d^3 = dd_d * d^2
     dd3 = dd_d * (d * d)
     # ds - s * (dd3 @ Wsq): the [G,Cout] x [Cout,Cin] contraction on e4s_grouped_linear_t_f32 with the combine fused

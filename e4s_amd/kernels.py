@@ -175,21 +175,32 @@ def weight_sqsum(w, out=None):
     return out
 
 
-def pack_taps(w):
+def _into(out, shape, device):
+    """`out` if given (checked: contiguous fp32 of exactly `shape` on `device`), else a fresh tensor.  The weight-pack builders take `out`
+    so that a module can keep ONE buffer per pack for its lifetime: a re-pack after a weight update -- eager, or replayed inside a captured
+    train step -- then writes in place and allocates nothing (stylegan2.ModulatedConv2d._buf)."""
+    if out is None:
+        return torch.empty(shape, device=device, dtype=torch.float32)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or out.device != device or not out.is_contiguous():
+        raise RuntimeError(f"pack buffer mismatch: need contiguous fp32 {tuple(shape)} on {device}, got {tuple(out.shape)} {out.dtype} {out.device}")
+    return out
+
+
+def pack_taps(w, out=None):
     """w [Cout,Cin,kh,kw] -> [1, kh*kw, Cout, Cin] (the conv kernel's B operand layout)."""
     w = _f32(w)
     cout, cin = w.shape[:2]
     taps = w.shape[2] * w.shape[3]
-    out = torch.empty(1, taps, cout, cin, device=w.device, dtype=torch.float32)
+    out = _into(out, (1, taps, cout, cin), w.device)
     call("e4s_pack_taps_f32", fptr(w), fptr(out), cout, cin, taps, stream())
     return out
 
 
-def polyphase_weights(w, blur_kernel):
+def polyphase_weights(w, blur_kernel, out=None):
     """w [Cout,Cin,3,3] + 4x4 blur -> [4, 9, Cout, Cin] phase kernels of the fused transposed conv + blur."""
     w = _f32(w)
     cout, cin = w.shape[:2]
-    out = torch.empty(4, 9, cout, cin, device=w.device, dtype=torch.float32)
+    out = _into(out, (4, 9, cout, cin), w.device)
     call("e4s_polyphase_weights_f32", fptr(w), fptr(_f32(blur_kernel)), fptr(out), cout, cin, stream())
     return out
 
@@ -413,21 +424,21 @@ def want_bf16x3(b, h, w, cin, cout, ncls=1, masked=False):
     return tiles * max(split, 1) >= 64
 
 
-def split_bf16x2(w):
+def split_bf16x2(w, out=None):
     """fp32 [..., Cin] -> its split-bf16 image (hi|lo per 32-channel chunk), returned as an opaque fp32-typed tensor of
     the same shape/byte size (only e4s_conv_bf16x3_f32 reads it)."""
     w = _f32(w)
-    out = torch.empty_like(w)
+    out = _into(out, tuple(w.shape), w.device)
     cin = w.shape[-1]
     call("e4s_split_bf16x2_f32", fptr(w), ptr(out), w.numel() // cin, cin, stream())
     return out
 
 
-def split16_bf16x2(w):
+def split16_bf16x2(w, out=None):
     """fp32 tap-packed weights [ncls, 9, Cout, Cin] -> the [ncls*9][Cin/16][Cout][16 hi | 16 lo] split image
     e4s_conv_region_bf16x3_f32 reads (opaque, same byte size)."""
     w = _f32(w)
-    out = torch.empty_like(w)
+    out = _into(out, tuple(w.shape), w.device)
     cout, cin = w.shape[-2], w.shape[-1]
     call("e4s_split16_bf16x2_f32", fptr(w), ptr(out), w.numel() // (cout * cin), cout, cin, stream())
     return out
@@ -544,12 +555,12 @@ def upconv_mfma(x, w3, cout, k4, *, in_scale=None, out_scale=None, labels=None, 
     return y
 
 
-def subpixel_weights(w):
+def subpixel_weights(w, out=None):
     """w [Cout,Cin,3,3] -> the packed, hi/lo-split sub-pixel GEMM operand of e4s_upconv_bf16x3_f32 (csrc/upconv_bf16x3.hip):
     [Cin/32, Cout/32, 9 blocks, 32 co, 32 hi | 32 lo bf16], returned as an opaque fp32-typed tensor of the same byte size."""
     w = _f32(w)
     cout, cin = w.shape[:2]
-    out = torch.empty(cin // 32, cout // 32, 9, 32, 32, device=w.device, dtype=torch.float32)
+    out = _into(out, (cin // 32, cout // 32, 9, 32, 32), w.device)
     call("e4s_subpixel_weights_f32", fptr(w), ptr(out), cout, cin, stream())
     return out
 
@@ -1041,11 +1052,11 @@ def upfirdn2d_nhwc(x, kernel, up=1, down=1, pad=(0, 0)):
 
 
 # ---- backward (generator) --------------------------------------------------------------------
-def pack_taps_bwd(w_fwd):
+def pack_taps_bwd(w_fwd, out=None):
     """forward-packed [ncls,9,Cout,Cin] -> backward layout [ncls,9,Cin,Cout] (taps flipped)."""
     ncls, taps, cout, cin = w_fwd.shape
     assert taps == 9
-    wt = torch.empty(ncls, 9, cin, cout, device=w_fwd.device, dtype=torch.float32)
+    wt = _into(out, (ncls, 9, cin, cout), w_fwd.device)
     call("e4s_pack_taps_bwd_f32", fptr(w_fwd), fptr(wt), ncls, cout, cin, stream())
     return wt
 

@@ -186,9 +186,15 @@ class GraphedStep:
             capture_error_mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
         from .shard import quiesce_before_capture
         quiesce_before_capture()                                # (a live "nccl" group: its watchdog's list is empty before the capture)
+        import os
+        dump = os.environ.get("E4S_GRAPH_DEBUG_DUMP")           # diagnostics: write the captured graph as a DOT file (node kinds: the
+        if dump:                                                # captured step must hold kernel nodes only, no MEMSET nodes -- kernels.sum_all)
+            self.graph.enable_debug_mode()
         with K.flag_sink(flags):                                # this thread's mask checks accumulate here instead of syncing
             with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
                 self.loss = body()
+        if dump:
+            self.graph.debug_dump(dump)
         self.flags = flags
         self._written = list(opt.written_tensors()) + list(also_written)
         self._state_ptrs = opt.captured_state_ptrs()

@@ -192,6 +192,18 @@ class ModulatedConv2d(nn.Module):
         self.fused = fused
         self._pack = None
 
+    def _buf(self, name, shape, device):
+        """ONE buffer per weight pack for the module's lifetime: re-packs after a weight update write in place.  Nothing is allocated
+        when the weights change -- not eagerly, and not inside a captured train step that re-packs in the graph (train.graphed_g_step with
+        train_G: the capture then holds no pack allocations at all) -- and whatever holds a pack's address (the style prologue's job
+        tables, Generator._style_plan) stays valid."""
+        bufs = self.__dict__.setdefault("_e4s_bufs", {})
+        t = bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != device:
+            t = torch.empty(shape, device=device, dtype=torch.float32)
+            bufs[name] = t
+        return t
+
     def packed(self):
         """Returns dict(w=[ncls,taps,Cout,Cin], wsq=[Cout,Cin] | None, w_rgb=[Cout,Cin] for 1x1)."""
         key = _param_key(self.weight) + ((_param_key(self.blur.kernel)) if self.upsample else ())
@@ -200,51 +212,48 @@ class ModulatedConv2d(nn.Module):
         with torch.no_grad():
             w = self.weight.detach()[0].float()                                  # [Cout,Cin,k,k]
             cout, cin, k, _ = w.shape
+            dev = w.device
             pack = {"key": key}
             if k == 1:
                 pack["w"] = w.reshape(1, 1, cout, cin).contiguous()
             elif not self.upsample:
-                pack["w"] = K.pack_taps(w.contiguous())
+                pack["w"] = K.pack_taps(w.contiguous(), out=self._buf("w", (1, 9, cout, cin), dev))
             else:
                 # same math as polyphase_upconv_weights() below (the CPU-tested statement of it)
-                pack["w"] = K.polyphase_weights(w.contiguous(), self.blur.kernel.detach().float())
-                pack["w3"] = K.pack_taps(w.contiguous())        # plain taps for the exact tile-fused up-conv
-            if self.demodulate:
-                # sum_k W^2 lives in ONE buffer for the module's lifetime (rewritten in place when the weights change): the batched
-                # style prologue's job tables hold its address (Generator._style_plan), so a weight update -- also one made by a
-                # replayed HIP graph that re-packs inside the graph (train.graphed_g_step with train_G) -- needs no new table
-                keep = self._pack["wsq"] if self._pack is not None else None
-                if keep is not None and (keep.shape != (cout, cin) or keep.device != w.device):
-                    keep = None
-                pack["wsq"] = K.weight_sqsum(w.contiguous(), out=keep)
-            else:
-                pack["wsq"] = None
+                pack["w"] = K.polyphase_weights(w.contiguous(), self.blur.kernel.detach().float(), out=self._buf("w", (4, 9, cout, cin), dev))
+                pack["w3"] = K.pack_taps(w.contiguous(), out=self._buf("w3", (1, 9, cout, cin), dev))   # plain taps: exact tile-fused up-conv
+            pack["wsq"] = K.weight_sqsum(w.contiguous(), out=self._buf("wsq", (cout, cin), dev)) if self.demodulate else None
         self._pack = pack
         return pack
 
+    def _derived(self, name, build):
+        """A lazily built image of the current pack (split-bf16 operands, backward layouts), in its lifetime buffer."""
+        pk = self.packed()
+        if name not in pk:
+            with torch.no_grad():
+                pk[name] = build(pk)
+        return pk[name]
+
     def subpixel_split_weights(self):
         """Split-bf16 image of the sub-pixel GEMM operand of e4s_upconv_bf16x3_f32 (exact up-conv; cached with the pack)."""
-        pk = self.packed()
-        if "w_sub_split" not in pk:
-            with torch.no_grad():
-                pk["w_sub_split"] = K.subpixel_weights(self.weight.detach()[0].float().contiguous())
-        return pk["w_sub_split"]
+        cout, cin = self.out_channel, self.in_channel
+        return self._derived("w_sub_split", lambda pk: K.subpixel_weights(
+            self.weight.detach()[0].float().contiguous(), out=self._buf("w_sub_split", (cin // 32, cout // 32, 9, 32, 32), self.weight.device)))
 
     def split_weights(self):
         """Split-bf16 image of packed()["w"] for e4s_conv_bf16x3_f32 (built on first use, cached with the pack)."""
-        pk = self.packed()
-        if "w_split" not in pk:
-            with torch.no_grad():
-                pk["w_split"] = K.split_bf16x2(pk["w"])
-        return pk["w_split"]
+        return self._derived("w_split", lambda pk: K.split_bf16x2(pk["w"], out=self._buf("w_split", tuple(pk["w"].shape), pk["w"].device)))
 
     def split_weights16(self):
         """16-channel-chunk split image of packed()["w"] for e4s_conv_region_bf16x3_f32 (masked layers; cached with the pack)."""
-        pk = self.packed()
-        if "w_split16" not in pk:
-            with torch.no_grad():
-                pk["w_split16"] = K.split16_bf16x2(pk["w"])
-        return pk["w_split16"]
+        return self._derived("w_split16", lambda pk: K.split16_bf16x2(pk["w"], out=self._buf("w_split16", tuple(pk["w"].shape), pk["w"].device)))
+
+    def bwd_taps(self):
+        """packed()["w"] in the backward layout [ncls,9,Cin,Cout], taps flipped (e4s_conv_bwd_mfma_f32's operand)."""
+        def build(pk):
+            ncls, _, cout, cin = pk["w"].shape
+            return K.pack_taps_bwd(pk["w"], out=self._buf("wt", (ncls, 9, cin, cout), pk["w"].device))
+        return self._derived("wt", build)
 
     def forward(self, input, style):
         """Drop-in single-style forward (NCHW in/out), model.py:242-320."""

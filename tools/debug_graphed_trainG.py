@@ -75,7 +75,17 @@ for vname, only in variants:
         l, _ = ite.g_step(img, mask, randomize_noise=False)
         losses_e.append(float(l))
     itg, ng = build(only)
+    dot = os.path.join("/tmp", "e4s_graph_%s.dot" % vname.split()[0])
+    os.environ["E4S_GRAPH_DEBUG_DUMP"] = dot
     gs = itg.graphed_g_step(img, mask, warmup=2, randomize_noise=False)
+    node_kinds = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from graph_node_kinds import kinds
+        node_kinds = kinds(dot)
+        os.remove(dot)
+    except Exception as e:      # noqa: BLE001
+        node_kinds = "dump failed: %s" % e
     # state after the 2 warm-ups must equal the eager twin after 2 steps: rebuild an eager twin for that
     it2, n2 = build(only)
     for _ in range(2):
@@ -87,7 +97,7 @@ for vname, only in variants:
     l4 = float(gs.step())
     d_2 = diff(ne, ng)
     torch.cuda.synchronize()
-    print(json.dumps({"variant": vname, "trainable_G": sum(1 for n, p in ng.named_parameters() if n.startswith("G.") and p.requires_grad),
+    print(json.dumps({"variant": vname, "graph_node_kinds": node_kinds, "trainable_G": sum(1 for n, p in ng.named_parameters() if n.startswith("G.") and p.requires_grad),
                       "eager_losses": losses_e, "graphed_losses_3_4": [l3, l4], "diff_after_warmups": d_w[:4], "n_after_warmups": len(d_w),
                       "diff_after_replay1": d_1[:6], "n_after_replay1": len(d_1), "diff_after_replay2": d_2[:6], "n_after_replay2": len(d_2)}), flush=True)
     del gs, itg, ng, ite, ne, it2, n2
