@@ -151,9 +151,11 @@ class bottleneck_IR_SE(Module):
         # out = gate * BN(r2) + shortcut; gate = sigmoid(fc2 relu(fc1 pooled)), pooled = mean_p BN(r2)
         dgate = K.instnorm_bwd_sums(dout, r2, st_r)[:, :, 1]
         fc1, fc2 = _se_weights(se)
-        hidden = torch.relu(pooled @ fc1.t())                          # [B,C]-sized chain rule
-        dz = dgate * gate * (1.0 - gate)
-        dpooled = ((dz @ fc2) * (hidden > 0)) @ fc1
+        # [B,C]-sized chain rule on the native grouped kernels (no library GEMM inside a captured step: kernels.sum_all)
+        hidden = K.grouped_linear(pooled.contiguous().unsqueeze(1), fc1.unsqueeze(0).contiguous(), None, None, 1.0, act=1, alpha=0.0)
+        dz = (dgate * gate * (1.0 - gate)).unsqueeze(1).contiguous()
+        dh = K.grouped_linear_t(dz, fc2.unsqueeze(0).contiguous(), 1.0, ref=hidden, alpha=0.0)
+        dpooled = K.grouped_linear_t(dh, fc1.unsqueeze(0).contiguous(), 1.0).squeeze(1)
         extra = (dpooled / float(r2.shape[1] * r2.shape[2])).contiguous()
         dr2 = K.norm_bwd_frozen(dout, st_r, gate=gate, extra=extra)
         gz2 = dr2 if s == 1 else K.strided_scatter(dr2, s)

@@ -93,11 +93,14 @@ def unit_backward(rec, dout, give):
     dr2, sums = K.instnorm_bwd(dout, r2, rec["st_r"], gate)
     dgate = sums[:, :, 1]
     fc1, fc2 = se.fc1.weight.detach().view(se.fc1.weight.shape[0], -1), se.fc2.weight.detach().view(se.fc2.weight.shape[0], -1)
-    hidden = torch.relu(rec["pooled"] @ fc1.t())                              # [B,Cr]  (tiny [B,C]-sized chain rule)
-    dz = dgate * gate * (1.0 - gate)
-    give(se.fc2.weight, (dz.t() @ hidden).view_as(se.fc2.weight))
-    dh = (dz @ fc2) * (hidden > 0)
-    give(se.fc1.weight, (dh.t() @ rec["pooled"]).view_as(se.fc1.weight))
+    # the SE chain rule on [B,C]-sized operands, on the native grouped kernels (ordered sums; no library GEMM inside a captured step:
+    # kernels.sum_all)
+    pooled = rec["pooled"].contiguous().unsqueeze(1)                          # [B,1,C]
+    hidden = K.grouped_linear(pooled, fc1.unsqueeze(0).contiguous(), None, None, 1.0, act=1, alpha=0.0)      # relu(pooled fc1^T) [B,1,Cr]
+    dz = (dgate * gate * (1.0 - gate)).unsqueeze(1).contiguous()              # [B,1,C]
+    give(se.fc2.weight, K.grouped_outer(dz, hidden, 1.0)[0].view_as(se.fc2.weight))
+    dh = K.grouped_linear_t(dz, fc2.unsqueeze(0).contiguous(), 1.0, ref=hidden, alpha=0.0)                   # (dz fc2) * (hidden > 0)
+    give(se.fc1.weight, K.grouped_outer(dh, pooled, 1.0)[0].view_as(se.fc1.weight))
     # ---- conv2 (3x3, stride s) ----
     give(conv2.weight, _wgrad(dr2, r1, s, 9))
     gz2 = dr2 if s == 1 else K.strided_scatter(dr2, s)

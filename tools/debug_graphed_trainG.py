@@ -62,6 +62,12 @@ variants = [("none (G frozen by filter)", ["@@"]), ("modulation", ["modulation"]
             ("convw_all conv.weight of every styled conv", lambda n: is_convw(n, -1)),
             ("convw_2_7", lambda n: is_convw(n, 2, 7)), ("convw_up even convs (up-convs)", lambda n: is_convw(n, 0) and int(n.split(".")[2]) % 2 == 0),
             ("convw_plain odd convs", lambda n: is_convw(n, 0) and int(n.split(".")[2]) % 2 == 1),
+            ("cwA conv1 + 2..7", lambda n: is_convw(n, 2, 7) or n == "G.conv1.conv.weight"),
+            ("cwB convs.0 + 2..7", lambda n: is_convw(n, 2, 7) or is_convw(n, 0, 0)),
+            ("cwC convs.1 + 2..7", lambda n: is_convw(n, 2, 7) or is_convw(n, 1, 1)),
+            ("cwD -1..2", lambda n: is_convw(n, -1, 2)), ("cwE -1..3", lambda n: is_convw(n, -1, 3)), ("cwF -1..5", lambda n: is_convw(n, -1, 5)),
+            ("cwG 0..7", lambda n: is_convw(n, 0, 7)), ("cwH -1,0,1,6,7", lambda n: is_convw(n, -1, 1) or is_convw(n, 6, 7)),
+            ("cwI -1..1 + 2,3", lambda n: is_convw(n, -1, 3)),
             ("noise.weight", ["noise.weight"]), ("activate.bias", ["activate.bias"]), ("to_rgb", ["to_rgb"]), ("input", ["input.input"]),
             ("allbut_convw", lambda n: not is_convw(n, -1)), ("allbut_rgb", lambda n: "to_rgb" not in n),
             ("all", None)]
