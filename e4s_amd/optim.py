@@ -170,6 +170,7 @@ class GraphedStep:
             raise RuntimeError("GraphedStep needs FusedAdam(capturable=True): the host-side step count cannot be replayed")
         self.opt = opt
         side = torch.cuda.Stream()
+        self._stream = side                                     # warm-ups AND capture run on it (see below)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):                     # also fills the weight-pack / target-feature caches
@@ -191,7 +192,13 @@ class GraphedStep:
         if dump:                                                # captured step must hold kernel nodes only, no MEMSET nodes -- kernels.sum_all)
             self.graph.enable_debug_mode()
         with K.flag_sink(flags):                                # this thread's mask checks accumulate here instead of syncing
-            with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
+            # ... on the SAME side stream as the warm-up steps.  Autograd's AccumulateGrad nodes keep the stream they were created on, and
+            # nodes that outlive the warm-ups (anything still referencing last step's graph keeps them alive; torch warns "The
+            # AccumulateGrad node's stream does not match ...") would otherwise run on a second stream inside the capture: their branch of
+            # the replayed graph is ordered against the main branch only through the engine's event edges, not through the caching
+            # allocator's per-stream reuse -- a train_G step captured that way came back with NaNs once all nine generator conv weights
+            # were trainable (tools/debug_graphed_trainG.py, profiles/r05_graphed_trainG_bisect.json).  One stream: one branch.
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=capture_error_mode):
                 self.loss = body()
         if dump:
             self.graph.debug_dump(dump)

@@ -201,7 +201,9 @@ class TrainIteration:
         self.opt.step()
         if self.net_ema is not None:
             accumulate(self.net_ema, self.core, self.ema_decay)
-        return loss.detach(), terms
+        # detached: a caller that keeps `terms` around must not keep this step's autograd graph (and with it the AccumulateGrad node of
+        # every parameter, pinned to the stream of THIS step) alive into the next one -- see optim.GraphedStep
+        return loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in terms.items()}
 
     def forget_targets(self):
         """A new batch: drop the loss networks' cached target features.  criteria.py caches them per target TENSOR (right for the

@@ -35,9 +35,21 @@ def build(only):
         for name, p in n3.named_parameters():
             if name.startswith("G.") and p.requires_grad and not keep(name):
                 p.requires_grad = False
+    if os.environ.get("DBG_FREEZE_ENCODER") == "1":          # far fewer graph nodes: does the failure follow the size of the graph?
+        for name, p in n3.named_parameters():
+            if name.startswith("encoder."):
+                p.requires_grad = False
     params = [p for p in n3.parameters() if p.requires_grad]
     opt = FusedAdam(params, lr=1e-4, capturable=True)
     lo = LossOpts(face_parsing_lambda=0.0, id_lambda=0.0, lpips_lambda=0.0)
+    n3.stash = {}
+    orig = n3.forward
+
+    def fwd(*a, **k):                       # keep the (static, when captured) output image of the last forward for inspection
+        out = orig(*a, **k)
+        n3.stash["recon"] = out[0].detach()
+        return out
+    n3.forward = fwd
     return TrainIteration(n3, None, {}, opt, None, lo=lo), n3
 
 
@@ -99,11 +111,20 @@ for vname, only in variants:
     d_w = diff(n2, ng)
     l3 = float(gs.step())
     it2.g_step(img, mask, randomize_noise=False)
+    rg, re_ = ng.stash["recon"], n2.stash["recon"]
+    recon_info = {"graph_recon_finite": bool(torch.isfinite(rg).all()), "recon_maxdiff_vs_eager": float((rg - re_).abs().max()),
+                  "l2_from_graph_recon": float(((rg - img) ** 2).mean()), "loss_tensor": l3}
+    gd = []
+    for (name, p), (_, q) in zip(ng.named_parameters(), n2.named_parameters()):
+        if p.grad is not None and q.grad is not None and not torch.equal(p.grad, q.grad):
+            gd.append((name, float((p.grad - q.grad).abs().max()), float(q.grad.abs().max())))
+    recon_info["n_grads_differ"] = len(gd)
+    recon_info["first_grads_differ"] = gd[:5] + gd[-3:]
     d_1 = diff(n2, ng)
     l4 = float(gs.step())
     d_2 = diff(ne, ng)
     torch.cuda.synchronize()
-    print(json.dumps({"variant": vname, "graph_node_kinds": node_kinds, "trainable_G": sum(1 for n, p in ng.named_parameters() if n.startswith("G.") and p.requires_grad),
+    print(json.dumps({"variant": vname, "replay1": recon_info, "trainable_G": sum(1 for n, p in ng.named_parameters() if n.startswith("G.") and p.requires_grad),
                       "eager_losses": losses_e, "graphed_losses_3_4": [l3, l4], "diff_after_warmups": d_w[:4], "n_after_warmups": len(d_w),
                       "diff_after_replay1": d_1[:6], "n_after_replay1": len(d_1), "diff_after_replay2": d_2[:6], "n_after_replay2": len(d_2)}), flush=True)
     del gs, itg, ng, ite, ne, it2, n2
