@@ -1083,6 +1083,62 @@ def conv_bwd(gz, wt, x, s, d, labels, num_regions, ncls, want_ds=True):
     return dx, ds
 
 
+def region_scale(gz, d, labels, num_regions, ncls=1):
+    """u = gz * d[region of the output pixel] (e4s_region_scale_f32): gz NHWC [B,Ho,Wo,C], d [B*R,C], labels uint8 [B,Hm,Wm].
+    ncls == 1: u like gz.  ncls == 4 (polyphase up-conv, Ho = 2H): u [4,B,H,W,C], one contiguous map per output phase."""
+    gz = _f32(gz)
+    b, ho, wo, c = gz.shape
+    if ncls == 4:
+        if ho % 2 or wo % 2:
+            raise RuntimeError("region_scale: the polyphase form needs an even output grid")
+        h, w = ho // 2, wo // 2
+        u = torch.empty(4, b, h, w, c, device=gz.device, dtype=torch.float32)
+    else:
+        h, w = ho, wo
+        u = torch.empty_like(gz)
+    call("e4s_region_scale_f32", fptr(gz), fptr(_f32(d)), ptr(labels), labels.shape[1], labels.shape[2], int(num_regions), fptr(u),
+         b, h, w, c, int(ncls), stream())
+    return u
+
+
+def col2im_region_ok(c):
+    return c % 4 == 0 and 4 <= c <= 1024 and 256 % (c // 4) == 0
+
+
+SCATTER_DGRAD = os.environ.get("E4S_SCATTER_DGRAD", "1") != "0"
+
+
+def scatter_dgrad_wanted(b, h, w, cy, cx):
+    """Policy of the scatter-form input gradient of a masked StyledConv (x [b,h,w,cx] -> cy channels; for an up-conv h, w are the INPUT
+    grid and one launch runs per output phase): a 1x1 split-bf16 contraction [b h w, cy] x [cy, 9 cx] on the gather kernel (256-row x
+    128-column tiles) + e4s_col2im_region_f32.  `auto`: where that launch fills the chip, `bf16x3`: wherever the kernels apply, `f32`: never
+    (the exact-fp32 dx + ds kernel)."""
+    if not SCATTER_DGRAD or PRECISION == "f32" or cy % 32 or (9 * cx) % 128 or not col2im_region_ok(cx):
+        return False
+    if PRECISION == "bf16x3":
+        return True
+    return (b * h * w + 255) // 256 * ((9 * cx) // 128) >= BF16X3_MIN_BLOCKS
+
+
+def col2im_region(G, x, s, labels, num_regions, ncls=1):
+    """(dx, ds) of a masked StyledConv from the scatter-form products (e4s_col2im_region_f32): G [ncls,B,H,W,9*C] (tap-major columns: the 1x1
+    contraction of u with the tap-stacked weights), x NHWC [B,H,W,C] the layer's input, s [B*R,C] -> dx like x, ds like s."""
+    b, h, w, c = x.shape
+    if G.numel() != ncls * b * h * w * 9 * c or not G.is_contiguous() or not x.is_contiguous():
+        raise RuntimeError("col2im_region: G must be contiguous [ncls,B,H,W,9*C] for x [B,H,W,C]")
+    r = int(num_regions)
+    dx = torch.empty_like(x)
+    ds = torch.empty(b * r, c, device=x.device, dtype=torch.float32)
+    L = lib.load()
+    nsplit = L.e4s_col2im_region_nsplit(b, h, w, c)
+    if nsplit <= 0:
+        raise RuntimeError("col2im_region: unsupported channel count")
+    ws = torch.empty(L.e4s_reduce_parts_ws_floats(nsplit, ds.numel()), device=x.device, dtype=torch.float32)
+    call("e4s_col2im_region_f32", fptr(G), fptr(x), fptr(_f32(s)), ptr(labels), labels.shape[1], labels.shape[2], r, fptr(dx), fptr(ds),
+         fptr(ws), b, h, w, c, int(ncls), stream())
+    return dx, ds
+
+
 def scale_dot(u, x, s):
     """u, x NHWC [B,H,W,C]; s [B,C]: u <- u * s[b] in place (returned) and ds[b,c] = sum_p x * u (the unscaled u), ordered sums."""
     b, h, w, c = u.shape

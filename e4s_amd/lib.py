@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E4S_LIB_PATH") or os.path.join(_HERE, "libe4s_hip.so")      # (E4S_LIB_PATH: A/B runs of two builds)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -117,6 +117,9 @@ SIGNATURES = {
     "e4s_adam_step_dev_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_p, c_d, c_d, c_d, c_d, c_p, c_p],
     "e4s_advance_i64": [c_p, c_l, c_p],
     "e4s_conv_smallcin_col2im_f32": [c_p, c_p] + [c_i] * 10 + [c_p],
+    "e4s_region_scale_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "e4s_col2im_region_nsplit": [c_i, c_i, c_i, c_i],
+    "e4s_col2im_region_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_act_bwd_demod_nsplit": [c_i, c_i, c_i, c_i],
     "e4s_act_bwd_demod_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_pixel_unshuffle2_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],

@@ -248,6 +248,17 @@ class ModulatedConv2d(nn.Module):
         """16-channel-chunk split image of packed()["w"] for e4s_conv_region_bf16x3_f32 (masked layers; cached with the pack)."""
         return self._derived("w_split16", lambda pk: K.split16_bf16x2(pk["w"], out=self._buf("w_split16", tuple(pk["w"].shape), pk["w"].device)))
 
+    def scatter_taps(self):
+        """packed()["w"] [ncls,9,Cout,Cin] as the operand of the scatter-form input gradient (autograd.styled_conv_backward, masked
+        layers): per class a 1x1 contraction [Cout] -> [9*Cin] with the taps stacked in the COLUMNS, wg[cls][0][t*Cin + ci][co] =
+        w[cls][t][co][ci]; returns (wg, its split-bf16 image), both in lifetime buffers."""
+        def build(pk):
+            ncls, _, cout, cin = pk["w"].shape
+            wg = self._buf("wg", (ncls, 1, 9 * cin, cout), pk["w"].device)
+            wg.view(ncls, 9, cin, cout).copy_(pk["w"].permute(0, 1, 3, 2))
+            return wg, K.split_bf16x2(wg, out=self._buf("wg_split", (ncls, 1, 9 * cin, cout), pk["w"].device))
+        return self._derived("wg", build)
+
     def bwd_taps(self):
         """packed()["w"] in the backward layout [ncls,9,Cin,Cout], taps flipped (e4s_conv_bwd_mfma_f32's operand)."""
         def build(pk):

@@ -268,6 +268,21 @@ int e4s_demod_grad_f32(const float* gz, const float* y, const float* noise, cons
                        int64_t noise_bstride, const float* bias, float alpha, float gain,
                        const uint8_t* labels, int Hm, int Wm, int R, float* dd, float* ws, int B, int H, int W, int C,
                        void* stream);
+/* Input gradient of the MASKED StyledConvs in scatter form (csrc/dgrad_scatter.hip; autograd of model.py:386-400): the contraction
+ * G[m, t, ci] = sum_co u[m, co] W[t][co][ci] is a plain 1x1 e4s_conv_bf16x3_f32 launch (rows = source pixels, 9 Cx columns); these two
+ * passes hold everything that depends on the region map:
+ *   e4s_region_scale_f32: u = gz * d[region of the output pixel]; gz NHWC [B, H*os, W*os, C] (os = 2 when ncls == 4), d [B*R, C];
+ *     ncls == 1: u like gz; ncls == 4 (polyphase up-conv): u [4 phases][B, H, W, C], one contiguous map per output phase.
+ *   e4s_col2im_region_f32: G [ncls][B, H, W, 9, C] (tap-major columns), x NHWC [B, H, W, C] (the layer's input), s [B*R, C] ->
+ *     dx [B, H, W, C] = sum_ph sum_t s[region(m_t, ph)] * G_ph[m_t, t] (m_t = h - (t - 1)),
+ *     ds [B*R, C]    = sum over rows (m, ph) of region rho of sum_t x[m + t - 1] * G_ph[m, t]   (ordered sums: bit-reproducible).
+ *   C a multiple of 4 in [4, 1024] with 256 % (C/4) == 0, R <= 16; ws: e4s_reduce_parts_ws_floats(e4s_col2im_region_nsplit(B,H,W,C), B*R*C). */
+int e4s_region_scale_f32(const float* gz, const float* d, const uint8_t* labels, int Hm, int Wm, int R, float* u, int B, int H, int W, int C,
+                         int ncls, void* stream);
+int e4s_col2im_region_nsplit(int B, int H, int W, int C);
+int e4s_col2im_region_f32(const float* G, const float* x, const float* s, const uint8_t* labels, int Hm, int Wm, int R, float* dx, float* ds,
+                          float* ws, int B, int H, int W, int C, int ncls, void* stream);
+
 /* pixel splits of the two segmented reductions here: their `ws` scratch holds e4s_reduce_parts_ws_floats(nsplit, output
  * elements) floats, one slot per split, added in order (bit-reproducible; no floating-point atomics) */
 int e4s_seg_reduce_nsplit(int B, int H, int W, int C);

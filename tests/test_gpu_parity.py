@@ -1485,3 +1485,62 @@ def test_polyphase_fold_is_the_transpose_of_polyphase_weights():
     lhs = float((pw.double().cpu() * deff).sum())
     rhs = float((w.detach() * got.double().cpu()).sum())
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("cin,cout,res,up,lab", [(128, 64, 32, False, "blocks"), (128, 128, 16, True, "blocks"), (512, 512, 16, False, "face"),
+                                                 (256, 128, 32, True, "face"), (128, 96, 24, False, "face")])
+def test_masked_styled_conv_dgrad_in_scatter_form_vs_exact_fp32_and_oracle_f64(cin, cout, res, up, lab, monkeypatch):
+    """Masked StyledConv (per-pixel region styles, model.py:386-400; plain and polyphase up-conv) under the split-bf16 policy: dL/dx and
+    dL/dstyle from the SCATTER form (csrc/dgrad_scatter.hip: e4s_region_scale_f32 -> one 1x1 split-bf16 contraction per phase with the
+    nine taps in its columns -> e4s_col2im_region_f32) against the exact-fp32 dx + ds kernel it replaces and the oracle's fp64 autograd.
+    'blocks' = one region per 16x16 block of the 512^2 map (every pixel of a 32^2 layer is a boundary pixel), 'face' = the synthetic
+    face map; 24^2 x 96 channels: partial 256-row tiles.  The gradients are bit-reproducible (ordered dL/ds sums)."""
+    from e4s_amd import kernels as K
+    from e4s_amd.autograd import styled_conv_backward
+    from e4s_amd.stylegan2 import StyledConv
+    sd = _styled_sd(cin, cout, up, 31)
+    m = StyledConv(cin, cout, 3, 512, upsample=up, mask_op=True)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(60)
+    b, r = 2, 12
+    x = torch.randn(b, cin, res, res, generator=g)
+    style = torch.randn(b, r, 512, generator=g)
+    mask = synth.onehot(synth.synth_labels_blocks(b, 512, 16, seed=7) if lab == "blocks" else synth.synth_labels_face(b, 512, seed=70))
+    ores = res * 2 if up else res
+    noise = torch.randn(b, 1, ores, ores, generator=g)
+    wgt = torch.randn(b, cout, ores, ores, generator=g)
+    xd = K.nchw_to_nhwc(x.to(DEV))
+    mod = m.conv.modulation
+    s = K.modulate_vec(style.reshape(-1, 512).to(DEV), mod.weight, mod.bias)
+    labels = K.mask_labels(mask.to(DEV))[0]
+    monkeypatch.setattr(K, "PRECISION", "f32")          # ONE exact forward for both backward paths (no activation-kink flips between them)
+    rec = {}
+    y = m.run_nhwc(xd, s, noise.to(DEV), labels, r, rec=rec)
+    rec.update(layer=m, x=xd, y=y, s=s, labels=labels)
+
+    def run(prec):
+        monkeypatch.setattr(K, "PRECISION", prec)
+        dx, ds = styled_conv_backward(rec, K.nchw_to_nhwc(wgt.to(DEV)), r, {})
+        return K.nhwc_to_nchw(dx), (ds @ mod.weight.detach()) * mod.scale, ds
+
+    monkeypatch.setattr(K, "PRECISION", "bf16x3")
+    used = K.scatter_dgrad_wanted(b, res, res, cout, cin)
+    dx, dstyle, ds = run("bf16x3")
+    dx2, _, ds2 = run("bf16x3")
+    dx32, dstyle32, _ = run("f32")
+    assert torch.equal(dx, dx2) and torch.equal(ds, ds2)
+    f64 = torch.float64
+    sd64 = {k: v.to(f64) for k, v in sd.items()}
+    xr = x.to(f64).requires_grad_(True)
+    sr = style.to(f64).requires_grad_(True)
+    yr = orc.styled_conv(sd64, "", xr, sr, mask.to(f64), noise.to(f64), up, True)
+    (yr * wgt.to(f64)).sum().backward()
+    gs, ss = float(xr.grad.abs().max()), float(sr.grad.abs().max())
+    assert maxabs(dx32, xr.grad) < 1e-4 * gs
+    assert maxabs(dx, xr.grad) < 1e-4 * gs, ("scatter-form dgrad", used, maxabs(dx, xr.grad), gs)
+    assert maxabs(dstyle.view_as(sr), sr.grad) < 3e-4 * ss and maxabs(dstyle, dstyle32) < 3e-4 * ss
+    if cout % 32 == 0:
+        assert used and 0 < maxabs(dx, dx32)            # really another kernel (96 output channels: the policy keeps the fp32 kernel)
+    else:
+        assert not used
