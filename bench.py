@@ -264,9 +264,11 @@ def stitch_leg(net, inputs, reps=10):
         out[name] = round((time.perf_counter() - t0) / reps * 1e3, 3)
     out["batch"] = b
     out["out"] = f"uint8 {list(res.shape)}"
-    # cv2 / skimage exist neither in the build container nor on the GPU box (probed this round): the OpenCV halves of the stitch (erode,
-    # fixed-point GaussianBlur, pyrDown / pyrUp) are checked against a restatement of OpenCV's algorithms, not against cv2 itself
-    out["parity"] = "mask swap / create_masks / tensor2im / alpha composite: pinned to the reference's own outputs; cv2 parts: unpinned"
+    # cv2 / skimage exist neither in the build container nor on the GPU box: the OpenCV halves of the stitch (erode, fixed-point
+    # GaussianBlur, pyrDown / pyrUp, the Laplacian blend's schedule) are restatements of OpenCV's algorithms, cross-checked against
+    # independent third-party implementations (scipy.ndimage, PIL) on the reference's example images (tests/golden/cv2free.pt) -- not cv2
+    out["parity"] = ("mask swap / create_masks / tensor2im / alpha composite: pinned to the reference's own outputs; cv2 parts: cross-checked "
+                     "against scipy.ndimage / PIL (erode, uint8 pyrDown exact; Gaussian, blend +-1 LSB; float pyramids 2 ulp), not pinned to cv2")
     return out
 
 

@@ -13,7 +13,7 @@ OUT=$R/gpurun_out/profiles
 RAW=/tmp/e4s_prof
 mkdir -p "$OUT" "$RAW"
 run() { name=$1; shift; timeout 400 rocprofv3 "$@" > "$RAW/$name.log" 2>&1; echo "$name rc=$?"; }
-STEPS="python bench.py --steps 4 --warmup 1 --steps-only"
+STEPS="python bench.py --steps 6 --warmup 2 --steps-only"
 run probe --kernel-trace --stats -f csv -d $RAW/probe -o probe -- python bench.py --probe-only --probe-reps 50
 run bench --kernel-trace --stats -f csv -d $RAW/bench -o bench -- $STEPS --no-graph
 run graph --kernel-trace --stats -f csv -d $RAW/graph -o graph -- $STEPS
@@ -29,7 +29,7 @@ fi
 f() { find $RAW/$1 -name "*$2" 2>/dev/null | head -1; }
 python tools/prof_summarize.py trace "$(f probe _kernel_trace.csv)" > $OUT/${TAG}_probe_kernel_stats.csv
 python tools/prof_summarize.py trace "$(f bench _kernel_trace.csv)" > $OUT/${TAG}_bench_kernel_stats.csv
-python tools/prof_summarize.py trace "$(f graph _kernel_trace.csv)" > $OUT/${TAG}_graph_replay_kernel_stats.csv
+python tools/prof_summarize.py replay "$(f graph _kernel_trace.csv)" $OUT/${TAG}_graph_replay_info.json > $OUT/${TAG}_graph_replay_kernel_stats.csv   # replays ONLY
 cp "$(f probe _kernel_stats.csv)" $OUT/${TAG}_probe_rocprof_stats.csv 2>/dev/null
 cp "$(f bench _kernel_stats.csv)" $OUT/${TAG}_bench_rocprof_stats.csv 2>/dev/null
 if [ "$MODE" != quick ]; then
