@@ -35,7 +35,12 @@ def _digest():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libe4s_hip.so in-tree.  Returns the path."""
+    """Compile every HIP source for gfx950 and link libe4s_hip.so in-tree.  Returns the path.
+    E4S_BUILD_OUT=<path.so>: a SECOND library beside the product one (profiling builds with E4S_BUILD_ABLATIONS=1, A/B builds; loaded
+    with E4S_LIB_PATH): own object directory, no stamp, the product library is not touched."""
+    alt = os.environ.get("E4S_BUILD_OUT")
+    if alt:
+        return _build_to(os.path.abspath(alt), os.path.join(os.path.dirname(os.path.abspath(alt)), "obj_" + os.path.basename(alt)), verbose)
     dig = _digest()
     if not force and os.path.isfile(LIB) and os.path.isfile(STAMP) and open(STAMP).read().strip() == dig:
         return LIB
@@ -66,6 +71,32 @@ def build(force=False, verbose=False):
     with open(STAMP, "w") as fh:
         fh.write(dig)
     return LIB
+
+
+def _build_to(lib, objdir, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.isfile(hipcc):
+        hipcc = "hipcc"
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + \
+            _extra_flags() + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out.decode(errors="replace"))
+            raise RuntimeError(f"hipcc failed on {src}")
+    res = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout.decode(errors="replace"))
+        raise RuntimeError("link failed")
+    return lib
 
 
 if __name__ == "__main__":

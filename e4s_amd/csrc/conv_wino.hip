@@ -45,8 +45,9 @@ constexpr int VROWS = (TH + 2) * NPAIR;          // 144 V-pixels per position an
 constexpr int BN = 128, KC = 16, ROWB = 64;
 constexpr int A_PLANE = VROWS * ROWB, A_BYTES = 4 * A_PLANE;        // 36 864
 constexpr int B_PLANE = BN * ROWB, B_BYTES = 4 * B_PLANE;           // 32 768
+constexpr int WT_MIN_CHUNKS = 8;                                     // wave tile 1 (64 x 64 x 2 positions) from this many 16-channel chunks per block on
 constexpr int NITEMS = VROWS * 4;                                   // 576 (V-pixel, 4-channel group) items per chunk
-constexpr int SMEM_WINO = 2 * A_BYTES + 2 * B_BYTES + 2 * BN * 2 * 8;       // + Cin * 8 bytes of {mean, rstd} when XF == 2 (launcher)
+constexpr int SMEM_WINO = 2 * A_BYTES + 2 * B_BYTES + 4 * BN * 2 * 8;       // + Cin * 16 bytes of {mean, rstd} tables when XF == 2 (launcher)
 
 __device__ __forceinline__ int swz(int row, int g) { return row * ROWB + ((g ^ ((row >> 2) & 3)) << 4); }
 
@@ -95,7 +96,15 @@ struct WTile {              // one 16x16-pixel x 128-column output tile (x one K
 // pipeline runs straight through the tile boundary -- while the last chunk of tile t is contracted, the V of tile t+1's first chunk is
 // loaded / transformed / stored and its first U stage arrives by DMA, so a tile's prologue is never exposed (it was ~4 us of the 17 us a
 // K = 64 tile takes, ~4 of 34 at K = 128); only the register epilogue (output transform + stores, ~1.5 us of issue) sits between two tiles.
-template <int XF, int VAR = 0>
+// WT (round 5): the wave tile.  0: wave (wm, wn) of 2 x 4 owns 64 rows x 32 channels of ALL four positions -- every A and B fragment feeds
+// one or two MFMAs: 24 ds_read_b128 per 24 MFMAs, and with the weight DMA and the transform's stores the LDS is ~86 % busy when the matrix
+// pipe is 100 % busy (ablation: the same kernel with a third of its fragment reads skipped runs 11 % faster on 512 -> 512 @32^2,
+// profiles/r05_wino_ablations.json).  1: wave (pp, wm, wn) of 2 x 2 x 2 owns 64 rows x 64 channels of TWO positions {2 pp, 2 pp + 1}: 16 reads
+// per 24 MFMAs, same accumulators (8 x 16 registers), same fragment registers (the B fragments of the next position roll into the registers
+// the first half of the MFMAs has released).  The output transform needs M0..M3 of a pair in one place: once per tile the two waves of a
+// (wm, wn) exchange one position each through the LDS buffer the finished tile has released (pp = 0 sends M1 and produces the EVEN columns
+// out[2j] = (M0 + M1) + M2, pp = 1 sends M2 and produces the ODD ones out[2j+1] = (M1 - M2) - M3; two barriers).
+template <int XF, int VAR = 0, int WT = 0>
 __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p, const int ntn, const int tx_n, const int per_img,
                                                          const int ntiles, const int ksplit, const int cper) {
     // ksplit > 1 (launches of <= 128 tiles: batch-1 latency runs, the 16x16 maps): the 16-channel chunks of a tile are divided over ksplit
@@ -104,14 +113,15 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                                  // [2][4 pos][144][64]
     unsigned char* sB = smem + 2 * A_BYTES;                    // [2][4 pos][128][64]
-    double* s_st = reinterpret_cast<double*>(sB + 2 * B_BYTES);      // [2 wm][BN][2]
-    float* s_in = reinterpret_cast<float*>(s_st + 2 * BN * 2);       // XF == 2: [2 tile parities][Cin][{mean, rstd}] (read at transform time:
+    double* s_st = reinterpret_cast<double*>(sB + 2 * B_BYTES);      // [2 wm | WT: 4 = (pp, wm)][BN][2]
+    float* s_in = reinterpret_cast<float*>(s_st + 4 * BN * 2);       // XF == 2: [2 tile parities][Cin][{mean, rstd}] (read at transform time:
                                                                      // an item does not carry its statistics across the stage boundary)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = WT ? (wave >> 1) & 1 : wave >> 2, wn = WT ? wave & 1 : wave & 3;
+    const int pp = WT ? wave >> 2 : 0;            // WT: this wave's positions are 2 pp and 2 pp + 1
     const int G = gridDim.x;
     const int first = xcd_remap(blockIdx.x, G);
     const int mtiles = ntiles / (ntn * ksplit);
@@ -261,12 +271,14 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
     __syncthreads();
 
     // ---- fragment addressing: byte offsets inside a position plane ----
-    int aoff[2][3], boff;
+    int aoff[2][3], boff, boff2[2];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) aoff[tm][ky] = swz(wm * 64 + tm * 32 + li + 8 * ky, kh);
     boff = swz(wn * 32 + li, kh);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) boff2[tn] = swz(wn * 64 + tn * 32 + li, kh);        // WT: channel tiles of this wave's 64 columns
 
     f32x16 acc[4][2];
     struct AF { bf16x8 h[2], l[2]; };
@@ -342,8 +354,13 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                         BF& Bc = (ps & 1) ? B1 : B0;
                         BF& Bnx = (ps & 1) ? B0 : B1;
                         if (ps + 1 < 4 && VAR != 4 && VAR != 5) {
-                            ldB(Bnx, ps + 1);
-                            ldA(Anx, ps + 1);
+                            // VAR 9 / 10 (ablation builds; results WRONG): the fragment traffic of a wave tile of 64 x 64 x TWO positions
+                            // -- 16 instead of 24 ds_read_b128 per 24 MFMAs (9: the A fragments of odd positions are not re-read;
+                            // 10: nor their B fragments, 12 reads) -- what the LDS share of this kernel's time is worth
+                            if (!(VAR == 10 && ((ps + 1) & 1))) ldB(Bnx, ps + 1);
+                            if (!((VAR == 9 || VAR == 10) && ((ps + 1) & 1))) ldA(Anx, ps + 1);
+                            else Anx = Ac;
+                            if (VAR == 10 && ((ps + 1) & 1)) Bnx = Bc;
                         }
                         if (STORE) item_part(An, I, ps);
                         // the loader's address arithmetic + four 16-byte loads ride between the first group's MFMAs instead of in front of them
@@ -377,7 +394,72 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
-                if (storer) {
+                // WT == 1: 2 local positions x (2 x 2 tiles x 3 MFMAs); acc[lp * 2 + tn][tm].  A of the next position is double buffered, its B
+                // fragments roll into B0 / B1 as soon as the six MFMAs that read them have been issued
+                auto body2 = [&](auto store_tag, auto load_tag) {
+                    constexpr bool STORE = decltype(store_tag)::value;
+                    constexpr bool LOAD = decltype(load_tag)::value;
+                    auto ldBt = [&](BF& F, int ps, int tn) {
+                        const unsigned char* b = Bb + ps * B_PLANE;
+                        F.h = *reinterpret_cast<const bf16x8*>(b + boff2[tn]);
+                        F.l = *reinterpret_cast<const bf16x8*>(b + (boff2[tn] ^ 32));
+                    };
+                    auto mfma6 = [&](const AF& A, const BF& B, f32x16 (&c)[2]) {
+                        c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[0], B.h, c[0], 0, 0, 0);
+                        c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[1], B.h, c[1], 0, 0, 0);
+                        c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[0], B.l, c[0], 0, 0, 0);
+                        c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[1], B.l, c[1], 0, 0, 0);
+                        c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[0], B.h, c[0], 0, 0, 0);
+                        c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[1], B.h, c[1], 0, 0, 0);
+                    };
+                    AF A0, A1;
+                    BF B0, B1;
+                    const int p0 = pp * 2;
+                    ldBt(B0, p0, 0);
+                    ldA(A0, p0);
+                    ldBt(B1, p0, 1);
+                    if (STORE) item_prep(I, lane, c_n, par_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+                        if (ts < 2) glds_stage(Bn, u_stage(ts + 1, chunk), cur.n0);
+                        else glds_stage(Bn, u_stage(0, c_n), Tn.n0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int lp = 0; lp < 2; ++lp) {
+                        AF& Ac = lp ? A1 : A0;
+                        if (lp == 0) ldA(A1, p0 + 1);
+                        if (STORE) {                                   // the four position planes of the item over the two halves
+                            item_part(An, I, 2 * lp);
+                            item_part(An, I, 2 * lp + 1);
+                        }
+                        if (LOAD && lp == 0) item_load(l_in ? cur : nxt, ((ts + 1) % 3) * 192 + lslot * 64 + lane, lc, I);
+                        mfma6(Ac, B0, acc[lp * 2 + 0]);
+                        if (lp == 0) ldBt(B0, p0 + 1, 0);
+                        mfma6(Ac, B1, acc[lp * 2 + 1]);
+                        if (lp == 0) ldBt(B1, p0 + 1, 1);
+                        if (STORE) {
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x306, 9, 0);      // then up to 9 VALU / SALU / DS
+                            }
+                        }
+                        if (LOAD && lp == 0) {
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x126, 12, 0);     // then up to 12 VALU / SALU / VMEM-read / DS-read
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                if (WT) {
+                    if (storer) body2(std::true_type{}, std::false_type{});
+                    else if (loader) body2(std::false_type{}, std::true_type{});
+                    else body2(std::false_type{}, std::false_type{});
+                } else if (storer) {
                     body(std::true_type{}, std::false_type{});
                 } else if (loader) {
                     body(std::false_type{}, std::true_type{});
@@ -391,6 +473,108 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
             ++cg;
         }
 
+        // ---- epilogue of the tile (WT == 1): exchange one position with the partner wave, then bias, activation, statistics, NHWC stores of
+        // this wave's column parity ----
+        if (WT) {
+            // the buffers of the finished tile's last chunk / last stage are free (the next tile's first chunk and first U stage sit in the
+            // other parities): 4 slots of 16 KB, two in the free A buffer, two in the free B buffer; slot = (wm, wn), shared by the pair
+            const int slot = wm * 2 + wn;
+            f32x4* xs = reinterpret_cast<f32x4*>((slot < 2 ? sA + ((cg + 1) & 1) * A_BYTES : sB + ((sg + 1) & 1) * B_BYTES) + (slot & 1) * 16384);
+            if (pp == 0) {                                            // M1 = local position 1
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            xs[((tn * 2 + tm) * 4 + g) * 64 + lane] = f32x4{acc[2 + tn][tm][4 * g], acc[2 + tn][tm][4 * g + 1],
+                                                                            acc[2 + tn][tm][4 * g + 2], acc[2 + tn][tm][4 * g + 3]};
+            }
+            __syncthreads();
+            if (pp == 1) {                                            // out[2j+1] = (M1 - M2) - M3, then send M2 = local position 0
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 m1 = xs[((tn * 2 + tm) * 4 + g) * 64 + lane];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                acc[2 + tn][tm][4 * g + i] = (m1[i] - acc[tn][tm][4 * g + i]) - acc[2 + tn][tm][4 * g + i];
+                            xs[((tn * 2 + tm) * 4 + g) * 64 + lane] = f32x4{acc[tn][tm][4 * g], acc[tn][tm][4 * g + 1], acc[tn][tm][4 * g + 2],
+                                                                            acc[tn][tm][4 * g + 3]};
+                        }
+            }
+            __syncthreads();
+            if (pp == 0) {                                            // out[2j] = (M0 + M1) + M2
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 m2 = xs[((tn * 2 + tm) * 4 + g) * 64 + lane];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                acc[tn][tm][4 * g + i] = (acc[tn][tm][4 * g + i] + acc[2 + tn][tm][4 * g + i]) + m2[i];
+                        }
+            }
+            const bool raw = ksplit > 1;
+            const float gain = (p.act == 1) ? p.gain : 1.f;
+            const bool do_act = p.act != 0 && !raw;
+            const bool stats = p.stats_ws != nullptr && !raw;
+            float* yb = (raw ? p.splitk_ws + (size_t)cur.ks * ((size_t)p.B * p.Ho * p.Wo * p.Cout) : p.y) + (size_t)cur.tb * p.Ho * p.Wo * p.Cout;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int co = cur.n0 + wn * 64 + tn * 32 + li;
+                const float bsv = (p.bias && !raw) ? p.bias[co] : 0.f;
+                const float slp = (p.act == 2) ? p.slope[co] : p.alpha;
+                double st_s = 0.0, st_q = 0.0;
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float y0[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float a = (pp == 0 ? acc[tn][tm][4 * g + i] : acc[2 + tn][tm][4 * g + i]) + bsv;
+                            if (do_act) a = (a > 0.f ? a : a * slp) * gain;
+                            y0[i] = a;
+                            if (stats) {
+                                st_s += (double)a;
+                                st_q += (double)a * (double)a;
+                            }
+                        }
+                        quad_transpose4(y0[0], y0[1], y0[2], y0[3], li);
+                        const int m = wm * 64 + tm * 32 + (li & 3) + 8 * g + 4 * kh;
+                        const int oy = cur.ty0 + (m >> 3), ox = cur.tx0 + 2 * (m & 7) + pp;
+                        *reinterpret_cast<f32x4*>(yb + ((size_t)oy * p.Wo + ox) * p.Cout + (co - (li & 3))) = f32x4{y0[0], y0[1], y0[2], y0[3]};
+                    }
+                }
+                if (stats) {
+                    st_s += __shfl_xor(st_s, 32, 64);
+                    st_q += __shfl_xor(st_q, 32, 64);
+                    if (kh == 0) {
+                        const int col = wn * 64 + tn * 32 + li;
+                        s_st[((pp * 2 + wm) * BN + col) * 2] = st_s;
+                        s_st[((pp * 2 + wm) * BN + col) * 2 + 1] = st_q;
+                    }
+                }
+            }
+            if (stats) {
+                __syncthreads();
+                if (tid < BN) {
+                    // fixed order: (even columns, odd columns) of the upper rows, then of the lower rows
+                    const double a = ((s_st[tid * 2] + s_st[(2 * BN + tid) * 2]) + s_st[(BN + tid) * 2]) + s_st[(3 * BN + tid) * 2];
+                    const double q = ((s_st[tid * 2 + 1] + s_st[(2 * BN + tid) * 2 + 1]) + s_st[(BN + tid) * 2 + 1]) + s_st[(3 * BN + tid) * 2 + 1];
+                    double* slot2 = p.stats_ws + (((size_t)cur.tb * p.Cout + cur.n0 + tid) * p.stats_slots + cur.slot) * 2;
+                    slot2[0] = a;
+                    slot2[1] = q;
+                }
+            }
+            // (the exchange slots are rewritten by the next tile's staging only after its first stage barrier; s_st a whole tile later)
+        } else
         // ---- epilogue of the tile: output transform in registers, bias, activation, statistics, NHWC stores ----
         {
             const int co = cur.n0 + wn * 32 + li;
@@ -542,7 +726,7 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
     const int64_t grid = tiles < ncu ? tiles : ncu;                               // persistent: one block per CU
 #ifdef E4S_ABLATIONS
     {
-        static std::atomic<uint64_t> mv[9];
+        static std::atomic<uint64_t> mv[11];
         const char* ev = getenv("E4S_WINO_VAR");
         const int var = ev ? atoi(ev) : 0;
         const void* fn = nullptr;
@@ -550,13 +734,28 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
               hipLaunchKernelGGL((conv_wino_kernel<0, V>), dim3((unsigned)grid), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img, (int)tiles, ksplit, cper); \
               E4S_CHECK_LAUNCH(); return 0;
         switch (p.in_stats ? 0 : var) {
-            WV(1) WV(2) WV(3) WV(4) WV(5) WV(6) WV(7) WV(8)
+            WV(1) WV(2) WV(3) WV(4) WV(5) WV(6) WV(7) WV(8) WV(9) WV(10)
             default: break;
         }
 #undef WV
     }
 #endif
-    if (p.in_stats) {
+    // wave tile (see the kernel): 64 x 64 x two positions where a tile has enough K stages to pay for the exchange in its epilogue
+    static const int wt_env = [] { const char* v = getenv("E4S_WINO_WT"); return v ? atoi(v) : -1; }();
+    const bool wt = wt_env >= 0 ? wt_env != 0 : (p.Cin / KC) / (ksplit > 0 ? ksplit : 1) >= WT_MIN_CHUNKS;
+    if (wt) {
+        static std::atomic<uint64_t> w0{0}, w2{0};
+        if (p.in_stats) {
+            if (p.Cin > 1024) return (int)hipErrorInvalidValue;
+            if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<2, 0, 1>, SMEM_WINO + 16384, w2))) return e;
+            hipLaunchKernelGGL((conv_wino_kernel<2, 0, 1>), dim3((unsigned)grid), dim3(NTHR), SMEM_WINO + p.Cin * 16, as_stream(stream), p, ntn,
+                               tx_n, per_img, (int)tiles, ksplit, cper);
+        } else {
+            if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<0, 0, 1>, SMEM_WINO, w0))) return e;
+            hipLaunchKernelGGL((conv_wino_kernel<0, 0, 1>), dim3((unsigned)grid), dim3(NTHR), SMEM_WINO, as_stream(stream), p, ntn, tx_n, per_img,
+                               (int)tiles, ksplit, cper);
+        }
+    } else if (p.in_stats) {
         if (p.Cin > 1024) return (int)hipErrorInvalidValue;                    // the two {mean, rstd} tables have 16 KB of LDS
         if ((e = e4s_ensure_dyn_smem((const void*)conv_wino_kernel<2>, SMEM_WINO + 16384, m2))) return e;
         hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)grid), dim3(NTHR), SMEM_WINO + p.Cin * 16, as_stream(stream), p, ntn, tx_n,

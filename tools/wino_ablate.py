@@ -21,9 +21,11 @@ if len(sys.argv) > 1:
     e1.record(); torch.cuda.synchronize()
     print("MS %.4f" % (e0.elapsed_time(e1) / 30))
 else:
-    names = {0: "full", 1: "no input-transform staging", 2: "no weight staging", 3: "no staging", 4: "MFMAs + barriers", 5: "MFMAs only", 6: "no MFMAs", 7: "items loaded, not transformed", 8: "items transformed, not loaded"}
+    names = {0: "full", 1: "no input-transform staging", 2: "no weight staging", 3: "no staging", 4: "MFMAs + barriers", 5: "MFMAs only", 6: "no MFMAs", 7: "items loaded, not transformed", 8: "items transformed, not loaded",
+             9: "A fragments of odd positions not re-read (16 of 24 reads: a 64x64x2-position wave tile's traffic)",
+             10: "A and B fragments of odd positions not re-read (12 of 24 reads)"}
     res = {}
-    for v in range(9):
+    for v in range(11):
         env = dict(os.environ, E4S_WINO_VAR=str(v))
         out = subprocess.run([sys.executable, __file__, "run"], env=env, capture_output=True, text=True).stdout
         ms = [l for l in out.splitlines() if l.startswith("MS ")]
