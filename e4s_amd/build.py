@@ -20,7 +20,8 @@ def sources():
 def _extra_flags():
     """E4S_BUILD_ABLATIONS=1: profiling build whose conv kernels honour E4S_BF16X3_ABL / E4S_UPCONV_ABL (ablated
     variants compute wrong results by construction; never enabled in a product build)."""
-    return ["-DE4S_ABLATIONS"] if os.environ.get("E4S_BUILD_ABLATIONS") == "1" else []
+    flags = ["-DE4S_ABLATIONS"] if os.environ.get("E4S_BUILD_ABLATIONS") == "1" else []
+    return flags + os.environ.get("E4S_EXTRA_CFLAGS", "").split()          # A/B builds (with E4S_BUILD_OUT): e.g. -DE4S_WINO_READS_FIRST=0
 
 
 def _digest():

@@ -45,7 +45,14 @@ constexpr int VROWS = (TH + 2) * NPAIR;          // 144 V-pixels per position an
 constexpr int BN = 128, KC = 16, ROWB = 64;
 constexpr int A_PLANE = VROWS * ROWB, A_BYTES = 4 * A_PLANE;        // 36 864
 constexpr int B_PLANE = BN * ROWB, B_BYTES = 4 * B_PLANE;           // 32 768
-constexpr int WT_MIN_CHUNKS = 8;                                     // wave tile 1 (64 x 64 x 2 positions) from this many 16-channel chunks per block on
+#ifndef E4S_WINO_READS_FIRST
+#define E4S_WINO_READS_FIRST 1
+#endif
+// wave tile 1 (64 x 64 x 2 positions) from this many 16-channel chunks per block on.  Measured (profiles/r05_wino_wave_tile.json, same-box
+// alternation): 512 -> 512 @32^2 -2 % (six pairs of six), 256 -> 256 @64^2 -2.6 %, the K = 128 / 64 layers +2 ... +4 % (the exchange in the
+// epilogue is per tile): the 512-channel layers only.  The 33 % fewer fragment reads it was built for bought far less than the ablation that
+// motivated it (-11 % with a third of the reads skipped): that gain was the shorter dependency chain of the ablated variant, not LDS bandwidth.
+constexpr int WT_MIN_CHUNKS = 32;
 constexpr int NITEMS = VROWS * 4;                                   // 576 (V-pixel, 4-channel group) items per chunk
 constexpr int SMEM_WINO = 2 * A_BYTES + 2 * B_BYTES + 4 * BN * 2 * 8;       // + Cin * 16 bytes of {mean, rstd} tables when XF == 2 (launcher)
 
@@ -375,6 +382,10 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                         } else {
                             asm volatile("" ::"v"(Ac.h[0]), "v"(Ac.l[0]), "v"(Ac.h[1]), "v"(Ac.l[1]), "v"(Bc.h), "v"(Bc.l));
                         }
+                        // the NEXT step's fragment reads are issued before this step's MFMAs (round 5: left to itself hipcc sank them behind
+                        // five of the six MFMAs and then waited lgkmcnt(0) with ONE MFMA of cover -- ISA of the plain body)
+                        if (E4S_WINO_READS_FIRST && ps + 1 < 4 && VAR == 0) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                        if (E4S_WINO_READS_FIRST && !STORE && !(LOAD && ps == 0) && VAR == 0) __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
                         if (STORE) {
                             // this position's transform + split + stores (~40 VALU, 2 DS writes) and the next group's 6 fragment reads go
                             // between the six MFMAs
@@ -394,8 +405,9 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
-                // WT == 1: 2 local positions x (2 x 2 tiles x 3 MFMAs); acc[lp * 2 + tn][tm].  A of the next position is double buffered, its B
-                // fragments roll into B0 / B1 as soon as the six MFMAs that read them have been issued
+                // WT == 1: four steps (lp, tn) of six MFMAs, acc[lp * 2 + tn][tm] -- the pipeline of `body` (the fragments of step k + 1 are
+                // read into the OTHER buffer before the MFMAs of step k are issued), with the A fragments of a position read once for both
+                // channel tiles: 2 x 4 A reads + 4 x 2 B reads = 16 per stage
                 auto body2 = [&](auto store_tag, auto load_tag) {
                     constexpr bool STORE = decltype(store_tag)::value;
                     constexpr bool LOAD = decltype(load_tag)::value;
@@ -404,20 +416,11 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                         F.h = *reinterpret_cast<const bf16x8*>(b + boff2[tn]);
                         F.l = *reinterpret_cast<const bf16x8*>(b + (boff2[tn] ^ 32));
                     };
-                    auto mfma6 = [&](const AF& A, const BF& B, f32x16 (&c)[2]) {
-                        c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[0], B.h, c[0], 0, 0, 0);
-                        c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[1], B.h, c[1], 0, 0, 0);
-                        c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[0], B.l, c[0], 0, 0, 0);
-                        c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[1], B.l, c[1], 0, 0, 0);
-                        c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[0], B.h, c[0], 0, 0, 0);
-                        c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[1], B.h, c[1], 0, 0, 0);
-                    };
                     AF A0, A1;
                     BF B0, B1;
                     const int p0 = pp * 2;
                     ldBt(B0, p0, 0);
                     ldA(A0, p0);
-                    ldBt(B1, p0, 1);
                     if (STORE) item_prep(I, lane, c_n, par_n);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) {
@@ -426,26 +429,33 @@ __global__ __launch_bounds__(NTHR) void conv_wino_kernel(const e4s_conv_params p
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int lp = 0; lp < 2; ++lp) {
+                    for (int k = 0; k < 4; ++k) {
+                        const int lp = k >> 1, tn = k & 1;
                         AF& Ac = lp ? A1 : A0;
-                        if (lp == 0) ldA(A1, p0 + 1);
-                        if (STORE) {                                   // the four position planes of the item over the two halves
-                            item_part(An, I, 2 * lp);
-                            item_part(An, I, 2 * lp + 1);
-                        }
-                        if (LOAD && lp == 0) item_load(l_in ? cur : nxt, ((ts + 1) % 3) * 192 + lslot * 64 + lane, lc, I);
-                        mfma6(Ac, B0, acc[lp * 2 + 0]);
-                        if (lp == 0) ldBt(B0, p0 + 1, 0);
-                        mfma6(Ac, B1, acc[lp * 2 + 1]);
-                        if (lp == 0) ldBt(B1, p0 + 1, 1);
+                        BF& Bc = (k & 1) ? B1 : B0;
+                        BF& Bnx = (k & 1) ? B0 : B1;
+                        if (k + 1 < 4) ldBt(Bnx, p0 + ((k + 1) >> 1), (k + 1) & 1);
+                        if (k == 0) ldA(A1, p0 + 1);
+                        if (STORE) item_part(An, I, k);
+                        if (LOAD && k == 0) item_load(l_in ? cur : nxt, ((ts + 1) % 3) * 192 + lslot * 64 + lane, lc, I);
+                        f32x16(&c)[2] = acc[lp * 2 + tn];
+                        c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[0], Bc.h, c[0], 0, 0, 0);
+                        c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[1], Bc.h, c[1], 0, 0, 0);
+                        c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[0], Bc.l, c[0], 0, 0, 0);
+                        c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[1], Bc.l, c[1], 0, 0, 0);
+                        c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[0], Bc.h, c[0], 0, 0, 0);
+                        c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[1], Bc.h, c[1], 0, 0, 0);
+                        if (E4S_WINO_READS_FIRST && k == 0) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                        if (E4S_WINO_READS_FIRST && (k == 1 || k == 2)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        if (E4S_WINO_READS_FIRST && !STORE && !(LOAD && k == 0)) __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
                         if (STORE) {
 #pragma unroll
-                            for (int i = 0; i < 12; ++i) {
+                            for (int i = 0; i < 6; ++i) {
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
                                 __builtin_amdgcn_sched_group_barrier(0x306, 9, 0);      // then up to 9 VALU / SALU / DS
                             }
                         }
-                        if (LOAD && lp == 0) {
+                        if (LOAD && k == 0) {
 #pragma unroll
                             for (int i = 0; i < 6; ++i) {
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
@@ -741,8 +751,9 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
     }
 #endif
     // wave tile (see the kernel): 64 x 64 x two positions where a tile has enough K stages to pay for the exchange in its epilogue
-    static const int wt_env = [] { const char* v = getenv("E4S_WINO_WT"); return v ? atoi(v) : -1; }();
-    const bool wt = wt_env >= 0 ? wt_env != 0 : (p.Cin / KC) / (ksplit > 0 ? ksplit : 1) >= WT_MIN_CHUNKS;
+    // (E4S_WINO_WT = 0 / 1 forces one of them: read per launch, so that a test can run both in one process)
+    const char* wt_env = getenv("E4S_WINO_WT");
+    const bool wt = wt_env ? atoi(wt_env) != 0 : (p.Cin / KC) / (ksplit > 0 ? ksplit : 1) >= WT_MIN_CHUNKS;
     if (wt) {
         static std::atomic<uint64_t> w0{0}, w2{0};
         if (p.in_stats) {

@@ -1330,13 +1330,17 @@ def test_f32_conv_split_k_small_maps(cin, cout, h, w, stride):
                                                  (2, 16, 16, 96, 128, "bias_lrelu"),
                                                  # more tiles than CUs: the persistent blocks walk 2-3 tiles each, across samples
                                                  (3, 256, 256, 64, 128, "in_prelu"), (5, 128, 128, 128, 128, "stats"), (9, 96, 96, 32, 256, "plain")])
-def test_winograd_f23_conv_vs_fp64(b, h, w, cin, cout, mode):
-    """e4s_conv_wino_bf16x3_f32 (Winograd F(2,3) along the rows, split-bf16 MFMAs) vs F.conv2d in fp64 on the same operands: plain,
+@pytest.mark.parametrize("wave_tile", [0, 1])
+def test_winograd_f23_conv_vs_fp64(b, h, w, cin, cout, mode, wave_tile, monkeypatch):
+    """wave_tile: both forms of the kernel on every shape (0: a wave owns 64 x 32 of all four positions; 1, round 5: 64 x 64 of two positions,
+    one position exchanged between the waves of a pair in the epilogue -- the policy picks it for the 512-channel layers only).
+    e4s_conv_wino_bf16x3_f32 (Winograd F(2,3) along the rows, split-bf16 MFMAs) vs F.conv2d in fp64 on the same operands: plain,
     with the InstanceNorm folded into the input transform + PReLU epilogue (the encoder unit's first conv, helpers.py:128-133), with the
     fused output statistics + SE gate (its second conv), with bias + leaky ReLU (the loss networks' convs).  Bound 3e-5 of the output
     scale (measured ~8e-6: 1.7x the direct split-bf16 kernel), statistics 2e-6 relative; bit-reproducible."""
     import torch.nn.functional as F
     from e4s_amd import kernels as K
+    monkeypatch.setenv("E4S_WINO_WT", str(wave_tile))
     g = torch.Generator().manual_seed(h * 7 + cin)
     x = torch.randn(b, cin, h, w, generator=g) * 1.3 + 0.4
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
