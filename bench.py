@@ -380,6 +380,9 @@ def build_parser():
     ap.add_argument("--no-graph", action="store_true", help="enqueue the ~700 launches per step eagerly instead of "
                                                             "replaying one captured HIP graph")
     ap.add_argument("--train-only", action="store_true", help="run only the configs[4] train-step legs")
+    ap.add_argument("--train-legs", default="full,frozen,mse", help="with --train-only: which legs (full = train_G + train_D, the reference's "
+                                                                    "default; frozen = G frozen; mse = l2 only, no D)")
+    ap.add_argument("--train-g-only", action="store_true", help="with --train-only: skip the D / R1 step timings (clean G-step profiles)")
     ap.add_argument("--opt-modes", default="full,mse",
                     help="config-3 legs to run: full = l2 + LPIPS x3 + ID + parsing, mse = l2 only")
     ap.add_argument("--opt-eager", dest="opt_graph", action="store_false",
@@ -468,10 +471,11 @@ def main():
         print(json.dumps(headline_probe(net, B, inputs[4], args.probe_reps)))
         return
     if args.train_only:
-        print(json.dumps({"config5_train_step_1gpu": train_leg(dev, lat, args.train_steps, losses="full"),
-                          "config5_train_step_1gpu_G_frozen": train_leg(dev, lat, args.train_steps, losses="full", train_G=False,
-                                                                        time_d=False),
-                          "config5_train_step_1gpu_mse_only": train_leg(dev, lat, args.train_steps, losses="mse", train_G=False)}))
+        legs = {"full": ("config5_train_step_1gpu", lambda: train_leg(dev, lat, args.train_steps, losses="full", time_d=not args.train_g_only)),
+                "frozen": ("config5_train_step_1gpu_G_frozen", lambda: train_leg(dev, lat, args.train_steps, losses="full", train_G=False,
+                                                                                 time_d=False)),
+                "mse": ("config5_train_step_1gpu_mse_only", lambda: train_leg(dev, lat, args.train_steps, losses="mse", train_G=False))}
+        print(json.dumps({legs[k][0]: legs[k][1]() for k in args.train_legs.split(",") if k in legs}))
         return
     if args.opt_only:
         one = [t[:1].contiguous() if torch.is_tensor(t) else [n[:1].contiguous() for n in t] for t in inputs]
