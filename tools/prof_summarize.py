@@ -57,9 +57,15 @@ def replay(path, out_json=None):
     rows.sort()
     names = [(r[2], r[3]) for r in rows]
     n = None
-    for cand in range(40, len(names) // 2 + 1):
-        if names[-cand:] == names[-2 * cand:-cand]:
-            n = cand
+    for skip in range(0, 40):                         # a few dispatches may follow the last replay (flag reset, validation)
+        tail_names = names[:len(names) - skip] if skip else names
+        for cand in range(40, len(tail_names) // 2 + 1):
+            if tail_names[-cand:] == tail_names[-2 * cand:-cand]:
+                n = cand
+                break
+        if n is not None:
+            if skip:
+                rows, names = rows[:len(rows) - skip], tail_names
             break
     if n is None:
         raise SystemExit("no periodic tail found: is this a graph-replay trace?")
