@@ -15,12 +15,20 @@
 //     channels = 64 KB of LDS, from which the FIR epilogue produces the 12 x 28 output pixels whose 4x4 windows lie inside
 //     (the anchors overlap by 2 between tiles: 1.52x the MACs -- still 2.6x fewer than the polyphase form).
 //     out = act(d[b,co] * sum_j kflip[j] I[o + j - 1] + noise_w * noise[b,o] + bias[co]) * gain.
-// (3) Persistent blocks, 8 waves: wave (wm, wn) owns anchor rows [32 wm, 32 wm + 32) and classes {2 wn, 2 wn + 1}; waves w and
-//     w + 4 share a SIMD and take different wn, so every SIMD carries 9 blocks although the classes have 4 / 2 / 2 / 1 taps.
-//     One pipeline stage = one 32-channel chunk (all 9 blocks); halos are fetched into registers two stages ahead, weights one
-//     (or the next tile's first); the I tile aliases the weight buffers, so the weights prefetched for the next tile are parked
-//     in registers across the epilogue.
-// Weights arrive pre-packed and pre-split by e4s_subpixel_weights_f32: [Cin/32][Cout/32][9 blocks][32 co][32 hi | 32 lo bf16].
+// (3) TWO persistent 256-thread blocks per CU (round 5, VERDICT r4 'next' 3).  The round-3 form was one 512-thread block per CU with
+//     128 KB of LDS whose phases ran back to back -- the K stages, the accumulator -> I-tile write, the FIR pass, the re-staging of the
+//     weights the I tile had overwritten -- and its ablations put the epilogue at 41 % of the launch with the matrix pipe idle and the
+//     main loop at 59 % with the VALU and the store path idle (profiles/r03_ablations_conv_c32_upconv.json); nothing inside one block
+//     overlaps them without a second I tile, which the LDS does not have.  Here a block is 74 KB: 16-channel K stages (A 2 x 12 KB,
+//     B 2 x 23 KB), the I tile aliased over ALL stage buffers (the next tile's first stage waits in registers through the FIR pass),
+//     four waves of 32 anchors x all four classes (9 blocks = 27 MFMAs per stage each: no class imbalance to hide).  A CU holds two
+//     independent blocks at different points of their tiles and the hardware overlaps one block's FIR / stores with the other's MFMA
+//     stages: 0.88 -> 0.77 ms (64 -> 32 into 1024^2) and 0.69 -> 0.60 ms (128 -> 64 into 512^2) on the same box; one such block per
+//     CU alone runs 1.07 ms (profiles/r05_upconv_two_blocks.json).  A start skew between the two blocks changes nothing (measured).
+// (4) The FIR as a 4-tap row pass + a 4-tap column pass when the blur kernel is an outer product (the reference's always is): 8
+//     multiply-adds per output instead of 16, 0.77 -> 0.71 / 0.60 -> 0.57 ms.
+// Weights arrive pre-packed and pre-split by e4s_subpixel_weights_f32: [Cin/32][Cout/32][9 blocks][32 co][32 hi | 32 lo bf16]; a stage
+// takes one 16-channel half of a row.
 #include "common.h"
 #include <stdlib.h>
 
@@ -29,24 +37,28 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-constexpr int KC = 32, ROWB = 144, LO = 64;
+constexpr int PKC = 32;                                    // input channels per chunk of the weight PACK (a K stage takes half a chunk)
+constexpr int KC = 16, ROWB = 80, LO = 32;                 // LDS rows: [16 hi | 16 lo | 16 bytes of padding] (80 = 16 x 5: conflict free)
 constexpr int TAH = 8, TAW = 16;                           // anchors per tile (GEMM rows: 128)
 constexpr int HH = TAH + 1, HW = TAW + 1, HALO = HH * HW;  // 9 x 17 input pixels: anchors and their (-1,-1) neighbours
 constexpr int OH = 2 * TAH - 4, OW = 2 * TAW - 4;          // 12 x 28 outputs per tile
 constexpr int IQH = 2 * TAH, IQW = 2 * TAW;                // 16 x 32 positions of I
 constexpr int BNC = 32;                                    // output channels per tile
-constexpr int NTHR = 512, NBLK = 9;
-constexpr int ITEMS = HALO * 4;                            // (halo pixel, 8-channel group) items of one chunk = 612
+constexpr int NTHR = 256, NBLK = 9;
+constexpr int ITEMS = HALO * 2;                            // (halo pixel, 8-channel group) items of one stage = 306
 constexpr int AJ = (ITEMS + NTHR - 1) / NTHR;              // 2
-constexpr int BPIECES = NBLK * BNC * 8;                    // 16-byte weight pieces of one chunk = 2304
+constexpr int BPIECES = NBLK * BNC * 4;                    // 16-byte weight pieces of one stage = 1152
 constexpr int BJ = (BPIECES + NTHR - 1) / NTHR;            // 5
-constexpr int A_BYTES = HALO * ROWB;                       // 22 032
-constexpr int B_BYTES = NBLK * BNC * ROWB;                 // 41 472
+constexpr int A_BYTES = HALO * ROWB;                       // 12 240
+constexpr int B_BYTES = NBLK * BNC * ROWB;                 // 23 040
+constexpr int STAGE_BYTES = 2 * A_BYTES + 2 * B_BYTES;     // 70 560
 constexpr int I_BYTES = IQH * IQW * BNC * 4;               // 65 536
-constexpr int SMEM = 2 * A_BYTES + 2 * B_BYTES + OH * OW * 4;
-static_assert(I_BYTES <= 2 * B_BYTES, "the I tile aliases the two weight buffers");
-static_assert(SMEM <= 160 * 1024, "LDS budget");
-static_assert(8 * OW * 2 <= NTHR, "FIR epilogue thread layout");
+constexpr int NZ = OH * OW;                                // 336
+constexpr int MAXC = 512;                                  // in_scale rows of the current and the next tile's sample live in LDS
+constexpr int SMEM = STAGE_BYTES + NZ * 4 + 2 * MAXC * 4;  // 76 000: two blocks per CU
+static_assert(I_BYTES <= STAGE_BYTES, "the I tile aliases the stage buffers");
+static_assert(2 * SMEM <= 160 * 1024, "two blocks per CU");
+static_assert(8 * OW <= NTHR && NZ <= 2 * NTHR, "epilogue thread layout");
 
 __device__ __forceinline__ void split_store(unsigned char* dst, const f32x8 v) {
     const bf16x8 h = __builtin_convertvector(v, bf16x8);
@@ -66,23 +78,29 @@ struct TileId { int tb, ty, tx, nt; };
 
 // XF: 0 none, 1 v * in_scale[b][c] while the halo is staged (one style per sample: unmasked StyledConv, model.py:655-657)
 template <int XF>
-__global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_params p, const float* __restrict__ k4, const int ntn,
-                                                            const int tx_n, const int per_img, const int ntiles, const int abl) {
-    // abl (profiling builds only, -DE4S_ABLATIONS + env E4S_UPCONV3_ABL; results WRONG): 1 no MFMA stages, 2 no FIR / output
-    // stores, 3 no epilogue at all, 4 no global loads, 5 no LDS staging of the prefetched operands
+__global__ __launch_bounds__(NTHR, 2) void upconv_fused_kernel(const e4s_conv_params p, const float* __restrict__ k4, const int ntn,
+                                                           const int tx_n, const int per_img, const int ntiles, const int abl_arg) {
+    // abl (profiling builds only, -DE4S_ABLATIONS + env E4S_UPCONV3_ABL; results WRONG): 1 no MFMA stages, 2 no FIR / output stores,
+    // 3 no epilogue at all, 4 no global loads, 5 no LDS staging of the prefetched operands, 6 FIR without the output stores,
+    // 7 FIR without the accumulator -> I-tile write
+#ifdef E4S_ABLATIONS
+    const int abl = abl_arg;
+#else
+    constexpr int abl = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                          // [2][HALO][ROWB]
     unsigned char* sB = smem + 2 * A_BYTES;            // [2][9][32][ROWB]
-    float* sI = reinterpret_cast<float*>(sB);          // [IQH][IQW][BNC]  (epilogue; aliases both weight buffers)
-    float* s_nz = reinterpret_cast<float*>(sB + 2 * B_BYTES);          // [OH*OW] noise_w * noise of the tile's output pixels
+    float* sI = reinterpret_cast<float*>(smem);        // [IQH][IQW][BNC]  (epilogue; aliases every stage buffer)
+    float* s_nz = reinterpret_cast<float*>(smem + STAGE_BYTES);          // [OH*OW] noise_w * noise of the tile's output pixels
+    float* s_sty = s_nz + NZ;                                            // XF: [2 tile parities][MAXC] in_scale row of the tile's sample
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the class schedule branches on it
+    const int lane = tid & 63, wm = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
-    const int wm = wave & 3, wn = wave >> 2;
     const int G = gridDim.x;
     const int first = xcd_remap(blockIdx.x, G);
-    const int nchunk = p.Cin / KC;
+    const int nchunk = p.Cin / KC;                     // even (Cin % 32 == 0)
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(p.w);
     const size_t img_stride = (size_t)p.Hi * p.Wi * p.Cin;
 
@@ -96,24 +114,25 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
         id.tx = rem - id.ty * tx_n;
         return id;
     };
-    // halo item -> global offset inside the sample (floats), LDS byte offset; halo pixel (hy, hx) = input (6 ty - 2 + hy, 14 tx - 2 + hx)
+    // halo item -> global offset inside the sample (floats); halo pixel (hy, hx) = input (6 ty - 2 + hy, 14 tx - 2 + hx)
     auto item_src = [&](const TileId& id, int item, bool& ok) -> size_t {
-        const int h = item >> 2, q = item & 3;
+        const int h = item >> 1, q = item & 1;
         const int hy = h / HW, hx = h - hy * HW;
         const int iy = id.ty * (OH / 2) - 2 + hy, ix = id.tx * (OW / 2) - 2 + hx;
         ok = item < ITEMS && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         return ok ? ((size_t)iy * p.Wi + ix) * p.Cin + q * 8 : (size_t)(q * 8);
     };
-    auto item_dst = [&](int item) -> int { return (item >> 2) * ROWB + (item & 3) * 16; };
+    auto item_dst = [&](int item) -> int { return (item >> 1) * ROWB + (item & 1) * 16; };
     const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // weights of (chunk, nt): 9 blocks x 32 rows x 128 bytes, contiguous; piece i -> LDS row i/8, 16-byte column i%8
-    auto b_src = [&](int i, int chunk, int nt) -> size_t {
-        return ((size_t)chunk * ntn + nt) * (NBLK * BNC * 128) + (size_t)i * 16;
+    // weights of (16-channel chunk c, nt): rows of 128 bytes [32 hi | 32 lo] in the 32-channel pack; piece i -> LDS row i / 4, 16-byte
+    // slot i % 4 (hi 0, hi 1, lo 0, lo 1) = bytes (c & 1) * 32 + (i & 1) * 16 of the row's hi (i & 2 == 0) or lo half
+    auto b_src = [&](int i, int c, int nt) -> size_t {
+        return ((size_t)(c >> 1) * ntn + nt) * (NBLK * BNC * 128) + (size_t)(i >> 2) * 128 + ((i >> 1) & 1) * 64 + (c & 1) * 32 + (i & 1) * 16;
     };
-    auto b_dst = [&](int i) -> int { return (i >> 3) * ROWB + (i & 7) * 16; };
+    auto b_dst = [&](int i) -> int { return (i >> 2) * ROWB + (i & 3) * 16; };
 
     struct AReg {
-        f32x8 a[AJ], x[AJ];
+        f32x8 a[AJ];
         bool ok[AJ];
     };
     typedef f32x4 BReg[BJ];
@@ -124,8 +143,13 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
             const int item = tid + NTHR * j;
             const size_t off = item_src(id, item, R.ok[j]);
             if (abl != 4) R.a[j] = load8(xb + off);
-            if (XF) R.x[j] = load8(p.in_scale + (real ? (size_t)id.tb * p.Cin + chunk * KC : 0) + (item & 3) * 8);
         }
+    };
+    // the style row of a tile's sample -> s_sty[par] (read at store time: a prefetched halo does not carry its style through the stages)
+    auto load_style = [&](const TileId& id, int par) {
+        if (XF)
+            for (int i = tid * 4; i < p.Cin; i += NTHR * 4)
+                *reinterpret_cast<f32x4*>(s_sty + par * MAXC + i) = *reinterpret_cast<const f32x4*>(p.in_scale + (size_t)id.tb * p.Cin + i);
     };
     auto fetch_b = [&](BReg& R, const TileId& id, int chunk, bool real) {
 #pragma unroll
@@ -134,13 +158,13 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
             if (abl != 4) R[j] = *reinterpret_cast<const f32x4*>(wbytes + b_src(i < BPIECES ? i : 0, real ? chunk : 0, real ? id.nt : 0));
         }
     };
-    auto store_a = [&](const AReg& R, int buf) {
+    auto store_a = [&](const AReg& R, int buf, int chunk, int par) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int item = tid + NTHR * j;
             if (item < ITEMS) {
                 f32x8 v = R.a[j];
-                if (XF) v = v * R.x[j];
+                if (XF) v = v * load8(s_sty + par * MAXC + chunk * KC + (item & 1) * 8);
                 if (!R.ok[j]) v = zero8;                    // zero padding applies after the style scale
                 split_store(sA + buf * A_BYTES + item_dst(item), v);
             }
@@ -160,16 +184,17 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
     bool has_next = t_next < ntiles;
     TileId nxt = decode(has_next ? t_next : first);
 
-    // Pipeline over the flat sequence of (tile, chunk) stages, unrolled by two (Cin % 64 == 0: an even number of chunks per
-    // tile, so even stages always live in LDS buffers 0 and odd ones in buffers 1).  A stage's halo is FETCHED two stages
-    // ahead (register sets RE / RO for even / odd stages) and stored one stage ahead -- one MFMA phase (~0.8 us) is shorter
-    // than an HBM round trip under load, which left every wave waiting on its loads at the end of each stage; its weights
-    // (L2-resident) are fetched one stage ahead.
+    // Flat sequence of (tile, chunk) stages, unrolled by two: even stages live in LDS buffers 0, odd ones in buffers 1.  A stage's halo is
+    // fetched two stages ahead (register sets RE / RO) and stored one stage ahead, its weights (L2-resident) are fetched one stage ahead
+    // -- across the tile boundary both wait in registers until the FIR pass has released the LDS.
     AReg RE, RO;
     BReg RB;
+    int par = 0;                                       // parity of the block's tile counter: s_sty[par] is the current tile's style
     fetch_a(RE, cur, 0, true);
     fetch_b(RB, cur, 0, true);
-    store_a(RE, 0);
+    load_style(cur, 0);
+    if (XF) __syncthreads();
+    store_a(RE, 0, 0, 0);
     store_b(RB, 0);
     fetch_a(RO, cur, 1, true);
     __syncthreads();
@@ -178,63 +203,104 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
     const int m_row = wm * 32 + li;
     const int arow = ((m_row / TAW) * HW + (m_row % TAW)) * ROWB + kh * 16;
     const int brow = li * ROWB + kh * 16;
-    // FIR epilogue role: (4 output channels, output column, half of the 12 rows)
-    const int e_c4 = tid & 7, e_ox = (tid >> 3) % OW, e_half = tid / (8 * OW);
-    const bool e_act = tid < 8 * OW * 2;
+    // FIR epilogue role: 4 output channels of one output column, all 12 rows
+    const int e_c4 = tid & 7, e_ox = tid >> 3;
+    const bool e_act = e_ox < OW;
 
-    f32x16 acc[2];
+    // The blur kernel of the reference is always an outer product (make_kernel, model.py:36-44): k4 = u v^T lets the FIR run as a 4-tap
+    // row pass + a 4-tap column pass (8 multiply-adds per output instead of 16).  Checked here, once per block, on the values themselves;
+    // any other 4x4 kernel takes the generic 16-tap pass.  Flipped taps (upfirdn2d is a true convolution, upfirdn2d_kernel.cu:77):
+    // kf[ay][ax] = k4[3-ay][3-ax] = fu[ay] * fv[ax].
+    float fu[4], fv[4];
+    bool sep;
+    {
+        float kk[16], vmax = 0.f;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            kk[a] = k4[a];
+            vmax = fmaxf(vmax, fabsf(kk[a]));
+        }
+        sep = kk[0] != 0.f;
+        const float inv = sep ? 1.f / kk[0] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fu[3 - i] = kk[4 * i];
+            fv[3 - i] = kk[i] * inv;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sep = sep && fabsf(kk[4 * i + j] - fu[3 - i] * fv[3 - j]) <= 1e-6f * vmax;
+    }
+
+    f32x16 acc[4];                                      // one per class (dy, dx) = (cls >> 1, cls & 1)
     // block order in LDS / in the packed weights: class 0: shifts 0,1,2,3 -> 0..3; class 1: shifts 0,2 -> 4,5;
     // class 2: shifts 0,1 -> 6,7; class 3: shift 0 -> 8
     auto contract = [&](int buf) {
         const unsigned char* Ab = sA + buf * A_BYTES + arow;
         const unsigned char* Bb = sB + buf * B_BYTES + brow;
-        auto ldA = [&](int shift, int kk, bf16x8& h, bf16x8& l) {
-            const unsigned char* a = Ab + ((1 - (shift >> 1)) * HW + (1 - (shift & 1))) * ROWB + kk * 32;
-            h = *reinterpret_cast<const bf16x8*>(a);
-            l = *reinterpret_cast<const bf16x8*>(a + LO);
+        struct Frag { bf16x8 h, l; };
+        auto ldA = [&](int shift) -> Frag {
+            const unsigned char* a = Ab + ((1 - (shift >> 1)) * HW + (1 - (shift & 1))) * ROWB;
+            return Frag{*reinterpret_cast<const bf16x8*>(a), *reinterpret_cast<const bf16x8*>(a + LO)};
         };
-        auto mm = [&](f32x16& c, const bf16x8& ah, const bf16x8& al, int blk, int kk) {
-            const unsigned char* b = Bb + blk * (BNC * ROWB) + kk * 32;
-            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b);
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + LO);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+        auto ldB = [&](int blk) -> Frag {
+            const unsigned char* b = Bb + blk * (BNC * ROWB);
+            return Frag{*reinterpret_cast<const bf16x8*>(b), *reinterpret_cast<const bf16x8*>(b + LO)};
         };
-        if (wn == 0) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 h0, l0, h1, l1, h2, l2, h3, l3;
-                ldA(0, kk, h0, l0); ldA(1, kk, h1, l1); ldA(2, kk, h2, l2); ldA(3, kk, h3, l3);
-                mm(acc[0], h0, l0, 0, kk);
-                mm(acc[1], h0, l0, 4, kk);
-                mm(acc[0], h1, l1, 1, kk);
-                mm(acc[1], h2, l2, 5, kk);
-                mm(acc[0], h2, l2, 2, kk);
-                mm(acc[0], h3, l3, 3, kk);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 h0, l0, h1, l1;
-                ldA(0, kk, h0, l0); ldA(1, kk, h1, l1);
-                mm(acc[0], h0, l0, 6, kk);
-                mm(acc[1], h0, l0, 8, kk);
-                mm(acc[0], h1, l1, 7, kk);
-            }
+        // term-major over the targets of one A fragment: consecutive MFMAs write different accumulators
+        {
+            const Frag a0 = ldA(0), b0 = ldB(0), b4 = ldB(4), b6 = ldB(6), b8 = ldB(8);
+            const Frag a1 = ldA(1), b1 = ldB(1), b7 = ldB(7);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.l, b0.h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.l, b4.h, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.l, b6.h, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.l, b8.h, acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.l, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b4.l, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b6.l, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b8.l, acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b4.h, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b6.h, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b8.h, acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.l, b1.h, acc[0], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.l, b7.h, acc[2], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.l, acc[0], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b7.l, acc[2], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.h, acc[0], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b7.h, acc[2], 0, 0, 0);
+        }
+        {
+            const Frag a2 = ldA(2), b2 = ldB(2), b5 = ldB(5);
+            const Frag a3 = ldA(3), b3 = ldB(3);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.l, b2.h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.l, b5.h, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.h, b2.l, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.h, b5.l, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.h, b2.h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.h, b5.h, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.l, b3.h, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.h, b3.l, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.h, b3.h, acc[0], 0, 0, 0);
         }
     };
 
     for (;;) {
+        if (has_next) load_style(nxt, par ^ 1);        // first read after this tile's FIR pass: barriers away
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
         // epilogue operands of THIS tile, requested now so that their latency hides under the tile's MFMA stages
-        float nz_reg = 0.f;
-        if (tid < OH * OW && p.noise) {
-            const int oy = cur.ty * OH + tid / OW, ox = cur.tx * OW + tid % OW;
-            if (oy < p.Ho && ox < p.Wo) nz_reg = p.noise[(int64_t)cur.tb * p.noise_bstride + (int64_t)oy * p.Wo + ox];
+        float nz_reg[2] = {0.f, 0.f};
+        if (p.noise) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = tid + NTHR * j;
+                const int oy = cur.ty * OH + e / OW, ox = cur.tx * OW + e % OW;
+                if (e < NZ && oy < p.Ho && ox < p.Wo) nz_reg[j] = p.noise[(int64_t)cur.tb * p.noise_bstride + (int64_t)oy * p.Wo + ox];
+            }
         }
         f32x4 d_reg = {1.f, 1.f, 1.f, 1.f}, b_reg = {0.f, 0.f, 0.f, 0.f};
         if (e_act) {
@@ -254,7 +320,7 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
             fetch_b(RB, cur, c0 + 1, true);                  // weights of the odd stage
             if (abl != 1) contract(0);
             if (abl != 5) {
-                store_a(RO, 1);                              // halo of the odd stage, fetched during the previous odd stage
+                store_a(RO, 1, c0 + 1, par);                 // halo of the odd stage, fetched during the previous odd stage
                 store_b(RB, 1);
             }
             __syncthreads();
@@ -262,93 +328,109 @@ __global__ __launch_bounds__(NTHR) void upconv_fused_kernel(const e4s_conv_param
             fetch_a(RO, nid, co, nreal);
             fetch_b(RB, nid, ce, nreal);                     // weights of the next even stage
             if (abl != 1) contract(1);
-            if (abl != 5) store_a(RE, 0);
-            // after the tile's last stage the I tile is about to overwrite both weight buffers: the next tile's weights wait
-            // in registers until the epilogue is through
-            if (!last_pair && abl != 5) store_b(RB, 0);
+            // after the tile's last stage the I tile overwrites every stage buffer: the next tile's first stage waits in RE / RB
+            if (!last_pair && abl != 5) {
+                store_a(RE, 0, ce, par);
+                store_b(RB, 0);
+            }
             __syncthreads();
-        }
-        if (abl == 3) {
-            asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][7]));
-            if (!has_next) break;
-            store_b(RB, 0);
-            __syncthreads();
-            cur = nxt;
-            t_next += G;
-            has_next = t_next < ntiles;
-            if (has_next) nxt = decode(t_next);
-            continue;
         }
 
         // ---- epilogue (a): accumulators -> I tile; anchor (ay, ax), class (dy, dx) -> I[2 ay + dy][2 ax + dx][co] ----
-        {
-            if (tid < OH * OW) s_nz[tid] = nw_reg * nz_reg;      // noise of the tile's output pixels (outside the aliased region)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int cls = wn * 2 + c, dy = cls >> 1, dx = cls & 1;
+        for (int j = 0; j < 2; ++j)
+            if (tid + NTHR * j < NZ) s_nz[tid + NTHR * j] = nw_reg * nz_reg[j];      // (outside the aliased region)
+        if (abl == 3 || abl == 7) asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][7]), "v"(acc[2][3]), "v"(acc[3][9]));
+        if (abl != 3 && abl != 7)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    const int qy = 2 * (m / TAW) + dy, qx = 2 * (m % TAW) + dx;
-                    sI[(qy * IQW + qx) * BNC + li] = acc[c][r];
-                }
+        for (int cls = 0; cls < 4; ++cls) {
+            const int dy = cls >> 1, dx = cls & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int qy = 2 * (m / TAW) + dy, qx = 2 * (m % TAW) + dx;
+                sI[(qy * IQW + qx) * BNC + li] = acc[cls][r];
             }
         }
         __syncthreads();
         // ---- epilogue (b): FIR + demodulation + noise + bias + activation.  Output (oyl, oxl) of the tile reads I rows
         // oyl + 1 .. oyl + 4, columns oxl + 1 .. oxl + 4 (tile origin of I = 2 * (first anchor) = output origin - 2) ----
-        if (e_act && abl != 2) {
-            // flipped blur taps (upfirdn2d is a true convolution, upfirdn2d_kernel.cu:77): kf[ay*4+ax] = k4[3-ay][3-ax]; re-read per
-            // tile (one scalar load) rather than held in 16 SGPRs across the main loop
-            float kf[16];
-#pragma unroll
-            for (int a = 0; a < 16; ++a) kf[a] = k4[15 - a];
+        if (e_act && abl != 2 && abl != 3) {
             const int co0 = cur.nt * BNC + e_c4 * 4;
             const int ox = cur.tx * OW + e_ox;
-            const int oyl0 = e_half * (OH / 2);
             const f32x4 d = d_reg, bs = b_reg;
             const float gain = (p.act == 1) ? p.gain : 1.f;
             const int ycs = p.y_cstride ? p.y_cstride : p.Cout;
-            const float* ip = sI + ((oyl0 + 1) * IQW + e_ox + 1) * BNC + e_c4 * 4;
-            f32x4 win[3][4];                            // sliding window: 3 I rows carried, one new row per output
-#pragma unroll
-            for (int ry = 0; ry < 3; ++ry)
-#pragma unroll
-                for (int ax = 0; ax < 4; ++ax) win[ry][ax] = *reinterpret_cast<const f32x4*>(ip + (ry * IQW + ax) * BNC);
-#pragma unroll
-            for (int r = 0; r < OH / 2; ++r) {
-                f32x4 nw[4];
-#pragma unroll
-                for (int ax = 0; ax < 4; ++ax) nw[ax] = *reinterpret_cast<const f32x4*>(ip + ((r + 3) * IQW + ax) * BNC);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ax = 0; ax < 4; ++ax)
-                    v += win[0][ax] * kf[ax] + win[1][ax] * kf[4 + ax] + win[2][ax] * kf[8 + ax] + nw[ax] * kf[12 + ax];
-#pragma unroll
-                for (int ax = 0; ax < 4; ++ax) { win[0][ax] = win[1][ax]; win[1][ax] = win[2][ax]; win[2][ax] = nw[ax]; }
-                const int oyl = oyl0 + r, oy = cur.ty * OH + oyl;
+            const float* ip = sI + (IQW + e_ox + 1) * BNC + e_c4 * 4;
+            auto finish = [&](f32x4 v, int r) {
+                const int oy = cur.ty * OH + r;
                 if (oy < p.Ho && ox < p.Wo) {
-                    v = v * d + bs + s_nz[oyl * OW + e_ox];
+                    v = v * d + bs + s_nz[r * OW + e_ox];
                     if (p.act) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * p.alpha) * gain;
                     }
-                    *reinterpret_cast<f32x4*>(p.y + (((size_t)cur.tb * p.Ho + oy) * p.Wo + ox) * ycs + co0) = v;
+                    f32x4* dst = reinterpret_cast<f32x4*>(p.y + (((size_t)cur.tb * p.Ho + oy) * p.Wo + ox) * ycs + co0);
+                    if (abl == 6) asm volatile("" :: "v"(v));
+                    else *dst = v;
+                }
+            };
+            if (sep) {
+                // row pass on the way in (one new I row per output row), column pass over the last four row results
+                auto hrow = [&](int ry) -> f32x4 {
+                    const float* q = ip + ry * IQW * BNC;
+                    return *reinterpret_cast<const f32x4*>(q) * fv[0] + *reinterpret_cast<const f32x4*>(q + BNC) * fv[1] +
+                           *reinterpret_cast<const f32x4*>(q + 2 * BNC) * fv[2] + *reinterpret_cast<const f32x4*>(q + 3 * BNC) * fv[3];
+                };
+                f32x4 h0 = hrow(0), h1 = hrow(1), h2 = hrow(2);
+#pragma unroll
+                for (int r = 0; r < OH; ++r) {
+                    const f32x4 h3 = hrow(r + 3);
+                    finish(h0 * fu[0] + h1 * fu[1] + h2 * fu[2] + h3 * fu[3], r);
+                    h0 = h1;
+                    h1 = h2;
+                    h2 = h3;
+                }
+            } else {
+                float kf[16];
+#pragma unroll
+                for (int a = 0; a < 16; ++a) kf[a] = k4[15 - a];
+                f32x4 win[3][4];                        // sliding window: 3 I rows carried, one new row per output
+#pragma unroll
+                for (int ry = 0; ry < 3; ++ry)
+#pragma unroll
+                    for (int ax = 0; ax < 4; ++ax) win[ry][ax] = *reinterpret_cast<const f32x4*>(ip + (ry * IQW + ax) * BNC);
+#pragma unroll
+                for (int r = 0; r < OH; ++r) {
+                    f32x4 nw[4];
+#pragma unroll
+                    for (int ax = 0; ax < 4; ++ax) nw[ax] = *reinterpret_cast<const f32x4*>(ip + ((r + 3) * IQW + ax) * BNC);
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ax = 0; ax < 4; ++ax)
+                        v += win[0][ax] * kf[ax] + win[1][ax] * kf[4 + ax] + win[2][ax] * kf[8 + ax] + nw[ax] * kf[12 + ax];
+#pragma unroll
+                    for (int ax = 0; ax < 4; ++ax) { win[0][ax] = win[1][ax]; win[1][ax] = win[2][ax]; win[2][ax] = nw[ax]; }
+                    finish(v, r);
                 }
             }
         }
         if (!has_next) break;
-        __syncthreads();                               // every FIR read of the I tile is done: the weight buffers are free again
-        store_b(RB, 0);                                // the next tile's chunk-0 weights, parked in registers since their prefetch
+        __syncthreads();                               // every FIR read of the I tile is done: the stage buffers are free again
+        if (abl != 5) {
+            store_a(RE, 0, 0, par ^ 1);                // the next tile's first stage, parked in registers since its prefetch
+            store_b(RB, 0);
+        }
         __syncthreads();
         cur = nxt;
+        par ^= 1;
         t_next += G;
         has_next = t_next < ntiles;
         if (has_next) nxt = decode(t_next);
     }
 }
 
-// w [Cout,Cin,3,3] -> the operand of the kernel above, packed AND split: [Cin/32][Cout/32][9 blocks][32 co][32 hi | 32 lo] bf16.
+// w [Cout,Cin,3,3] -> the operand of upconv_fused_kernel, packed AND split: [Cin/32][Cout/32][9 blocks][32 co][32 hi | 32 lo] bf16.
 // block -> (class, shift): 0..3 = class 0 shifts 0..3; 4,5 = class 1 shifts 0,2; 6,7 = class 2 shifts 0,1; 8 = class 3 shift 0;
 // class (dy,dx) = (cls >> 1, cls & 1), shift s = (sy, sx) = (-(s >> 1), -(s & 1)); the tap is W[dy - 2 sy][dx - 2 sx].
 __global__ void subpixel_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin,
@@ -364,7 +446,7 @@ __global__ void subpixel_weights_kernel(const float* __restrict__ w, unsigned sh
     const int cls_of[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3}, sh_of[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0};
     const int cls = cls_of[blk], s = sh_of[blk];
     const int ky = (cls >> 1) + 2 * (s >> 1), kx = (cls & 1) + 2 * (s & 1);
-    const int co = nt * BNC + col, ci0 = chunk * KC + q * 8;
+    const int co = nt * BNC + col, ci0 = chunk * PKC + q * 8;
     f32x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = w[(((size_t)co * Cin + ci0 + e) * 3 + ky) * 3 + kx];
@@ -392,8 +474,8 @@ int num_cus() {
 
 // out: (Cin/32) * (Cout/32) * 9 * 32 * 64 bf16 = 9 * Cout * Cin * 4 bytes (an opaque buffer only e4s_upconv_bf16x3_f32 reads)
 extern "C" int e4s_subpixel_weights_f32(const float* w, void* out, int Cout, int Cin, void* stream) {
-    if (Cout % BNC || Cin % KC || Cout <= 0 || Cin <= 0) return (int)hipErrorInvalidValue;
-    const int64_t n8 = (int64_t)(Cin / KC) * (Cout / BNC) * NBLK * BNC * 4;
+    if (Cout % BNC || Cin % PKC || Cout <= 0 || Cin <= 0) return (int)hipErrorInvalidValue;
+    const int64_t n8 = (int64_t)(Cin / PKC) * (Cout / BNC) * NBLK * BNC * 4;
     hipLaunchKernelGGL(subpixel_weights_kernel, dim3(cdiv(n8, 256)), dim3(256), 0, as_stream(stream), w,
                        reinterpret_cast<unsigned short*>(out), Cout, Cin, n8);
     E4S_CHECK_LAUNCH();
@@ -405,8 +487,8 @@ extern "C" int e4s_subpixel_weights_f32(const float* w, void* out, int Cout, int
 // blur kernel (model.py:206-213, already x4).
 extern "C" int e4s_upconv_bf16x3_f32(const e4s_conv_params* pp, const float* k4, void* stream) {
     const e4s_conv_params& p = *pp;
-    // Cin % 64: the stage pipeline is unrolled by two 32-channel chunks
-    if (p.Cin % (2 * KC) || p.Cout % BNC || !k4 || p.labels || p.tiles || p.in_stats || p.noise_per_channel || p.act == 2 ||
+    // Cin % 32: the stage pipeline is unrolled by two 16-channel chunks
+    if (p.Cin % (2 * KC) || p.Cin > MAXC || p.Cout % BNC || !k4 || p.labels || p.tiles || p.in_stats || p.noise_per_channel || p.act == 2 ||
         p.Ho != 2 * p.Hi || p.Wo != 2 * p.Wi || p.B <= 0 || (p.y_cstride && p.y_cstride % 4))
         return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
@@ -417,7 +499,8 @@ extern "C" int e4s_upconv_bf16x3_f32(const e4s_conv_params* pp, const float* k4,
     const int tx_n = (p.Wo + OW - 1) / OW, per_img = ((p.Ho + OH - 1) / OH) * tx_n;
     const int64_t ntiles = (int64_t)p.B * per_img * ntn;
     if (ntiles >= (1ll << 31)) return (int)hipErrorInvalidValue;
-    const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
+    const int slots = 2 * num_cus();                    // two co-resident blocks per CU
+    const int grid = (int)(ntiles < slots ? ntiles : slots);
     int abl = 0;
 #ifdef E4S_ABLATIONS
     if (const char* e = getenv("E4S_UPCONV3_ABL")) abl = atoi(e);

@@ -429,7 +429,8 @@ def test_unmasked_exact_upconv_bf16x3_vs_oracle(b, cin, cout, h, w, monkeypatch)
     """the unmasked up-sampling StyledConvs (model.py:287-300 + Blur :206-213; the 128 -> 64 -> 512^2 and
     64 -> 32 -> 1024^2 layers of a face swap, run here at their FULL sizes too) on the exact split-bf16 sub-pixel GEMM
     (e4s_upconv_bf16x3_f32: 9 Cin Cout MACs per input pixel) + FIR epilogue, against the oracle's conv_transpose2d + blur;
-    odd, non-square and partial-tile geometries; per-sample and shared noise maps; <= 5e-5 of the output scale."""
+    odd, non-square and partial-tile geometries; per-sample and shared noise maps; <= 5e-5 of the output scale.  (The blur kernel of
+    the reference is an outer product: this is the kernel's row pass + column pass FIR; the generic 16-tap pass has its own test below.)"""
     from e4s_amd import kernels as K
     from e4s_amd import stylegan2
     from e4s_amd.stylegan2 import StyledConv
@@ -454,6 +455,31 @@ def test_unmasked_exact_upconv_bf16x3_vs_oracle(b, cin, cout, h, w, monkeypatch)
     assert maxabs(got, want) < 5e-5 * scale, (maxabs(got, want), scale)
     got2 = m(x.to(DEV), style.to(DEV), None, noise=noise.to(DEV))
     assert torch.equal(got, got2)                                  # no atomics anywhere: bit-reproducible
+
+
+@pytest.mark.parametrize("separable", [False, True])
+def test_exact_upconv_kernel_with_an_arbitrary_4x4_blur_kernel_vs_fp64(separable):
+    """e4s_upconv_bf16x3_f32 called directly: the FIR epilogue factors the blur kernel into a row pass and a column pass when it is an
+    outer product (checked in the kernel, on the values) and runs the generic 16-tap pass otherwise.  Both against fp64
+    conv_transpose2d + upfirdn2d (model.py:287-300, 206-213) with a kernel that is NOT symmetric (the flip matters), partial tiles, two
+    samples with their own style."""
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(71)
+    b, cin, cout, h, w = 2, 64, 32, 21, 30
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    s = torch.rand(b, cin, generator=g) + 0.5
+    d = torch.rand(b, cout, generator=g) + 0.5
+    k4 = torch.outer(torch.tensor([0.7, 2.0, 3.1, 0.4]), torch.tensor([1.0, 2.5, 3.0, 1.5])) / 16 if separable else \
+        torch.randn(4, 4, generator=g) / 4
+    f64 = torch.float64
+    want = torch.stack([orc.upfirdn2d(F.conv_transpose2d((x[i] * s[i][:, None, None])[None].to(f64), wt.to(f64).transpose(0, 1), stride=2),
+                                      k4.to(f64), pad=(1, 1))[0] * d[i].to(f64)[:, None, None] for i in range(b)])
+    got = K.nhwc_to_nchw(K.upconv_bf16x3(K.nchw_to_nhwc(x.to(DEV)), K.subpixel_weights(wt.to(DEV)), cout, k4.to(DEV).contiguous(),
+                                         in_scale=s.to(DEV), out_scale=d.to(DEV)))
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    assert maxabs(got, want) < 5e-5 * scale, (maxabs(got, want), scale)
 
 
 @pytest.mark.parametrize("b,cout,h,w", [(2, 32, 48, 48), (1, 32, 37, 70), (3, 64, 16, 33), (1, 32, 256, 256)])

@@ -58,6 +58,47 @@ def conv_winograd(x, w, split_ops=True):
     return y.permute(0, 1, 2, 4, 3, 5).reshape(b, k, h, wd)
 
 
+# 1-D forms along the image rows (what conv_wino.hip computes: the three vertical taps stay direct, one GEMM per (tap row, position)).
+# F(2,3): 4 positions per 2 outputs (1.5x fewer MACs than direct); F(4,3): 6 positions per 4 outputs (2x fewer), Lavin & Gray's points
+# 0, +-1, +-2, inf.
+W1D = {
+    2: (torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64),
+        torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64),
+        torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)),
+    4: (torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                      [0, 4, 0, -5, 0, 1]], dtype=torch.float64),
+        torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                      [0, 0, 1]], dtype=torch.float64),
+        torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)),
+}
+
+
+def conv_winograd_1d(x, w, m=2, split_ops=True):
+    """1-D Winograd F(m,3) along the width, direct along the height; operands split AFTER the transforms (as the kernel stages them)."""
+    b, c, h, wd = x.shape
+    k = w.shape[0]
+    dt = x.dtype
+    bt, g, at = (t.to(dt) for t in W1D[m])
+    n = m + 2
+    tw = wd // m
+    xp = F.pad(x, (1, 1, 1, 1))
+    d = xp.unfold(3, n, m)                                        # [b,c,h+2,tw,n]
+    v = torch.einsum("ij,bcyxj->bcyxi", bt, d)                    # B^T d per row
+    u = torch.einsum("ij,kcrj->kcri", g, w)                       # G g per tap row  [k,c,3,n]
+    ops = ((split(v), split(u)) if split_ops else None)
+    mm = None
+    for r in range(3):
+        if split_ops:
+            (vh, vl), (uh, ul) = ops
+            t = (torch.einsum("bcyxi,kci->bkyxi", vh[:, :, r:r + h], uh[:, :, r]) + torch.einsum("bcyxi,kci->bkyxi", vh[:, :, r:r + h], ul[:, :, r])
+                 + torch.einsum("bcyxi,kci->bkyxi", vl[:, :, r:r + h], uh[:, :, r]))
+        else:
+            t = torch.einsum("bcyxi,kci->bkyxi", v[:, :, r:r + h], u[:, :, r])
+        mm = t if mm is None else mm + t
+    y = torch.einsum("ij,bkyxj->bkyxi", at, mm)                   # [b,k,h,tw,m]
+    return y.reshape(b, k, h, wd)
+
+
 class Patch:
     def __init__(self, mode, which):
         self.mode, self.which, self.real = mode, which, _CONV
@@ -67,6 +108,8 @@ class Patch:
                 and w.shape[1] >= 64):
             if self.mode == "winograd" and (self.which == 0 or w.shape[1] == self.which) and x.shape[2] % 2 == 0:
                 return conv_winograd(x, w)
+            if self.mode in ("wino1d_f2", "wino1d_f4") and (self.which == 0 or w.shape[1] == self.which) and x.shape[3] % 4 == 0:
+                return conv_winograd_1d(x, w, 2 if self.mode == "wino1d_f2" else 4)
             return conv_direct_bf16x3(x, w)
         return self.real(x, w, bias, stride, padding, *a, **kw)
 
@@ -85,9 +128,11 @@ def main():
     ref = _CONV(x.double(), w.double(), padding=1)
     sc = float(ref.abs().max())
     for name, y in (("fp32 direct (ATen)", _CONV(x, w, padding=1)), ("direct bf16x3", conv_direct_bf16x3(x, w)),
-                    ("winograd fp32 (no split)", conv_winograd(x, w, False)), ("winograd bf16x3", conv_winograd(x, w))):
+                    ("winograd fp32 (no split)", conv_winograd(x, w, False)), ("winograd bf16x3", conv_winograd(x, w)),
+                    ("1-D F(2,3) bf16x3 (conv_wino.hip)", conv_winograd_1d(x, w, 2)), ("1-D F(4,3) fp32 (no split)", conv_winograd_1d(x, w, 4, False)),
+                    ("1-D F(4,3) bf16x3", conv_winograd_1d(x, w, 4))):
         e = (y.double() - ref).abs()
-        print(f"layer 512->512@32^2  {name:28s} max-abs/scale {float(e.max()) / sc:.3e}  rms/scale {float(e.pow(2).mean().sqrt()) / sc:.3e}")
+        print(f"layer 512->512@32^2  {name:34s} max-abs/scale {float(e.max()) / sc:.3e}  rms/scale {float(e.pow(2).mean().sqrt()) / sc:.3e}")
     # whole encoder
     sd = synth.synth_state_dict(256, 13)
     img = synth.synth_image(args.batch, 1024, tag="wino_img")
@@ -96,7 +141,7 @@ def main():
     with torch.no_grad():
         ref, _ = orc.get_style_vectors(sd64, img.double(), mask.double())
         sc = float(ref.abs().max())
-        for mode in ("direct", "winograd"):
+        for mode in ("direct", "winograd", "wino1d_f2", "wino1d_f4"):
             orc.F.conv2d = Patch(mode, args.which)
             try:
                 sv, _ = orc.get_style_vectors(sd, img, mask)
