@@ -106,7 +106,7 @@ struct WTile {              // one 16x16-pixel x 128-column output tile (x one K
 // WT (round 5): the wave tile.  0: wave (wm, wn) of 2 x 4 owns 64 rows x 32 channels of ALL four positions -- every A and B fragment feeds
 // one or two MFMAs: 24 ds_read_b128 per 24 MFMAs, and with the weight DMA and the transform's stores the LDS is ~86 % busy when the matrix
 // pipe is 100 % busy (ablation: the same kernel with a third of its fragment reads skipped runs 11 % faster on 512 -> 512 @32^2,
-// profiles/r05_wino_ablations.json).  1: wave (pp, wm, wn) of 2 x 2 x 2 owns 64 rows x 64 channels of TWO positions {2 pp, 2 pp + 1}: 16 reads
+// profiles/r05_wino_wave_tile.json).  1: wave (pp, wm, wn) of 2 x 2 x 2 owns 64 rows x 64 channels of TWO positions {2 pp, 2 pp + 1}: 16 reads
 // per 24 MFMAs, same accumulators (8 x 16 registers), same fragment registers (the B fragments of the next position roll into the registers
 // the first half of the MFMAs has released).  The output transform needs M0..M3 of a pair in one place: once per tile the two waves of a
 // (wm, wn) exchange one position each through the LDS buffer the finished tile has released (pp = 0 sends M1 and produces the EVEN columns

@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B aid: build the library of the LAST COMMIT beside the working tree's (e4s_amd/libe4s_prev.so; load it with E4S_LIB_PATH).
+set -e
+cd "$(dirname "$0")/.."
+rm -rf e4s_amd/build/prev && mkdir -p e4s_amd/build/prev
+git archive HEAD e4s_amd/csrc include | tar -x -C e4s_amd/build/prev
+cd e4s_amd/build/prev
+for f in e4s_amd/csrc/*.hip; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Ie4s_amd/csrc -c "$f" -o "$(basename "$f").o" 2>/dev/null &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../libe4s_prev.so *.o
+echo built e4s_amd/libe4s_prev.so from $(git rev-parse --short HEAD)
