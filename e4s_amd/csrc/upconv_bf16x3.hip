@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NTHR, 2) void upconv_fused_kernel(const e4s_conv_pa
     const int e_c4 = tid & 7, e_ox = tid >> 3;
     const bool e_act = e_ox < OW;
 
-    // The blur kernel of the reference is always an outer product (make_kernel, model.py:36-44): k4 = u v^T lets the FIR run as a 4-tap
+    // The blur kernel of the reference is always an outer product (make_kernel, model.py:23-31): k4 = u v^T lets the FIR run as a 4-tap
     // row pass + a 4-tap column pass (8 multiply-adds per output instead of 16).  Checked here, once per block, on the values themselves;
     // any other 4x4 kernel takes the generic 16-tap pass.  Flipped taps (upfirdn2d is a true convolution, upfirdn2d_kernel.cu:77):
     // kf[ay][ax] = k4[3-ay][3-ax] = fu[ay] * fv[ax].
