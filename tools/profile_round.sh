@@ -35,6 +35,7 @@ cp "$(f bench _kernel_stats.csv)" $OUT/${TAG}_bench_rocprof_stats.csv 2>/dev/nul
 if [ "$MODE" != quick ]; then
 for c in fetch write sq; do python tools/prof_summarize.py pmc "$(f $c _counter_collection.csv)" > $OUT/${TAG}_pmc_$c.csv; done
 for c in sfetch swrite ssq; do python tools/prof_summarize.py pmc "$(f $c _counter_collection.csv)" grid > $OUT/${TAG}_steps_pmc_${c#s}.csv; done
+python tools/steps_summary.py $OUT/${TAG} > $OUT/${TAG}_steps_per_kernel_summary.json      # one row per kernel: bytes, TB/s, MFMA busy, LDS conflicts
 fi
 grep -h '^{' $RAW/probe.log $RAW/bench.log $RAW/graph.log > $OUT/${TAG}_bench_lines.json
 ls -la $OUT; du -sh $RAW
