@@ -19,9 +19,11 @@ from torch.autograd.function import once_differentiable
 from . import kernels as K
 
 
-def styled_conv_backward(rec, dy, num_regions, extras=None):
+def styled_conv_backward(rec, dy, num_regions, extras=None, defer=None):
     """Backward of one fused StyledConv launch.  rec: the forward tape record (layer, x, y, s, d, noise, labels);
-    dy: dL/dy NHWC.  Returns (dL/dx NHWC, dL/ds [G,Cin] including the path through the demodulation d(s))."""
+    dy: dL/dy NHWC.  Returns (dL/dx NHWC, dL/ds [G,Cin] including the path through the demodulation d(s)).
+    defer (a list): the demodulation path and everything behind dL/ds is left to ONE batched launch pair for all layers
+    (kernels.style_grad_multi); the pieces are appended as a job and the second return value is None."""
     layer = rec["layer"]
     conv, act = layer.conv, layer.activate
     y, s, d, labels = rec["y"], rec["s"], rec["d"], rec["labels"]
@@ -80,6 +82,11 @@ def styled_conv_backward(rec, dy, num_regions, extras=None):
     else:
         dx, ds = K.conv_bwd(gz, conv.bwd_taps(), x, s, d, labels, num_regions, 4 if conv.upsample else 1)
     # d = scale * rsqrt(scale^2 sum_ci s^2 Wsq + eps)  =>  dd/ds_ci = -d^3 s_ci Wsq[co,ci];  dL/dd = dd_d / d, so dL/dd * d^3 = dd_d * d^2
+    if defer is not None:
+        defer.append(dict(ds_raw=ds, dd_d=dd_d, d=d, s=s, wsq=pk["wsq"], G=ds.shape[0], Cin=cin, Cout=cout))
+        if extras is not None:
+            extras.update(gz=gz, dd3=dd_d * (d * d))
+        return dx, None
     dd3 = dd_d * (d * d)
     # ds - s * (dd3 @ Wsq): the [G,Cout] x [Cout,Cin] contraction on e4s_grouped_linear_t_f32 with the combine fused
     ds = K.grouped_linear_t(dd3.unsqueeze(1), pk["wsq"].unsqueeze(0), -1.0, base=ds.unsqueeze(1),
@@ -138,8 +145,8 @@ class GeneratorFn(torch.autograd.Function):
         if dimage is None:
             dimage = torch.zeros_like(tape[-1]["out"])
         dev = dimage.device
-        dlat = torch.zeros_like(lat)
         pgrads = [None] * len(ctx.pidx)
+        jobs = []                                       # per layer: the pieces of its dL/ds -> dL/dlatent tail (one batched launch pair below)
 
         def want(p_):
             return id(p_) in ctx.pidx
@@ -154,32 +161,45 @@ class GeneratorFn(torch.autograd.Function):
         def style_rows(rec):
             return lat[:, :, rec["idx"]].reshape(b * r, -1) if rec["masked"] else lat[:, 0, rec["idx"]]
 
-        def add_style_grad(rec, ds_total):
+        multi = K.STYLE_GRAD_MULTI
+        dlat = None if multi else torch.zeros_like(lat)
+
+        def mod_grads(rec, ds_total):
             mod = rec["layer"].conv.modulation
-            dstyle = K.grouped_linear_t(ds_total.unsqueeze(1).contiguous(), mod.weight.detach().unsqueeze(0),
-                                        mod.scale).squeeze(1)               # [G,Cin] x [Cin,512] -> [G,512]
-            if rec["masked"]:
-                dlat[:, :, rec["idx"]] += dstyle.view(b, r, -1)
-            else:
-                dlat[:, 0, rec["idx"]] += dstyle
             if want(mod.weight):                                             # s = style @ Wm^T * scale + bias
                 give(mod.weight, K.grouped_outer(ds_total.unsqueeze(1).contiguous(), style_rows(rec).unsqueeze(1).contiguous(),
                                                  mod.scale)[0])
             if want(mod.bias):
                 give(mod.bias, K.batch_sum(ds_total.contiguous()))
 
+        def add_style_grad(rec, job):
+            """dL/ds -> dL/dlatent through the layer's modulation EqualLinear (s = style @ Wm^T * scale + bias): deferred to
+            kernels.style_grad_multi, which also finishes dL/ds itself (demodulation path / ToRGB's ws = scale * w3 * s).
+            (E4S_STYLE_GRAD_MULTI=0: the per-layer chain of rounds 2-4, kept for A/B runs: `job` is then the finished dL/ds.)"""
+            mod = rec["layer"].conv.modulation
+            if multi:
+                job.update(wmod=mod.weight.detach(), mod_scale=mod.scale, slot=rec["idx"], masked=bool(rec["masked"]), rec=rec)
+                jobs.append(job)
+                return
+            dstyle = K.grouped_linear_t(job.unsqueeze(1).contiguous(), mod.weight.detach().unsqueeze(0), mod.scale).squeeze(1)
+            if rec["masked"]:
+                dlat[:, :, rec["idx"]] += dstyle.view(b, r, -1)
+            else:
+                dlat[:, 0, rec["idx"]] += dstyle
+            mod_grads(rec, job)
+
         for rec in reversed(tape):
             layer = rec["layer"]
             if rec["kind"] == "rgb":
                 labels = rec["labels"]
                 dact, dws = K.torgb_bwd(dskip, rec["x"], rec["ws"], labels, r, dx_acc=dact)
-                w3 = layer.conv.weight.detach()[0, :, :, 0, 0]                  # [3,Cin]
-                ds = layer.conv.scale * (dws * w3.unsqueeze(0)).sum(1)         # [G,Cin]
+                w3 = layer.conv.weight.detach()[0, :, :, 0, 0]                  # [3,Cin]; dL/ds = scale * sum_c dws[:, c] * w3[c] (batched below)
                 if want(layer.conv.weight):                                     # ws = scale * w * s
                     give(layer.conv.weight, (layer.conv.scale * (dws * rec["s"].unsqueeze(1)).sum(0)).view(1, 3, -1, 1, 1))
                 if want(layer.bias):
                     give(layer.bias, K.channel_sum(dskip).view(1, 3, 1, 1))
-                add_style_grad(rec, ds)
+                add_style_grad(rec, dict(dws=dws, w3=w3, conv_scale=layer.conv.scale, G=dws.shape[0], Cin=dws.shape[2]) if multi
+                               else layer.conv.scale * (dws * w3.unsqueeze(0)).sum(1))
                 if rec["has_skip"]:                     # Upsample backward = FIR-downsample of the incoming grad
                     k4 = layer.upsample.kernel
                     n, c, h, w = dskip.shape
@@ -195,7 +215,8 @@ class GeneratorFn(torch.autograd.Function):
             conv = layer.conv
             train_w = want(conv.weight)
             extras = {} if (train_w or want(layer.noise.weight) or want(layer.activate.bias)) else None
-            dact, ds = styled_conv_backward(rec, dact, r, extras)
+            conv_job = [] if multi else None
+            dact, ds = styled_conv_backward(rec, dact, r, extras, defer=conv_job)
             if extras is not None:
                 gz = extras["gz"]
                 if want(layer.activate.bias):
@@ -207,9 +228,14 @@ class GeneratorFn(torch.autograd.Function):
                     give(layer.noise.weight, K.sum_all(gz.sum(-1) * nz[:, 0]).view(1))
                 if train_w:
                     give(conv.weight, styled_conv_weight_grad(rec, extras, r))
-            add_style_grad(rec, ds)
+            add_style_grad(rec, conv_job[0] if multi else ds)
         if want(gen.input.input) and dact is not None:
             give(gen.input.input, dact.sum(0, keepdim=True).permute(0, 3, 1, 2).contiguous())
+        # every layer's dL/ds (demodulation path included) and dL/dlatent in two launches; the modulation layers' own gradients need dL/ds
+        if multi:
+            dlat, ds_totals = K.style_grad_multi(jobs, b, r, nl, lat.shape[3], dev)
+            for job, ds_total in zip(jobs, ds_totals):
+                mod_grads(job["rec"], ds_total)
         return (None, dlat if ctx.need_lat else None, None, None) + tuple(pgrads)
 
 

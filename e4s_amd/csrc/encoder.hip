@@ -556,6 +556,35 @@ __global__ void grouped_linear_longk_kernel(const float* __restrict__ x, const f
     }
 }
 
+
+// ---- regional style swap (scripts/face_swap.py:117-146, per sample): out[b][r] = swap bit r ? src[b][r] : tgt[b][r]; a source without
+// ears (region `ear`: sum of its style vector == 0) takes the mean of both, without teeth (`teeth`) the target's; `below` >= 0: the mean
+// of both for that region.  One block per (b, r); the emptiness test is an ordered block sum of the 1280 (C) values -- an absent region's
+// vector is exact zeros (regional average pooling of no pixels). ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swap_styles_kernel(const float* __restrict__ tgt, const float* __restrict__ src,
+                                                          float* __restrict__ out, int R, int C, unsigned sel, int ear, int teeth,
+                                                          int below) {
+    __shared__ float part[256];
+    const int b = blockIdx.x / R, r = blockIdx.x - b * R;
+    const float* a = tgt + ((int64_t)b * R + r) * C;
+    const float* c = src + ((int64_t)b * R + r) * C;
+    float* o = out + ((int64_t)b * R + r) * C;
+    int mode = (sel >> r) & 1u;                              // 0: target, 1: source, 2: mean of both
+    if (r == ear || r == teeth) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < C; i += 256) s += c[i];
+        part[threadIdx.x] = s;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (part[0] == 0.f) mode = (r == ear) ? 2 : 0;
+    }
+    if (r == below) mode = 2;
+    for (int i = threadIdx.x; i < C; i += 256) o[i] = mode == 2 ? (a[i] + c[i]) / 2.f : (mode == 1 ? c[i] : a[i]);
+}
+
 }  // namespace
 
 extern "C" int e4s_resize_bilinear_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream) {
@@ -693,6 +722,17 @@ extern "C" int e4s_grouped_linear_f32(const float* x, const float* W, const floa
         return 0;
     }
     hipLaunchKernelGGL(grouped_linear_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, as_stream(stream), x, W, bias, add, y, B, R, K, O, scale, act, alpha);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
+/* Regional style swap on the device in one launch (scripts/face_swap.py:117-146, applied per sample): tgt / src / out [B][R][C];
+ * sel: bit r set = region r comes from src; ear / teeth / below: region indices of the three special cases (below < 0: off). */
+extern "C" int e4s_swap_styles_f32(const float* tgt, const float* src, float* out, int B, int R, int C, unsigned sel, int ear, int teeth,
+                                   int below, void* stream) {
+    if (!tgt || !src || !out || B < 1 || R < 1 || R > 32 || C < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(swap_styles_kernel, dim3((unsigned)(B * R)), dim3(256), 0, as_stream(stream), tgt, src, out, R, C, sel, ear, teeth,
+                       below);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -324,6 +324,122 @@ int linear_t_nsplit(int R, int O, int K) {
     return ns < 1 ? 1 : ns;
 }
 
+
+// ---- style-gradient tail of the generator backward, all layers in two launches (round 5) ---------------------------------------------
+// Every StyledConv / ToRGB of the generator backward ends in the same small chain (autograd.GeneratorFn.backward): dL/ds of the
+// contraction, minus the path through the demodulation coefficients (model.py:276-285: d = scale * rsqrt(scale^2 sum_ci s^2 Wsq + eps)),
+// then through the modulation EqualLinear into the layer's latent slot.  Per layer that was 2 transposed contractions with their ordered
+// second stages and 3-5 ATen glue launches -- ~180 launches of 5-10 us in a latent-optimisation step of ~470.  The jobs travel BY VALUE
+// in the kernel arguments (a HIP-graph capture bakes them in; the addresses of a captured step are stable under replay).
+struct StyleGradJobs {
+    e4s_style_grad_job j[E4S_STYLE_GRAD_MAX_JOBS];
+    int blk0[E4S_STYLE_GRAD_MAX_JOBS + 1];      // stage 1: first block of job i (256 input channels per block)
+    int n;
+};
+
+// stage 1: ds_total[g][ci] = ds_raw[g][ci] - s[g][ci] * sum_co (dd_d[g][co] d[g][co]^2) Wsq[co][ci]          (StyledConv)
+//          ds_total[g][ci] = conv_scale * ((dws[g][0][ci] w3[0][ci] + dws[g][1][ci] w3[1][ci]) + dws[g][2][ci] w3[2][ci])   (ToRGB)
+// block = (job, 256 input channels): four waves walk Cout (wave w takes rows w, w + 4, ...), 16 rows g per pass, cross-wave sum in order
+__global__ __launch_bounds__(256) void style_grad_stage1_kernel(const StyleGradJobs J) {
+    __shared__ f32x4 red[3][TB][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int ji = 0;
+    while (ji + 1 < J.n && (int)blockIdx.x >= J.blk0[ji + 1]) ++ji;
+    const e4s_style_grad_job& q = J.j[ji];
+    const int k = (((int)blockIdx.x - J.blk0[ji]) * 64 + lane) * 4;
+    const bool live = k < q.Cin;
+    if (q.dws) {                                             // ToRGB: elementwise
+        if (wv == 0 && live)
+            for (int g = 0; g < q.G; ++g) {
+                const float* dw = q.dws + (int64_t)g * 3 * q.Cin + k;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(dw) * *reinterpret_cast<const f32x4*>(q.w3 + k);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(dw + q.Cin) * *reinterpret_cast<const f32x4*>(q.w3 + q.Cin + k);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(dw + 2 * q.Cin) * *reinterpret_cast<const f32x4*>(q.w3 + 2 * q.Cin + k);
+                *reinterpret_cast<f32x4*>(q.ds_total + (int64_t)g * q.Cin + k) = ((a + b) + c) * q.conv_scale;
+            }
+        return;
+    }
+    const float* wr = q.wsq + (live ? k : 0);
+    for (int g0 = 0; g0 < q.G; g0 += TB) {
+        const int nb = min(TB, q.G - g0);
+        f32x4 acc[TB];
+#pragma unroll
+        for (int b = 0; b < TB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int co = wv; co < q.Cout; co += 4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + (int64_t)co * q.Cin);
+#pragma unroll
+            for (int b = 0; b < TB; ++b)
+                if (b < nb) {
+                    const float dd = q.dd_d[(int64_t)(g0 + b) * q.Cout + co], dv = q.d[(int64_t)(g0 + b) * q.Cout + co];
+                    acc[b] += (dd * (dv * dv)) * w4;                     // wave-uniform scalar
+                }
+        }
+        __syncthreads();                                     // (red is re-used by the next pass)
+        if (wv > 0) {
+#pragma unroll
+            for (int b = 0; b < TB; ++b) red[wv - 1][b][lane] = acc[b];
+        }
+        __syncthreads();
+        if (wv == 0 && live) {
+#pragma unroll
+            for (int b = 0; b < TB; ++b)
+                if (b < nb) {
+                    const f32x4 v = ((acc[b] + red[0][b][lane]) + red[1][b][lane]) + red[2][b][lane];
+                    const int64_t o = (int64_t)(g0 + b) * q.Cin + k;
+                    *reinterpret_cast<f32x4*>(q.ds_total + o) =
+                        *reinterpret_cast<const f32x4*>(q.ds_raw + o) - *reinterpret_cast<const f32x4*>(q.s + o) * v;
+                }
+        }
+    }
+}
+
+// stage 2: dlat[b][r][slot][:] = sum over the jobs of that slot, in job order, of mod_scale * ds_total[g] @ Wmod   (Wmod [Cin][S]).
+// A masked job's row g = b * R + r feeds dlat[b][r]; an unmasked job's row g = b feeds dlat[b][0].  Every (row, slot) is written, zeros
+// included.  grid = (NL * ceil(S / 256), ceil(B * R / 16)); the four waves walk Cin, cross-wave sum in order.
+__global__ __launch_bounds__(256) void style_grad_stage2_kernel(const StyleGradJobs J, float* __restrict__ dlat, const int BR,
+                                                                const int R, const int NL, const int S) {
+    __shared__ f32x4 red[3][TB][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kblk = (S + 255) / 256;
+    const int slot = blockIdx.x / kblk;
+    const int k = ((blockIdx.x - slot * kblk) * 64 + lane) * 4;
+    const bool live = k < S;
+    const int r0 = blockIdx.y * TB;                          // first dlat row (b * R + r) of this block
+    f32x4 acc[TB];
+#pragma unroll
+    for (int b = 0; b < TB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ji = 0; ji < J.n; ++ji) {
+        const e4s_style_grad_job& q = J.j[ji];
+        if (q.slot != slot) continue;
+        const float* wr = q.wmod + (live ? k : 0);
+        for (int ci = wv; ci < q.Cin; ci += 4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + (int64_t)ci * S);
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const int row = r0 + b;
+                if (row < BR) {
+                    if (q.masked) acc[b] += (q.ds_total[(int64_t)row * q.Cin + ci] * q.mod_scale) * w4;
+                    else if (row % R == 0) acc[b] += (q.ds_total[(int64_t)(row / R) * q.Cin + ci] * q.mod_scale) * w4;
+                }
+            }
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int b = 0; b < TB; ++b) red[wv - 1][b][lane] = acc[b];
+    }
+    __syncthreads();
+    if (wv == 0 && live) {
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const int row = r0 + b;
+            if (row < BR)
+                *reinterpret_cast<f32x4*>(dlat + ((int64_t)row * NL + slot) * S + k) =
+                    ((acc[b] + red[0][b][lane]) + red[1][b][lane]) + red[2][b][lane];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t e4s_grouped_linear_t_ws_floats(int B, int R, int O, int K) {
@@ -512,5 +628,37 @@ extern "C" int e4s_ema_multi_f32(int count, float* const* dst, const float* cons
         hipLaunchKernelGGL(ema_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, c, cnt, (float)decay, (float)(1.0 - decay));
         E4S_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+/* The style-gradient tail of the generator backward for every layer at once (see the kernels above): jobs[i].ds_total <- dL/ds of layer
+ * i including the demodulation path; dlat [B][R][NL][S] <- every layer's dL/dstyle in its latent slot (all of dlat is written). */
+extern "C" int e4s_style_grad_multi_f32(const e4s_style_grad_job* jobs, int njobs, float* dlat, int B, int R, int NL, int S,
+                                        void* stream) {
+    if (!jobs || !dlat || njobs < 0 || njobs > E4S_STYLE_GRAD_MAX_JOBS || B < 1 || R < 1 || NL < 1 || S < 4 || S % 4)
+        return (int)hipErrorInvalidValue;
+    StyleGradJobs J;
+    J.n = njobs;
+    int blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const e4s_style_grad_job& q = jobs[i];
+        const bool rgb = q.dws != nullptr;
+        if (!q.ds_total || !q.wmod || q.G < 1 || q.Cin < 4 || q.Cin % 4 || q.slot < 0 || q.slot >= NL ||
+            q.G != (q.masked ? B * R : B) || (rgb ? !q.w3 : (!q.ds_raw || !q.dd_d || !q.d || !q.s || !q.wsq || q.Cout < 1)))
+            return (int)hipErrorInvalidValue;
+        J.j[i] = q;
+        J.blk0[i] = blocks;
+        blocks += (q.Cin + 255) / 256;
+    }
+    J.blk0[njobs] = blocks;
+    hipStream_t st = as_stream(stream);
+    if (blocks > 0) {
+        hipLaunchKernelGGL(style_grad_stage1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, J);
+        E4S_CHECK_LAUNCH();
+    }
+    const int BR = B * R;
+    hipLaunchKernelGGL(style_grad_stage2_kernel, dim3((unsigned)(NL * ((S + 255) / 256)), (unsigned)((BR + TB - 1) / TB)), dim3(256), 0,
+                       st, J, dlat, BR, R, NL, S);
+    E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -252,6 +252,18 @@ def mask_labels(mask):
     return labels, flags
 
 
+def swap_styles(tgt, src, comp_indices, below_face=False):
+    """scripts/face_swap.py:117-146 per sample, one launch (e4s_swap_styles_f32): tgt / src [B,R,C] -> [B,R,C]."""
+    tgt, src = _f32(tgt), _f32(src)
+    b, r, c = tgt.shape
+    out = torch.empty_like(tgt)
+    sel = 0
+    for i in comp_indices:
+        sel |= 1 << int(i)
+    call("e4s_swap_styles_f32", fptr(tgt), fptr(src), fptr(out), b, r, c, sel, 7, 9, 8 if below_face else -1, stream())
+    return out
+
+
 class RowPlan:
     __slots__ = ("rows", "tiles", "meta", "tiles_cap", "Ha", "Wa", "nphase", "R")
 
@@ -784,6 +796,42 @@ def grouped_linear_t(g, w, scale, base=None, mul=None, ref=None, alpha=1.0):
              fptr(base[sl]) if base is not None else None, fptr(mul[sl]) if mul is not None else None,
              fptr(ref[sl]) if ref is not None else None, float(alpha), stream())
     return out
+
+
+# the style-gradient tails of the generator backward batched over the layers (E4S_STYLE_GRAD_MULTI=0: one chain per layer, for A/B runs)
+STYLE_GRAD_MULTI = os.environ.get("E4S_STYLE_GRAD_MULTI", "1") != "0"
+
+
+def style_grad_multi(jobs, b, r, nl, sdim, device):
+    """The style-gradient tail of the generator backward for every layer in two launches (e4s_style_grad_multi_f32).
+    jobs: dicts in the order their layers' gradients arrive, each
+        StyledConv: ds_raw [G,Cin], dd_d [G,Cout], d [G,Cout], s [G,Cin], wsq [Cout,Cin]
+        ToRGB:      dws [G,3,Cin], w3 [3,Cin], conv_scale
+        both:       wmod [Cin,S], mod_scale, slot, masked
+    Returns (dlat [B,R,NL,S], [ds_total [G,Cin] per job]): dL/ds per layer including the demodulation path, dL/dlatent with every
+    layer's contribution in its slot (jobs of one slot added in job order)."""
+    if len(jobs) > lib.STYLE_GRAD_MAX_JOBS:
+        raise RuntimeError(f"{len(jobs)} style-gradient jobs: the ABI carries at most {lib.STYLE_GRAD_MAX_JOBS}")
+    arr = (lib.StyleGradJob * max(len(jobs), 1))()
+    ws = torch.empty(sum(j["G"] * j["Cin"] for j in jobs), device=device, dtype=torch.float32)
+    outs, keep, off = [], [], 0
+    for q, j in zip(arr, jobs):
+        n = j["G"] * j["Cin"]
+        out = ws[off:off + n].view(j["G"], j["Cin"])
+        off += n
+        outs.append(out)
+        rgb = "dws" in j
+        for name in (("dws", "w3") if rgb else ("ds_raw", "dd_d", "d", "s", "wsq")) + ("wmod",):
+            t = _f32(j[name])
+            keep.append(t)
+            setattr(q, name, fptr(t).value)
+        q.ds_total = fptr(out).value
+        q.conv_scale = float(j.get("conv_scale", 0.0))
+        q.mod_scale = float(j["mod_scale"])
+        q.G, q.Cin, q.Cout, q.slot, q.masked = j["G"], j["Cin"], j.get("Cout", 0), j["slot"], int(j["masked"])
+    dlat = torch.empty(b, r, nl, sdim, device=device, dtype=torch.float32)
+    call("e4s_style_grad_multi_f32", ctypes.cast(arr, ctypes.c_void_p), len(jobs), fptr(dlat), b, r, nl, sdim, stream())
+    return dlat, outs
 
 
 def grouped_outer(g, h, scale):

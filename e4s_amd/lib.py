@@ -13,13 +13,24 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E4S_LIB_PATH") or os.path.join(_HERE, "libe4s_hip.so")      # (E4S_LIB_PATH: A/B runs of two builds)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
 c_l = ctypes.c_int64
 c_f = ctypes.c_float
 c_d = ctypes.c_double
+
+
+STYLE_GRAD_MAX_JOBS = 32
+
+
+class StyleGradJob(ctypes.Structure):
+    """Mirror of ``e4s_style_grad_job`` (include/e4s_hip.h)."""
+    _fields_ = [
+        ("ds_raw", c_p), ("dd_d", c_p), ("d", c_p), ("s", c_p), ("wsq", c_p), ("dws", c_p), ("w3", c_p), ("wmod", c_p), ("ds_total", c_p),
+        ("conv_scale", c_f), ("mod_scale", c_f), ("G", c_i), ("Cin", c_i), ("Cout", c_i), ("slot", c_i), ("masked", c_i),
+    ]
 
 
 class ConvParams(ctypes.Structure):
@@ -92,6 +103,8 @@ SIGNATURES = {
     "e4s_reduce_parts_f32": [c_p, c_p, c_i, c_l, c_f, c_p],
     "e4s_reduce_parts_ws_floats": [c_i, c_l],
     "e4s_grouped_outer_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "e4s_style_grad_multi_f32": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+    "e4s_swap_styles_f32": [c_p, c_p, c_p, c_i, c_i, c_i, ctypes.c_uint, c_i, c_i, c_i, c_p],
     "e4s_batch_sum_f32": [c_p, c_p, c_i, c_l, c_p],
     "e4s_adam_step_f32": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_p],
     "e4s_subpixel_weights_f32": [c_p, c_p, c_i, c_i, c_p],

@@ -379,6 +379,22 @@ int e4s_reduce_parts_f32(float* parts, float* out, int nparts, int64_t n, float 
 int64_t e4s_reduce_parts_ws_floats(int nparts, int64_t n);
 /* dw[r,o,k] = scale * sum_b g[b,r,o] * h[b,r,k] (LocalMLP weight gradients);  out[i] = sum_b x[b*n + i] (bias gradients) */
 int e4s_grouped_outer_f32(const float* g, const float* h, float* dw, int B, int R, int O, int K, float scale, void* stream);
+/* Style-gradient tail of the generator backward (autograd of model.py:242-320 / 422-448 w.r.t. the style, all layers in two launches;
+ * replaces per layer: dd3 = dd_d * d^2, ds = ds_raw - s * (dd3 @ Wsq), dstyle = mod_scale * ds @ Wmod, dlat[:, :, slot] += dstyle).
+ * StyledConv job: ds_raw [G,Cin] (dL/ds of the contraction), dd_d [G,Cout] (d * dL/dd), d [G,Cout], s [G,Cin], wsq [Cout,Cin], dws = NULL.
+ * ToRGB job: dws [G,3,Cin] (dL/d(ws)), w3 [3,Cin], conv_scale (ws = conv_scale * w3 * s); the conv pointers unused.
+ * Both: wmod [Cin,S] (the modulation EqualLinear's weight), mod_scale, ds_total [G,Cin] (OUT: dL/ds), slot (latent index),
+ * masked (1: G = B*R, row g = b*R + r feeds dlat[b][r][slot]; 0: G = B, row b feeds dlat[b][0][slot]).  Jobs of one slot are added in
+ * job order; every element of dlat [B][R][NL][S] is written.  Ordered sums only: bit-reproducible. */
+#define E4S_STYLE_GRAD_MAX_JOBS 32    /* 32 jobs by value = 3.4 KB of kernel arguments (limit 4 KB); a 1024^2 generator has 26 */
+typedef struct e4s_style_grad_job {
+    const float* ds_raw; const float* dd_d; const float* d; const float* s; const float* wsq;
+    const float* dws; const float* w3;
+    const float* wmod; float* ds_total;
+    float conv_scale, mod_scale;
+    int G, Cin, Cout, slot, masked;
+} e4s_style_grad_job;
+int e4s_style_grad_multi_f32(const e4s_style_grad_job* jobs, int njobs, float* dlat, int B, int R, int NL, int S, void* stream);
 int e4s_batch_sum_f32(const float* x, float* out, int B, int64_t n, void* stream);
 /* out[c] = sum_r x[r*C + c] over a tall [rows][C] matrix (C % 4 == 0, C <= 1024): bias gradients of channels-last activations
  * (rows = B*H*W); two ordered levels, bit-reproducible; ws: e4s_colsum_ws_floats(rows, C) floats */
@@ -535,6 +551,11 @@ int e4s_instnorm_finalize_se_f32(const double* ws, float* stats, const float* fc
  * label r of feats[b, p, c]; exact 0 for empty regions.  feats NHWC [B,H,W,C]. */
 int e4s_region_mean_f32(const float* feats, const uint8_t* labels, int Hm, int Wm, float* out,
                         int B, int H, int W, int C, int R, int out_stride, int out_off, void* stream);
+/* Regional style swap (scripts/face_swap.py:117-146, per sample) in one launch: out[b][r] = (sel >> r) & 1 ? src[b][r] : tgt[b][r];
+ * region `ear` of a source whose style vector sums to 0 (no ears): the mean of both; region `teeth` likewise empty: the target's;
+ * `below` >= 0: the mean of both for that region (belowFace_interpolation).  tgt / src / out [B][R][C], R <= 32. */
+int e4s_swap_styles_f32(const float* tgt, const float* src, float* out, int B, int R, int C, unsigned sel, int ear, int teeth, int below,
+                        void* stream);
 /* LocalMLP layer (networks.py:15-39): y[b, r, o] = act(sum_i x[b, r, i]*W[r][o, i]*scale + bias[r][o]) [+ add[o]]
  * W is [R][O][K] (stacked EqualLinear weights); act: 0 none, 1 leaky(alpha). */
 int e4s_grouped_linear_f32(const float* x, const float* W, const float* bias, const float* add, float* y,

@@ -378,3 +378,52 @@ def test_native_mse_and_sum_all_vs_torch():
         assert torch.equal(mse_loss(a.detach(), b.detach()), l.detach())
         x = a.detach()
         assert abs(float(K.sum_all(x)) - float(x.double().sum())) < 1e-3
+
+
+@pytest.mark.parametrize("b,r", [(1, 12), (2, 12), (3, 5)])
+def test_style_grad_multi_vs_fp64(b, r):
+    """e4s_style_grad_multi_f32 -- the dL/ds -> dL/dlatent tail of every generator layer in two launches (the chain rule of
+    model.py:242-320 through the demodulation coefficients and the modulation EqualLinear; ToRGB: ws = scale * w3 * s, model.py:422-440)
+    -- against the per-layer fp64 statement: masked and unmasked StyledConv jobs, ToRGB jobs, two jobs sharing a latent slot, a slot no
+    job writes (must come back zero), more than 16 rows (two row passes); bit-reproducible."""
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(123)
+    nl, sdim = 6, 512
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g)
+
+    specs = [("conv", True, 64, 128, 0), ("rgb", True, 128, 0, 2), ("conv", False, 128, 64, 2), ("conv", True, 512, 512, 3),
+             ("rgb", False, 32, 0, 5), ("conv", True, 32, 32, 5)]
+    jobs, ref = [], []
+    for kind, masked, cin, cout, slot in specs:
+        G = b * r if masked else b
+        j = dict(G=G, Cin=cin, Cout=cout, slot=slot, masked=masked, wmod=rnd(cin, sdim) / 8, mod_scale=0.0442)
+        if kind == "conv":
+            j.update(ds_raw=rnd(G, cin), dd_d=rnd(G, cout), d=torch.rand(G, cout, generator=g) + 0.5, s=rnd(G, cin), wsq=torch.rand(cout, cin, generator=g))
+        else:
+            j.update(dws=rnd(G, 3, cin), w3=rnd(3, cin), conv_scale=0.177)
+        ref.append(j)
+        jobs.append({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in j.items()})
+    dlat, ds_totals = K.style_grad_multi(jobs, b, r, nl, sdim, DEV)
+    want_lat = torch.zeros(b, r, nl, sdim, dtype=torch.float64)
+    for j, got in zip(ref, ds_totals):
+        f = {k: (v.double() if torch.is_tensor(v) else v) for k, v in j.items()}
+        if "dws" in f:
+            ds = f["conv_scale"] * (f["dws"] * f["w3"][None]).sum(1)
+        else:
+            ds = f["ds_raw"] - f["s"] * ((f["dd_d"] * f["d"] ** 2) @ f["wsq"])
+        sc = float(ds.abs().max())
+        assert float((got.cpu().double() - ds).abs().max()) < 2e-6 * sc, (j["Cin"], j["masked"])
+        dstyle = f["mod_scale"] * ds @ f["wmod"]
+        if j["masked"]:
+            want_lat[:, :, j["slot"]] += dstyle.view(b, r, sdim)
+        else:
+            want_lat[:, 0, j["slot"]] += dstyle
+    sc = float(want_lat.abs().max())
+    assert float((dlat.cpu().double() - want_lat).abs().max()) < 2e-6 * sc
+    assert float(dlat[:, :, 1].abs().max()) == 0.0 and float(dlat[:, :, 4].abs().max()) == 0.0      # slots nobody writes
+    if r > 1:
+        assert float(dlat[:, 1:, 2].abs().max()) > 0.0 and float(dlat[:, 1:, 5].abs().max()) > 0.0
+    dlat2, ds2 = K.style_grad_multi(jobs, b, r, nl, sdim, DEV)
+    assert torch.equal(dlat, dlat2) and all(torch.equal(a, c) for a, c in zip(ds_totals, ds2))

@@ -234,3 +234,23 @@ def test_graphed_swap_flags_soft_masks_and_guards_encoder_autograd():
             p.requires_grad = False
         sv, _ = net.get_style_vectors(driven, hard)        # frozen encoder: plain inference
         assert not sv.requires_grad
+
+
+@pytest.mark.parametrize("below", [False, True])
+def test_native_style_swap_equals_the_torch_statement(below):
+    """e4s_swap_styles_f32 (one launch) against networks.swap_comp_style_vector's torch statement of scripts/face_swap.py:117-146 on CPU
+    tensors (that statement is checked against the reference script in tests/test_reference_scripts.py): every combination of a source
+    with / without ears and teeth in one batch, bit for bit."""
+    from e4s_amd.networks import swap_comp_style_vector
+    g = torch.Generator().manual_seed(5)
+    t_sv = torch.randn(4, 12, 1280, generator=g)
+    d_sv = torch.randn(4, 12, 1280, generator=g)
+    d_sv[1, 7] = 0
+    d_sv[2, 9] = 0
+    d_sv[3, 7] = 0
+    d_sv[3, 9] = 0
+    comp = set(range(12)) - {0, 4, 11, 10}
+    want = swap_comp_style_vector(t_sv, d_sv, comp, belowFace_interpolation=below)
+    got = swap_comp_style_vector(t_sv.to(DEV), d_sv.to(DEV), comp, belowFace_interpolation=below)
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(want[1, 7], (t_sv[1, 7] + d_sv[1, 7]) / 2) and torch.equal(want[2, 9], t_sv[2, 9])      # the cases are really hit
