@@ -578,8 +578,8 @@ def subpixel_weights(w, out=None):
 
 
 def upconv_bf16x3_eligible(cin, cout):
-    """e4s_upconv_bf16x3_f32: 32-channel output tiles; its stage pipeline is unrolled by two 32-channel input chunks."""
-    return cin % 64 == 0 and cout % 32 == 0
+    """e4s_upconv_bf16x3_f32: 32-channel output tiles, 32-channel chunks of packed weights, the sample's style row (<= 512 channels) in LDS."""
+    return cin % 64 == 0 and cin <= 512 and cout % 32 == 0
 
 
 def upconv_bf16x3(x, w_sub, cout, k4, *, in_scale=None, out_scale=None, noise=None, noise_w=None, bias=None, act=0,
