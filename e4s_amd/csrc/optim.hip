@@ -329,7 +329,7 @@ int linear_t_nsplit(int R, int O, int K) {
 // Every StyledConv / ToRGB of the generator backward ends in the same small chain (autograd.GeneratorFn.backward): dL/ds of the
 // contraction, minus the path through the demodulation coefficients (model.py:276-285: d = scale * rsqrt(scale^2 sum_ci s^2 Wsq + eps)),
 // then through the modulation EqualLinear into the layer's latent slot.  Per layer that was 2 transposed contractions with their ordered
-// second stages and 3-5 ATen glue launches -- ~180 launches of 5-10 us in a latent-optimisation step of ~470.  The jobs travel BY VALUE
+// second stages and 3-5 ATen glue launches -- ~170 launches of 5-10 us in an l2-only latent-optimisation step of 472.  The jobs travel BY VALUE
 // in the kernel arguments (a HIP-graph capture bakes them in; the addresses of a captured step are stable under replay).
 struct StyleGradJobs {
     e4s_style_grad_job j[E4S_STYLE_GRAD_MAX_JOBS];
