@@ -144,6 +144,7 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
     import types
     from e4s_amd.train import mse_loss
     driven, dm, target, tm, sm, _noise = one
+    torch.manual_seed(1234)                                 # the per-step noise draws: same sequence in every run of this leg
     for p in net.parameters():
         p.requires_grad = False
     with torch.no_grad():
@@ -164,21 +165,34 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
         fpl.load_state_dict(synth.synth_module_state_dict(fpl, 0, "fp."))
         lpips, idl, fpl = lpips.to(target.device).eval(), idl.to(target.device).eval(), fpl.to(target.device).eval()
 
+    # the three loss networks are independent chains of batch-1 launches: each on its own stream, forked from and joined to the step's
+    # stream inside the capture (e4s_amd.optim.forked_sum; E4S_BENCH_LOSS_STREAMS=0: one stream, for A/B runs -- same loss, same latent)
+    fork = os.environ.get("E4S_BENCH_LOSS_STREAMS", "1") != "0"
+    last = {}
+    from e4s_amd.optim import forked_sum
+
     def body():
         codes = net.cal_style_codes(latent)
         img, _, _ = net.gen_img(None, codes, tm, randomize_noise=True)
         loss = mse_loss(img, target)            # (F.mse_loss's semaphore memset must not sit in the captured step: e4s_amd.train.mse_loss)
         if lpips is not None:
             terms = os.environ.get("E4S_BENCH_TERMS", "lpips,id,parsing").split(",")      # debugging aid: subset of the terms
+            fns = []
             if "lpips" in terms:
-                loss = loss + 0.8 * lpips.forward_pooled(img, target, (1024, 512, 256))
+                fns.append(lambda: 0.8 * lpips.forward_pooled(img, target, (1024, 512, 256)))
             if "id" in terms:
-                loss = loss + 0.1 * idl(img, target)[0]
+                fns.append(lambda: 0.1 * idl(img, target)[0])
             if "parsing" in terms:
-                loss = loss + 0.1 * fpl(img, target)[0]
+                fns.append(lambda: 0.1 * fpl(img, target)[0])
+            if fork:
+                loss = forked_sum(loss, fns, inputs=(img, target))
+            else:
+                for fn in fns:
+                    loss = loss + fn()
         loss.backward()
         opt.step()
-        return loss.detach()
+        last["loss"] = loss.detach()
+        return last["loss"]
     if graphed:
         from e4s_amd.optim import GraphedStep
         gs = GraphedStep(opt, body, warmup=2)       # 2 eager steps, then the step as ONE HIP graph
@@ -190,6 +204,9 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         gs.validate()                               # one-hot masks, finite loss (one sync, untimed)
+        if os.environ.get("E4S_BENCH_PRINT_LOSS") == "1":
+            print("opt leg %s: final loss %.9g, latent checksum %.9g" % (losses, float(last["loss"]), float(latent.detach().double().sum())),
+                  file=sys.stderr, flush=True)
         return round(dt / steps * 1e3, 3)
     for _ in range(2):
         opt.zero_grad(set_to_none=True)

@@ -244,9 +244,10 @@ def test_capturable_adam_and_graphed_step_equal_eager():
     _graphed_equals_eager(256, (256, 128), steps=5)
 
 
-def _graphed_equals_eager(size, lpips_sizes, steps):
+def _graphed_equals_eager(size, lpips_sizes, steps, fork=False):
     """The script's default objective (optimization.py:88-122: l2 + 0.8 LPIPS x scales + 0.1 ID + 0.1 parsing) as ONE replayed
-    HIP graph == the eager loop, bit for bit."""
+    HIP graph == the eager loop, bit for bit.  fork: the captured step runs the three loss networks on three forked streams
+    (optim.forked_sum, as bench.py's config-3 leg does) -- and must still equal the ONE-stream eager loop bit for bit."""
     import types
     from e4s_amd.criteria import FaceParsingLoss, IDLoss, LPIPS
     from e4s_amd.networks import Net3
@@ -274,14 +275,21 @@ def _graphed_equals_eager(size, lpips_sizes, steps):
 
     from e4s_amd.train import mse_loss          # the l2 term as bench.py's captured config-3 step computes it (no ATen global reduce)
 
+    from e4s_amd.optim import forked_sum
+
     def run(graphed):
         latent = sv.clone().requires_grad_(True)
         opt = FusedAdam([latent], lr=1e-2, capturable=True)
 
         def body():
             img, _, _ = net.gen_img(None, net.cal_style_codes(latent), mask, noise=noise)
-            loss = mse_loss(img, target) + 0.8 * lp.forward_pooled(img, target, lpips_sizes) \
-                + 0.1 * idl(img, target)[0] + 0.1 * fpl(img, target)[0]
+            if fork and graphed:
+                loss = forked_sum(mse_loss(img, target), [lambda: 0.8 * lp.forward_pooled(img, target, lpips_sizes),
+                                                          lambda: 0.1 * idl(img, target)[0], lambda: 0.1 * fpl(img, target)[0]],
+                                  inputs=(img, target))
+            else:
+                loss = mse_loss(img, target) + 0.8 * lp.forward_pooled(img, target, lpips_sizes) \
+                    + 0.1 * idl(img, target)[0] + 0.1 * fpl(img, target)[0]
             loss.backward()
             opt.step()
             return loss.detach()
@@ -304,10 +312,12 @@ def _graphed_equals_eager(size, lpips_sizes, steps):
     assert loss_e[-1] < loss_e[0]
 
 
-def test_graphed_four_term_step_equals_eager_at_1024():
+@pytest.mark.parametrize("fork", [False, True])
+def test_graphed_four_term_step_equals_eager_at_1024(fork):
     """the config-3 step bench.py times by default -- l2 + LPIPS(1024, 512, 256) + ID + parsing at 1024^2,
-    captured -- against the eager loop, bitwise."""
-    _graphed_equals_eager(1024, (1024, 512, 256), steps=4)
+    captured (fork: with the three loss networks on three forked streams inside the capture, as bench.py runs it) -- against the
+    one-stream eager loop, bitwise."""
+    _graphed_equals_eager(1024, (1024, 512, 256), steps=6 if fork else 4, fork=fork)
 
 
 def test_plan_path_replays_in_a_graph_with_other_masks_than_the_captured_one(monkeypatch):
