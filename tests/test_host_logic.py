@@ -365,6 +365,25 @@ def test_rowdot_job_record_matches_the_header(tmp_path):
     assert got == [struct.calcsize(K._JOB_FMT), 0, 8, 16, 24, 32, 40, 44, 48, 52] and got[0] == 56
 
 
+def test_style_grad_job_record_matches_the_header(tmp_path):
+    """lib.StyleGradJob (ctypes) mirrors e4s_style_grad_job of include/e4s_hip.h: same size, same field offsets, and the job limit the
+    Python side enforces is the header's (the jobs travel by value in the kernel arguments: 32 of them stay under 4 KB)."""
+    import ctypes
+    import subprocess
+    from e4s_amd import lib
+    fields = [f[0] for f in lib.StyleGradJob._fields_]
+    src = tmp_path / "sg.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "e4s_hip.h"\nint main(void){printf("%zu %d", sizeof(e4s_style_grad_job), '
+                   'E4S_STYLE_GRAD_MAX_JOBS);' + "".join('printf(" %%zu", offsetof(e4s_style_grad_job, %s));' % f for f in fields) +
+                   'printf("\\n");return 0;}\n')
+    exe = tmp_path / "sg"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == ctypes.sizeof(lib.StyleGradJob) and got[1] == lib.STYLE_GRAD_MAX_JOBS
+    assert got[2:] == [getattr(lib.StyleGradJob, f).offset for f in fields]
+    assert got[0] * got[1] + 4 * (got[1] + 1) + 4 + 32 <= 4096          # jobs + block offsets + count + the other arguments of stage 2
+
+
 def test_train_iteration_cadence_follows_the_coach_loop():
     """e4s_amd.train.TrainIteration.iteration = the body of Coach.train() (coach.py:281-398): D step when global_step % d_every ==
     0, R1 only inside a D step and only when d_reg_every != -1 and batch_idx % d_reg_every == 0, one G step every iteration; D is
