@@ -134,6 +134,105 @@ def headline_probe(net, batch, mask, reps):
             "avg_launch_ms": round(ms, 4), "flop_per_launch": flops, "exact_fp32_variant": exact}
 
 
+PEAK_HBM_TBPS = 8.0               # same guide: HBM3E spec (6.3 TB/s is what a float4 copy reaches)
+_TIMED = {"e4s_conv_wino_bf16x3_f32", "e4s_conv_bf16x3_f32", "e4s_conv_region_bf16x3_f32", "e4s_upconv_bf16x3_f32",
+          "e4s_conv_c32_bf16x3_f32"}
+
+
+class LaunchTimer:
+    """HIP events on the launch stream around every native conv launch of an EAGER step (the graph replays exactly these launches):
+    kernels.call is the one door every C-ABI entry point of e4s_amd.kernels goes through.  A record = (entry point, dims of its
+    e4s_conv_params, start event, end event); an entry point that issues a second launch (the region-select fallback behind the
+    variant-rows kernel, a split-K epilogue) is timed with it."""
+
+    def __init__(self):
+        self.recs = []
+
+    def __enter__(self):
+        self._orig = K.call
+        recs = self.recs
+
+        def timed_call(name, *args):
+            if name not in _TIMED:
+                return self._orig(name, *args)
+            q = args[0]._obj
+            dims = {k: int(getattr(q, k)) for k in ("B", "Hi", "Wi", "Ho", "Wo", "Cin", "Cout", "ncls", "istride", "ntaps")}
+            dims["masked"] = bool(q.labels)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self._orig(name, *args)
+            e1.record()
+            recs.append((name, dims, e0, e1))
+            return r
+        K.call = timed_call
+        return self
+
+    def __exit__(self, *exc):
+        K.call = self._orig
+        return False
+
+    def rows(self):
+        torch.cuda.synchronize()
+        return [(n, d, e0.elapsed_time(e1)) for n, d, e0, e1 in self.recs]
+
+
+def step_rooflines(net, inputs, reps=3):
+    """`roofline_dominant`: the kernel that takes the largest share of the timed step -- the encoder's stride-1 3x3 convs on
+    conv_wino_kernel (44 launches per step of 2 x B images) -- as sum of algorithmic FLOP (2 * B * H * W * Cin * Cout * 9 per launch; the
+    kernel executes 2/3 of the direct form's products, three bf16 MFMAs each) / sum of HIP-event time.  `roofline_hbm`: the HBM-bound tail of
+    the generator (the two exact up-convs, 64->64 @512^2, 32->32 @1024^2 with the ToRGB partial) as algorithmic bytes (input once + output
+    once, fp32) / time against the 8 TB/s spec.  Events around each launch of `reps` eager steps after one warm-up step."""
+    def run():
+        face_swap_core(net, *inputs[:5], noise=inputs[5])
+    run()
+    with LaunchTimer() as lt:
+        for _ in range(reps):
+            run()
+    rows = lt.rows()
+    wino = [(d, ms) for n, d, ms in rows if n == "e4s_conv_wino_bf16x3_f32"]
+    out = {}
+    if wino:
+        fl = sum(2.0 * d["B"] * d["Hi"] * d["Wi"] * d["Cin"] * d["Cout"] * 9 for d, _ in wino) / reps
+        ms = sum(m for _, m in wino) / reps
+        shapes = {}
+        for d, m in wino:
+            k = "%d->%d@%d" % (d["Cin"], d["Cout"], d["Hi"])
+            a = shapes.setdefault(k, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += m
+            a[2] += 2.0 * d["B"] * d["Hi"] * d["Wi"] * d["Cin"] * d["Cout"] * 9
+        ach = fl / (ms * 1e-3) / 1e12
+        out["roofline_dominant"] = {
+            "bound": "mfma", "kernel": "conv_wino_kernel (Winograd F(2,3) along the rows, 3x v_mfma_f32_32x32x16_bf16 per product): the "
+                                       "encoder's stride-1 3x3 convs of one step (2 x %d images)" % inputs[0].shape[0],
+            "launches_per_step": len(wino) // reps, "flop_per_step": fl, "ms_per_step": round(ms, 4),
+            "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+            "frac_ceiling": 0.5, "mfma_executed_tflops": round(2 * ach, 1),
+            "frac_of_power_limited_mfma_rate": round(2 * ach / 1780.0, 4),
+            "by_shape": {k: {"launches": a[0] // reps, "ms": round(a[1] / reps, 4), "tflops": round(a[2] / a[1] / 1e9, 1)}
+                         for k, a in shapes.items()}}
+    tail = []
+    for n, d, ms in rows:
+        if n == "e4s_upconv_bf16x3_f32" or n == "e4s_conv_c32_bf16x3_f32" or \
+                (n == "e4s_conv_bf16x3_f32" and not d["masked"] and d["Cin"] <= 64 and d["Hi"] >= 512 and d["istride"] == 1):
+            by = 4.0 * d["B"] * (d["Hi"] * d["Wi"] * d["Cin"] + d["Ho"] * d["Wo"] * d["Cout"])
+            tail.append(("%s %d->%d@%d" % (n.replace("e4s_", "").replace("_bf16x3_f32", ""), d["Cin"], d["Cout"], d["Ho"]), by, ms))
+    if tail:
+        per = {}
+        for k, by, ms in tail:
+            a = per.setdefault(k, [0.0, 0.0])
+            a[0] += by / reps
+            a[1] += ms / reps
+        tb = sum(a[0] for a in per.values())
+        tms = sum(a[1] for a in per.values())
+        out["roofline_hbm"] = {
+            "bound": "hbm", "kernels": {k: {"bytes": a[0], "ms": round(a[1], 4), "TBps": round(a[0] / a[1] / 1e9, 3)} for k, a in per.items()},
+            "achieved": round(tb / tms / 1e9 * 1e3, 1), "peak": PEAK_HBM_TBPS * 1e3, "unit": "GB/s",
+            "frac": round(tb / tms / 1e9 / PEAK_HBM_TBPS, 4), "ms_per_step": round(tms, 4), "bytes_per_step": tb,
+            "traffic": None, "note": "algorithmic bytes = fp32 input once + fp32 output once per launch (weights are < 1 % of either)"}
+    return out
+
+
 def optimisation_leg(net, one, steps, losses="full", graphed=False):
     """BASELINE.json configs[2] (scripts/optimization.py:209-232): Adam(lr=1e-2) on the [1,12,1280] regional style
     vectors through cal_style_codes -> gen_img (fresh noise every step, as the script does).  losses = "full": the
@@ -613,6 +712,10 @@ def main():
         torch.cuda.synchronize()
         out["latency_b1_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
         out["roofline"] = headline_probe(net, B, inputs[4], args.probe_reps)
+        try:
+            out.update(step_rooflines(net, inputs))
+        except Exception as e:      # noqa: BLE001
+            out["roofline_dominant_error"] = f"{type(e).__name__}: {e}"[:300]
         if args.f32_steps > 0 and K.PRECISION != "f32" and not args.no_graph:
             # the same step in exact fp32 (v_mfma_f32_32x32x2_f32 everywhere): a second captured graph under the f32 policy
             saved = K.PRECISION

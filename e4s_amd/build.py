@@ -17,6 +17,11 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+# per-file flags.  conv_region1w.hip: the SLP vectoriser re-packs the scalar f32 multiplies / FMAs of the operand split into v_pk_mul_f32 /
+# v_pk_fma_f32, which cost ~22 cycles each beside MFMAs on gfx950 (guide: "packed f32 VALU ... an anti-lever beside MFMAs")
+PER_FILE_FLAGS = {"conv_region1w.hip": ["-fno-slp-vectorize"]}
+
+
 def _extra_flags():
     """E4S_BUILD_ABLATIONS=1: profiling build whose conv kernels honour E4S_BF16X3_ABL / E4S_UPCONV_ABL (ablated
     variants compute wrong results by construction; never enabled in a product build)."""
@@ -27,6 +32,7 @@ def _extra_flags():
 def _digest():
     h = hashlib.sha256()
     h.update(" ".join(_extra_flags()).encode())
+    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())
     files = sources() + [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "e4s_hip.h")]
     for f in files:
         h.update(f.encode())
@@ -54,7 +60,7 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-               "-I" + CSRC] + _extra_flags() + ["-c", src, "-o", obj]
+               "-I" + CSRC] + _extra_flags() + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -83,7 +89,7 @@ def _build_to(lib, objdir, verbose=False):
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + \
-            _extra_flags() + ["-c", src, "-o", obj]
+            _extra_flags() + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

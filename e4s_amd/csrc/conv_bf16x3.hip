@@ -591,11 +591,16 @@ static_assert(XPIECE * 9 >= XITEMS && XPIECE <= NTHR, "extended halo split");
 // MFMAs, 48 VALU of scale/split per stage and wave), 2 = 4 x 2 waves of 64 x 64 (TM 2, TN 2: 6 MFMAs per fragment, the same rows
 // scaled by both column waves).  SPL: 1 = hand-written split (packed convert, shift/mask re-expansion: 24 VALU per 8 products),
 // 0 = __builtin_convertvector round trip (the compiler converts every element twice: 32 VALU).
-template <int WN_, int SPL>
+// SCAN: the launch BEHIND conv_region_rows_kernel (conv_region.hip): a small grid whose blocks walk the logical block ids b, b + grid, ...
+// and contract only the pixel tiles that kernel flagged (too many variant rows).  On face-parsing masks no tile is flagged and every block
+// leaves after reading a few flags: ~3 us, where a full grid of early-exiting 512-thread / 150 KB-LDS blocks cost 13-17 us per masked layer
+// (0.23 ms of a batch-8 step, 13 launches).
+template <int WN_, int SPL, bool SCAN = false>
 __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv_params p, const int ntn,
                                                                   const int tx_n, const int per_img,
                                                                   const int tiles_per_cls, const int ksplit,
-                                                                  const int cper, const int* __restrict__ only_flagged) {
+                                                                  const int cper, const int* __restrict__ only_flagged,
+                                                                  const int nblocks) {
     constexpr int WN = WN_, WM = NTHR / 64 / WN, TM = BM / (WM * 32), TN = BN / (WN * 32), NG = 2 * TM;
     static_assert(TM * TN == 4 && (NG == 2 || NG == 4), "wave layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -612,12 +617,16 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
 
     // ksplit > 1 (few tiles: batch-1 latency runs): the input-channel chunks are split over ksplit blocks per tile; each
     // stores d[region] * (its partial sum) and a second kernel adds the slabs in order and applies noise / bias / activation
-    const int logical0 = xcd_remap(blockIdx.x, gridDim.x);
+    int scan_b = blockIdx.x;
+  for (;;) {
+    if (SCAN) {
+        while (scan_b < nblocks && !only_flagged[(scan_b / ksplit) / ntn]) scan_b += gridDim.x;
+        if (scan_b >= nblocks) return;
+    }
+    const int logical0 = SCAN ? scan_b : xcd_remap(blockIdx.x, gridDim.x);
     const int ks = logical0 % ksplit;
     const int logical = logical0 / ksplit;
     const int mt = logical / ntn, nt = logical - mt * ntn;
-    // second launch behind conv_region_rows_kernel (conv_region.hip): only the pixel tiles that kernel flagged (too many variant rows)
-    if (only_flagged && !only_flagged[mt]) return;
     const int n0 = nt * BN;
     const int cls = mt / tiles_per_cls;
     const int tt = mt - cls * tiles_per_cls;
@@ -880,13 +889,17 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_region_kernel(const e4s_conv
             }
         }
     }
+    if (!SCAN) return;
+    scan_b += gridDim.x;
+    __syncthreads();               // the next flagged tile re-uses the LDS
+  }
 }
 
 template <int WN_, int SPL>
 int launch_region_v(const e4s_conv_params& p, const int* only_flagged, hipStream_t st) {
-    auto kern = conv_bf16x3_region_kernel<WN_, SPL>;
-    static std::atomic<uint64_t> smem_set{0};
-    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), SMEM_REGION, smem_set)) return e;
+    auto kern = only_flagged ? conv_bf16x3_region_kernel<WN_, SPL, true> : conv_bf16x3_region_kernel<WN_, SPL, false>;
+    static std::atomic<uint64_t> smem_set[2] = {{0}, {0}};
+    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), SMEM_REGION, smem_set[only_flagged ? 1 : 0])) return e;
     const int ntn = p.Cout / BN;
     const int tx_n = (p.Wa + TW - 1) / TW, per_img = ((p.Ha + TH - 1) / TH) * tx_n;
     const int tiles_per_cls = p.B * per_img;
@@ -895,8 +908,10 @@ int launch_region_v(const e4s_conv_params& p, const int* only_flagged, hipStream
     if (ksplit > 1 && !p.splitk_ws) return (int)hipErrorInvalidValue;
     const int64_t blocks = (int64_t)tiles_per_cls * p.ncls * ntn * ksplit;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM_REGION, st, p, ntn, tx_n, per_img, tiles_per_cls,
-                       ksplit, cper, only_flagged);
+    if (blocks >= (1ll << 31)) return (int)hipErrorInvalidValue;
+    const unsigned grid = only_flagged ? (unsigned)(blocks < 256 ? blocks : 256) : (unsigned)blocks;      // scan mode: one block per CU at most
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), SMEM_REGION, st, p, ntn, tx_n, per_img, tiles_per_cls,
+                       ksplit, cper, only_flagged, (int)blocks);
     E4S_CHECK_LAUNCH();
     if (ksplit > 1) {           // slabs already carry d[region]: the second stage adds them and applies noise / bias / act
         e4s_conv_params q = p;

@@ -19,9 +19,12 @@
 // [tap][Cin/16][Cout][16 hi | 16 lo] layout of e4s_split16_bf16x2_f32: a stage's B tile is three contiguous 8 KB runs.
 // Block = 512 threads = 4 x 2 waves of 64 x 64, tile 256 pixels x 128 output channels, one block per CU (128 KB of LDS).
 #include "common.h"
+#include <stdlib.h>
 
 int e4s_launch_region_select(const e4s_conv_params& p, const int* only_flagged, hipStream_t st);      // conv_bf16x3.hip
 void e4s_region_split_policy(const e4s_conv_params& p, int& ksplit, int& cper);                       // conv_bf16x3.hip
+bool e4s_region_rows1w_ok(const e4s_conv_params& p);                                                  // conv_region1w.hip
+int e4s_launch_region_rows1w(const e4s_conv_params& p, const void* w16, int* flags, hipStream_t st, int layout);  // conv_region1w.hip
 
 namespace {
 
@@ -524,6 +527,13 @@ extern "C" int e4s_conv_region_bf16x3_f32(const e4s_conv_params* pp, const void*
     if (blocks <= 0) return 0;
     if (blocks >= (1ll << 31)) return (int)hipErrorInvalidValue;
     int* flags = reinterpret_cast<int*>(p.splitk_ws + (ksplit > 1 ? (size_t)ksplit * p.B * p.Ho * p.Wo * p.Cout : 0));
+    // launches that fill the chip without a K split and have >= 256 output channels: the one-wave-per-SIMD kernel (256 x 256 tiles,
+    // conv_region1w.hip; E4S_REGION_1W=0 keeps this file's kernel: the A/B switch of tools/bench_region.py)
+    static const int use_1w = [] { const char* e = getenv("E4S_REGION_1W"); return e ? atoi(e) : 1; }();
+    if (use_1w && ksplit == 1 && e4s_region_rows1w_ok(p)) {
+        if (int e = e4s_launch_region_rows1w(p, w16, flags, st, use_1w)) return e;
+        return e4s_launch_region_select(p, flags, st);
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), SMEM, st, p, reinterpret_cast<const unsigned char*>(w16), flags,
                        ntn, tx_n, per_img, tiles_per_cls, ksplit, cper * (32 / KC));
     E4S_CHECK_LAUNCH();

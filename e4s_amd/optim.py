@@ -35,7 +35,7 @@ class FusedAdam(torch.optim.Optimizer):
     def sync_hyper(self):
         """Upload every group's learning rate if it changed on the host (one fill launch per changed group; call it OUTSIDE a capture --
         GraphedStep.step() does).  betas / eps / weight_decay travel by value in the launches: a captured graph keeps the values it was
-        captured with, so changing them under a GraphedStep raises instead of being silently ignored."""
+        captured with, so GraphedStep.step() refuses a replay after they changed (hyper_by_value) instead of silently ignoring them."""
         for gi, group in enumerate(self.param_groups):
             d = self._dev.get(gi)
             if d is None:
@@ -43,9 +43,20 @@ class FusedAdam(torch.optim.Optimizer):
             if float(group["lr"]) != d["lr_host"]:
                 d["lr"].fill_(float(group["lr"]))
                 d["lr_host"] = float(group["lr"])
-            hyper = (tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"]))
-            if d.get("captured") and d["hyper"] is not None and d["hyper"] != hyper:
-                raise RuntimeError("FusedAdam: betas / eps / weight_decay changed after a step was captured; re-capture the GraphedStep")
+
+    def hyper_by_value(self):
+        """What a captured step bakes into its kernel arguments besides addresses: (betas, eps, weight_decay) of every group.  GraphedStep
+        compares it before every replay and refuses a change; the optimiser itself never refuses to step (a sticky refusal here
+        blocked eager stepping and the very re-capture the message asked for)."""
+        return tuple((tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])) for g in self.param_groups)
+
+    def load_state_dict(self, state_dict):
+        """torch semantics; the flat step tensors are re-packed by the next step().  A GraphedStep captured before the reload notices the
+        new state addresses in its step() and raises; the optimiser steps eagerly and can be captured again."""
+        super().load_state_dict(state_dict)
+        for d in self._dev.values():
+            d["flat"] = None
+            d["hyper"] = None
 
     def _flat_steps(self, d, plist, device):
         """One int64 tensor holding the step counts of `plist` (state[p]['step'] are views of it).  Re-packed when the state was
@@ -60,11 +71,8 @@ class FusedAdam(torch.optim.Optimizer):
                     ok = False
                     break
         if not ok:
-            if d.get("captured"):
-                # a GraphedStep holds the OLD flat tensor (and the exp_avg / exp_avg_sq addresses) in its kernel arguments: re-packing
-                # here would leave its replays advancing and reading freed memory without any error
-                raise RuntimeError("FusedAdam: the optimiser state changed after a step was captured (load_state_dict, or a parameter "
-                                   "that first received a gradient); re-capture the GraphedStep")
+            # (a GraphedStep captured earlier holds the OLD flat tensor and the exp_avg / exp_avg_sq addresses in its kernel arguments -- and
+            # references to them, so the memory stays valid; its step() compares captured_state_ptrs() and refuses to replay)
             vals = []
             for p in plist:
                 st = self.state[p].get("step", 0)
@@ -125,8 +133,6 @@ class FusedAdam(torch.optim.Optimizer):
                 if not capturing:
                     self.sync_hyper()
                 d["hyper"] = (tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"]))
-                if capturing:
-                    d["captured"] = True          # these values are now baked into a graph's kernel arguments
                 with_state = [p for p in group["params"] if p in self.state and "exp_avg" in self.state[p]]
                 flat = self._flat_steps(d, with_state, dev)
                 if len(live) == len(with_state):
@@ -205,12 +211,19 @@ class GraphedStep:
         self.flags = flags
         self._written = list(opt.written_tensors()) + list(also_written)
         self._state_ptrs = opt.captured_state_ptrs()
+        self._hyper = opt.hyper_by_value()
+        # the graph's kernel arguments point INTO these tensors: holding them keeps the addresses from being handed to anybody else if the
+        # optimiser drops them (load_state_dict), so that a stale replay can only be refused below, never scribble over foreign memory
+        self._state_refs = [d.get("flat") for d in opt._dev.values()] + [t for st in opt.state.values() for t in st.values() if torch.is_tensor(t)]
 
     def step(self):
         self.opt.sync_hyper()                                   # a changed group["lr"] reaches the replay through device memory
         if self.opt.captured_state_ptrs() != self._state_ptrs:
             raise RuntimeError("GraphedStep: the optimiser's state tensors are not the ones this step was captured with "
                                "(load_state_dict / new state after the capture); re-capture the GraphedStep")
+        if self.opt.hyper_by_value() != self._hyper:
+            raise RuntimeError("GraphedStep: betas / eps / weight_decay changed after the step was captured (they travel by value in the "
+                               "captured launches); re-capture the GraphedStep")
         self.graph.replay()
         self.steps_done += 1
         torch.autograd.graph.increment_version(self._written)

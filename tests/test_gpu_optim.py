@@ -177,6 +177,30 @@ def test_graphed_step_reads_the_learning_rate_from_device_memory():
     og.load_state_dict(copy.deepcopy(og.state_dict()))
     with pytest.raises(RuntimeError, match="re-capture"):
         gs.step()
+    # ... and the suggested re-capture WORKS with the same optimiser (the refusal used to be sticky inside FusedAdam: the new
+    # GraphedStep's warm-up steps raised again, and so did plain eager stepping).  Eager twin: the same state, stepped eagerly.
+    wg2 = og.param_groups[0]["params"][0]
+    w2 = wg2.detach().clone().requires_grad_(True)
+    opt2 = FusedAdam([w2], lr=og.param_groups[0]["lr"], capturable=True)
+    sd2 = copy.deepcopy(og.state_dict())
+    opt2.load_state_dict(sd2)
+
+    def body2():
+        loss = ((wg2 * x - 1.0) ** 2).sum()
+        loss.backward()
+        og.step()
+        return loss.detach()
+    gs2 = GraphedStep(og, body2, warmup=1)            # 1 eager step on the reloaded optimiser, then a fresh capture
+    for _ in range(3):
+        gs2.step()
+    for _ in range(4):
+        opt2.zero_grad(set_to_none=True)
+        loss = ((w2 * x - 1.0) ** 2).sum()
+        loss.backward()
+        opt2.step()
+    assert torch.equal(wg2.detach(), w2.detach()), float((wg2.detach() - w2.detach()).abs().max())
+    with pytest.raises(RuntimeError, match="re-capture"):
+        gs.step()                                     # the OLD graph stays refused
 
 
 def test_optimisation_step_gradients_are_bit_reproducible():
