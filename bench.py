@@ -96,7 +96,7 @@ def headline_probe(net, batch, mask, reps):
             # the PMC figure belongs to ONE version of the kernel: keyed on a hash of its source, so that it cannot go stale silently
             import hashlib
             rows = traffic.get("bf16x3_rows", {})
-            src = os.path.join(ROOT, rows.get("kernel_source", "e4s_amd/csrc/conv_region.hip"))
+            src = os.path.join(ROOT, rows.get("kernel_source", "e4s_amd/csrc/conv_region1w.hip"))
             if hashlib.sha256(open(src, "rb").read()).hexdigest() != rows.get("kernel_source_sha256"):
                 traffic_stale = True
         except Exception:
@@ -119,6 +119,8 @@ def headline_probe(net, batch, mask, reps):
         extra["w_split16"] = layer.conv.split_weights16()
         name = "conv_region_rows_kernel"
     ms, ach = timed(extra)
+    if sg2.REGION_ROWS and K.LAST_REGION_PATH == 2:
+        name = "conv_region_rows1w_kernel<2 x 2 waves, one per SIMD, 256 x 256 tile>"
     return {"bound": "mfma", "kernel": name + " (3x v_mfma_f32_32x32x16_bf16 per product) " + what,
             "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "frac_ceiling": round(1.0 / 3.0, 4),
@@ -231,6 +233,47 @@ def step_rooflines(net, inputs, reps=3):
             "frac": round(tb / tms / 1e9 / PEAK_HBM_TBPS, 4), "ms_per_step": round(tms, 4), "bytes_per_step": tb,
             "traffic": None, "note": "algorithmic bytes = fp32 input once + fp32 output once per launch (weights are < 1 % of either)"}
     return out
+
+
+def gather_contention_leg(step, steps, world_equiv=8, payload_per_rank=8 * 1024 * 1024 * 3):
+    """What the all-gather of N = world_equiv ranks can cost a rank's step in CU / HBM contention, bounded on ONE GPU: beside every timed
+    step a side stream lands (world_equiv - 1) x payload_per_rank bytes (the peers' uint8 shards: 7 x 25 MB per step at N = 8) in a
+    gather-sized buffer with RCCL-shaped copy kernels -- a few persistent workgroups (e4s_stream_copy_u8: `blocks` of 512 threads), not
+    the hundreds a torch copy would launch.  This over-counts RCCL's receive side (peers' writes over xGMI occupy no CU of the receiver
+    for the direct-write protocols; the ring / LL protocols copy through local workgroups as modelled here) and adds the HBM write
+    traffic of the real gather, so the ratio is an upper bound on the efficiency loss from contention; wire time and barrier skew are
+    not in it."""
+    from e4s_amd.lib import call, ptr
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nbytes = (world_equiv - 1) * payload_per_rank
+    src = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
+    dst = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    side = torch.cuda.Stream()
+
+    def timed(blocks):
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if blocks:
+                side.wait_stream(torch.cuda.current_stream())     # the gather of step i - 1 starts when step i starts (OverlappedGather)
+                call("e4s_stream_copy_u8", ptr(src), ptr(dst), nbytes, blocks, ctypes_stream(side))
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    base = timed(0)
+    out = {"world_equiv": world_equiv, "bytes_per_step": nbytes, "ms_per_step_alone": round(base, 3)}
+    for blocks in (8, 32, 64):
+        ms = timed(blocks)
+        out["ms_per_step_with_%d_copy_workgroups" % blocks] = round(ms, 3)
+        out["efficiency_bound_%d" % blocks] = round(base / ms, 4)
+    return out
+
+
+def ctypes_stream(stream):
+    import ctypes
+    return ctypes.c_void_p(stream.cuda_stream)
 
 
 def optimisation_leg(net, one, steps, losses="full", graphed=False):
@@ -744,6 +787,8 @@ def main():
                 out.update(res if key is None else {key: res})
             except Exception as e:      # noqa: BLE001
                 out[(key or "config3") + "_error"] = f"{type(e).__name__}: {e}"[:300]
+        if graphed is not None:
+            side("gather_contention", lambda: gather_contention_leg(step, args.steps))
         side("gpen512", lambda: gpen_leg(dev))
         side("stitch_b8", lambda: stitch_leg(net, inputs))
         if args.train_steps > 0:

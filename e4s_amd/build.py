@@ -17,9 +17,9 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-# per-file flags.  conv_region1w.hip: the SLP vectoriser re-packs the scalar f32 multiplies / FMAs of the operand split into v_pk_mul_f32 /
+# per-file flags.  conv_region1w.hip / conv_wino1w.hip: the SLP vectoriser re-packs the scalar f32 multiplies / FMAs of the operand split into v_pk_mul_f32 /
 # v_pk_fma_f32, which cost ~22 cycles each beside MFMAs on gfx950 (guide: "packed f32 VALU ... an anti-lever beside MFMAs")
-PER_FILE_FLAGS = {"conv_region1w.hip": ["-fno-slp-vectorize"]}
+PER_FILE_FLAGS = {"conv_region1w.hip": ["-fno-slp-vectorize"], "conv_wino1w.hip": ["-fno-slp-vectorize"]}
 
 
 def _extra_flags():

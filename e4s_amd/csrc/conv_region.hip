@@ -509,6 +509,18 @@ extern "C" int64_t e4s_conv_region_ws_floats(const e4s_conv_params* pp) {
     return (ksplit > 1 ? (int64_t)ksplit * p.B * p.Ho * p.Wo * p.Cout : 0) + tiles;        // [split-K slabs][tile flags]
 }
 
+static int region_1w_mode() {
+    static const int m = [] { const char* e = getenv("E4S_REGION_1W"); return e ? atoi(e) : 1; }();
+    return m;
+}
+
+extern "C" int e4s_conv_region_path(const e4s_conv_params* pp) {
+    if (!pp || !region_rows_ok(*pp)) return 0;
+    int ksplit, cper;
+    e4s_region_split_policy(*pp, ksplit, cper);
+    return (region_1w_mode() && ksplit == 1 && e4s_region_rows1w_ok(*pp)) ? 2 : 1;
+}
+
 extern "C" int e4s_conv_region_bf16x3_f32(const e4s_conv_params* pp, const void* w16, void* stream) {
     const e4s_conv_params& p = *pp;
     if (!region_rows_ok(p)) return (int)hipErrorInvalidValue;
@@ -529,7 +541,7 @@ extern "C" int e4s_conv_region_bf16x3_f32(const e4s_conv_params* pp, const void*
     int* flags = reinterpret_cast<int*>(p.splitk_ws + (ksplit > 1 ? (size_t)ksplit * p.B * p.Ho * p.Wo * p.Cout : 0));
     // launches that fill the chip without a K split and have >= 256 output channels: the one-wave-per-SIMD kernel (256 x 256 tiles,
     // conv_region1w.hip; E4S_REGION_1W=0 keeps this file's kernel: the A/B switch of tools/bench_region.py)
-    static const int use_1w = [] { const char* e = getenv("E4S_REGION_1W"); return e ? atoi(e) : 1; }();
+    const int use_1w = region_1w_mode();
     if (use_1w && ksplit == 1 && e4s_region_rows1w_ok(p)) {
         if (int e = e4s_launch_region_rows1w(p, w16, flags, st, use_1w)) return e;
         return e4s_launch_region_select(p, flags, st);

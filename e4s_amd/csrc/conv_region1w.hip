@@ -154,6 +154,8 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
     int* s_misc = reinterpret_cast<int*>(smem + OFF_MISC);
 
     const int tid = threadIdx.x;
+    [[maybe_unused]] unsigned long long tstamp[5];
+    if (VAR == 9) tstamp[0] = __builtin_amdgcn_s_memtime();
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -194,9 +196,11 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
         if (PFD == 2) pbs[0][j] = *reinterpret_cast<const f32x4*>(wb + 3 * wtap + (w_voff + j * (NTHR * 16)));
     }
     if (p.out_scale) {
+        // stored as [region][column wave][lane][tn]: a lane's TN = 4 coefficients of a row are ONE 16-byte LDS read in the epilogue
         for (int t = tid; t < R * BN; t += NTHR) {
             const int r = t / BN, n = t - r * BN;
-            sD[t] = p.out_scale[((size_t)tb * R + r) * p.Cout + n0 + n];
+            const int cw = n / (TN * 32), tn = (n / 32) % TN, l = n % 32;
+            sD[((r * WN + cw) * 32 + l) * TN + tn] = p.out_scale[((size_t)tb * R + r) * p.Cout + n0 + n];
         }
     }
 
@@ -275,6 +279,7 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
     }
     __syncthreads();
 
+    if (VAR == 9) tstamp[1] = __builtin_amdgcn_s_memtime();
     // ---- 4: per-lane LDS row of each (pixel, tap) pair; per-thread staging items ----
     int ro[TM][9];
 #pragma unroll
@@ -365,6 +370,7 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
     Af[0].h = *reinterpret_cast<const bf16x8*>(sA + ro[0][0]);
     Af[0].l = *reinterpret_cast<const bf16x8*>(sA + (ro[0][0] ^ 32));
 
+    if (VAR == 9) tstamp[2] = __builtin_amdgcn_s_memtime();
     f32x8 ix[2], is[2];            // staging items in flight (x, style); two waves per SIMD: only [0]
     unsigned hp[4], lp[4];         // hi / lo halves of the item being stored (built over several segments)
     const int dummy = OFF_DUMMY + lane * ROWB;
@@ -394,8 +400,8 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
             const unsigned char* Anx = t == 8 ? An : Ab;
             const int tnx = (t + 1) % 9;
             const int it = t - 1 >= 0 && t - 1 < NIT ? t - 1 : 0;
-            const bool st_item = t >= 1 && t <= NIT && (VAR < 2 || VAR == 6);
-            const bool ld_item = t < NIT && (VAR < 2 || VAR == 6);
+            const bool st_item = t >= 1 && t <= NIT && (VAR < 2 || VAR == 6 || VAR == 9);
+            const bool ld_item = t < NIT && (VAR < 2 || VAR == 6 || VAR == 9);
             const int li_ = t < NIT ? t : 0;
             const int ib = TM > 2 ? (it & 1) : 0, lb = TM > 2 ? (t & 1) : 0;       // register set of the item stored / fetched in this tap
             int d_item = 0;
@@ -433,7 +439,8 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
             // slot n of the tap = what rides behind its n-th MFMA (12 TM slots): at most ONE LDS / global instruction plus a few VALU
             auto slot = [&](int n) {
                 if (VAR >= 2 && VAR <= 4) return;
-                constexpr bool B_ST = VAR < 2 || VAR == 5 || VAR == 8, B_LD = VAR < 2 || VAR == 5 || VAR == 7, ITEMS = VAR < 2 || VAR == 6;
+                constexpr bool B_ST = VAR < 2 || VAR == 5 || VAR == 8 || VAR == 9, B_LD = VAR < 2 || VAR == 5 || VAR == 7 || VAR == 9,
+                               ITEMS = VAR < 2 || VAR == 6 || VAR == 9;
                 if (TM > 2) {                                    // 48 slots
                     if (B_ST && n >= 2 && n < 2 + BJ) b_store(n - 2);
                     if (B_LD && n >= 6 && n < 6 + BJ) {
@@ -507,6 +514,7 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
         }
     }
 
+    if (VAR == 9) tstamp[3] = __builtin_amdgcn_s_memtime();
     // ---- epilogue: d[region][co] * acc + noise + bias, activation, NHWC store ----
     float bsv[TN];
 #pragma unroll
@@ -524,11 +532,10 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
                 const int r = 4 * g + i;
                 const int row = (wm * TM + tm) * 32 + i + 8 * g + 4 * kh;
                 const float nz = s_nz[row];
-                const float* drow = sD + s_grp[row] * BN;
+                const f32x4 d4 = scaled ? *reinterpret_cast<const f32x4*>(sD + ((s_grp[row] * WN + wn) * 32 + li) * TN) : f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
-                    const int ncol = (wn * TN + tn) * 32 + li;
-                    float t = acc[tm][tn][r] * (scaled ? drow[ncol] : 1.f);
+                    float t = acc[tm][tn][r] * d4[tn];
                     t += nz + bsv[tn];
                     if (do_act) t = (t > 0.f ? t : t * p.alpha) * gain;
                     v[tn][i] = t;
@@ -544,6 +551,13 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
                         f32x4{v[tn][0], v[tn][1], v[tn][2], v[tn][3]};
             }
         }
+    }
+    if (VAR == 9) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tstamp[4] = __builtin_amdgcn_s_memtime();
+        if ((blockIdx.x == 0 || blockIdx.x == 100) && (tid == 0 || tid == 192))
+            printf("1w block %d wave %d: analysis %llu, rows+frags %llu, loop %llu, epilogue %llu cycles\n", (int)blockIdx.x, tid >> 6,
+                   tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3]);
     }
 }
 
@@ -570,6 +584,7 @@ static int launch1w(const e4s_conv_params& p, const void* w16, int* flags, hipSt
         case 6: kern = conv_region_rows1w_kernel<6, WM, WN>; break;
         case 7: kern = conv_region_rows1w_kernel<7, WM, WN>; break;
         case 8: kern = conv_region_rows1w_kernel<8, WM, WN>; break;
+        case 9: kern = conv_region_rows1w_kernel<9, WM, WN>; break;
         default: break;
     }
     if (int e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM)) return e;

@@ -34,6 +34,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
+int e4s_launch_wino1w(const e4s_conv_params& p, int ntn, int tx_n, int per_img, int ntiles, int grid, hipStream_t st);      // conv_wino1w.hip
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -750,6 +752,15 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
 #undef WV
     }
 #endif
+    // launches without a K split and with >= 16 chunks per tile (Cin >= 256): the one-wave-per-SIMD kernel (conv_wino1w.hip).  Measured
+    // (profiles/r06_wino1w.json, 16 images, InstanceNorm+PReLU form / statistics form): 512 -> 512 @32^2 -6.4 / -7.5 %, 256 -> 256 @64^2 -6.5 / -6 %,
+    // 256 -> 512 @64^2 -6 / -4 %; 128 -> 128 @128^2 -1 / +2 %, 64 -> 128 @256^2 +4 / +5 % (short tiles: its register epilogue is not covered by a
+    // SIMD partner).  E4S_WINO_1W = 0 / 1 forces one of them (read per launch, so that a test can run both in one process)
+    {
+        const char* e1 = getenv("E4S_WINO_1W");
+        const bool want = e1 ? atoi(e1) != 0 : p.Cin / KC >= 16;
+        if (ksplit == 1 && want) return e4s_launch_wino1w(p, ntn, tx_n, per_img, (int)tiles, (int)grid, as_stream(stream));
+    }
     // wave tile (see the kernel): 64 x 64 x two positions where a tile has enough K stages to pay for the exchange in its epilogue
     // (E4S_WINO_WT = 0 / 1 forces one of them: read per launch, so that a test can run both in one process)
     const char* wt_env = getenv("E4S_WINO_WT");

@@ -206,6 +206,22 @@ extern "C" int e4s_create_masks_f32(const float* mask, float* border, float* ful
     return 0;
 }
 
+// A copy with a CHOSEN number of workgroups: the stand-in for the RCCL kernels that land the peers' shards in a rank's all-gather output
+// (bench.py `gather_contention`: RCCL moves data with a few persistent workgroups per channel, which share the CUs with the step's own
+// persistent one-block-per-CU kernels; with one reachable GPU that term of the N = 8 efficiency can only be bounded this way).
+__global__ __launch_bounds__(512) void stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int e4s_stream_copy_u8(const void* src, void* dst, int64_t bytes, int blocks, void* stream) {
+    if (!src || !dst || bytes < 0 || bytes % 16 || blocks <= 0) return (int)hipErrorInvalidValue;
+    if (bytes == 0) return 0;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), reinterpret_cast<const uint4*>(src),
+                       reinterpret_cast<uint4*>(dst), bytes / 16);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int e4s_tensor2im_u8(const float* img, uint8_t* out, int B, int H, int W, void* stream) {
     const int64_t hw = (int64_t)H * W, n = (int64_t)B * hw;
     if (n <= 0) return 0;

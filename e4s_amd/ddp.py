@@ -50,7 +50,14 @@ def notify_grad(param, grad):
 
 
 class GradAverager:
-    def __init__(self, params, group=None, bucket_mb=64, force=None):
+    def __init__(self, params, group=None, bucket_mb=64, force=None, payload_dtype=torch.float32):
+        """payload_dtype: what travels over xGMI.  torch.float32 (default; what torch DDP sends for the reference, which trains fp32) or
+        torch.bfloat16 -- BASELINE.json configs[4] names bf16: the staging copies round the fp32 gradients to bf16 (RNE), the all-reduce
+        sums bf16 (322 MB instead of 644 MB per G step with the generator), the averages are widened back into the fp32 .grad tensors;
+        master weights, Adam moments and the local gradient accumulation stay fp32."""
+        if payload_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("GradAverager: payload_dtype is torch.float32 or torch.bfloat16")
+        self.payload_dtype = payload_dtype
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -58,7 +65,7 @@ class GradAverager:
             from . import shard
             force = shard._FORCE                         # E4S_FORCE_COLLECTIVES=1
         self.active = self.world > 1 or (bool(force) and dist.is_initialized())
-        cap = int(bucket_mb * (1 << 20) // 4)
+        cap = int(bucket_mb * (1 << 20) // (4 if payload_dtype == torch.float32 else 2))
         self.buckets, cur, n = [], [], 0
         for p in reversed(self.params):                  # backward finishes the LAST layers first
             if cur and n + p.numel() > cap:
@@ -96,7 +103,7 @@ class GradAverager:
         bucket = self.buckets[i]
         dev = bucket[0].device
         if self._flat[i] is None or self._flat[i].device != dev:
-            self._flat[i] = torch.empty(sum(p.numel() for p in bucket), device=dev, dtype=torch.float32)
+            self._flat[i] = torch.empty(sum(p.numel() for p in bucket), device=dev, dtype=self.payload_dtype)
         return self._flat[i]
 
     def _staged_on_current_stream(self, i, dev):
@@ -190,7 +197,10 @@ class GradAverager:
                         flat[o:o + p.numel()].zero_()
                     else:
                         flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
-                self._fire(i)                            # (the copies above ran on the current stream, the one it fires from)
+                # these copies ran on the CURRENT stream, which need not be the stream arm() ran on (the one every bucket is issued
+                # from): announce it like a hook's staging copy, so that _fire joins it first
+                self._staged_on_current_stream(i, flat.device)
+                self._fire(i)
             self._next = len(self.buckets)
             for i, bucket in enumerate(self.buckets):
                 self._works[i].wait()
@@ -200,7 +210,7 @@ class GradAverager:
                     _, o = self._where[id(p)]
                     g = flat[o:o + p.numel()].view_as(p)
                     if p.grad is None:
-                        p.grad = g.clone()
+                        p.grad = g.to(p.dtype) if g.dtype != p.dtype else g.clone()     # (a bf16 payload widens back into an fp32 .grad)
                     else:
                         p.grad.copy_(g)
         self._sent, self._works = set(), [None] * len(self.buckets)

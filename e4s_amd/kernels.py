@@ -372,6 +372,8 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
                 raise RuntimeError("e4s_conv_region_bf16x3_f32 does not cover this contraction")
             skws = torch.empty(nws, device=x.device, dtype=torch.float32)
             p.splitk_ws = fptr(skws)
+            global LAST_REGION_PATH
+            LAST_REGION_PATH = lib.load().e4s_conv_region_path(ctypes.byref(p))     # 1: 8-wave kernel, 2: one wave per SIMD (tests / bench)
             call("e4s_conv_region_bf16x3_f32", ctypes.byref(p), ptr(w_split16), stream())
             return y
         nws = lib.load().e4s_conv_bf16x3_ws_floats(ctypes.byref(p))        # split-K partial sums (few-tile launches)
@@ -456,6 +458,8 @@ def split16_bf16x2(w, out=None):
     return out
 
 
+REGION_1W = os.environ.get("E4S_REGION_1W", "1") != "0"        # mirrors the library's switch (csrc/conv_region.hip)
+LAST_REGION_PATH = 0           # which kernel the last masked launch took (e4s_conv_region_path)
 WINO = os.environ.get("E4S_WINO", "1") == "1"        # policy switch of the Winograd F(2,3) kernel (encoders._conv3x3)
 
 

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E4S_LIB_PATH") or os.path.join(_HERE, "libe4s_hip.so")      # (E4S_LIB_PATH: A/B runs of two builds)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -89,6 +89,7 @@ SIGNATURES = {
     "e4s_split_bf16x2_f32": [c_p, c_p, c_l, c_i, c_p],
     "e4s_conv_region_bf16x3_f32": [ctypes.POINTER(ConvParams), c_p, c_p],
     "e4s_conv_region_ws_floats": [ctypes.POINTER(ConvParams)],
+    "e4s_conv_region_path": [ctypes.POINTER(ConvParams)],
     "e4s_split16_bf16x2_f32": [c_p, c_p, c_l, c_i, c_i, c_p],
     "e4s_upconv_blocks_per_cu": [],
     "e4s_instnorm_ws_doubles": [c_i, c_i, c_i],
@@ -182,6 +183,7 @@ SIGNATURES = {
     "e4s_morph_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_create_masks_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_tensor2im_u8": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "e4s_stream_copy_u8": [c_p, c_p, ctypes.c_int64, c_i, c_p],
     "e4s_paste_u8": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "e4s_grouped_linear_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p],
     "e4s_adaptive_pool_f32": [c_p, c_p] + [c_i] * 11 + [c_p, c_p, c_p],

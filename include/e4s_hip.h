@@ -205,9 +205,13 @@ int e4s_split_bf16x2_f32(const float* w, void* out, int64_t rows, int cin, void*
  * rows, and launches of <= 128 tiles that split K, run on the region-select kernel); w16 = the e4s_split16_bf16x2_f32 image of
  * the same tap-packed weights; p->splitk_ws = e4s_conv_region_ws_floats(p) floats of scratch (tile flags or split-K slabs).
  * e4s_split16_bf16x2_f32: w fp32 [rows][Cout][Cin] (rows = ncls * 9) -> out [rows][Cin/16][Cout][16 hi bf16 | 16 lo bf16]
- * (same byte size), Cin % 16 == 0. */
+ * (same byte size), Cin % 16 == 0.
+ * Which kernel a launch takes (host-side policy, no launch; ABI v12): e4s_conv_region_path(p) = 0 not covered, 1 the 8-wave kernel
+ * (256 pixels x 128 channels per block, two waves per SIMD; with a K split for launches of <= 128 tiles), 2 the one-wave-per-SIMD
+ * kernel (csrc/conv_region1w.hip: 256 x 256 tiles, 16 accumulator tiles per wave; Cout % 256 == 0 and no K split). */
 int e4s_conv_region_bf16x3_f32(const e4s_conv_params* p, const void* w16, void* stream);
 int64_t e4s_conv_region_ws_floats(const e4s_conv_params* p);
+int e4s_conv_region_path(const e4s_conv_params* p);
 int e4s_split16_bf16x2_f32(const float* w, void* out, int64_t rows, int cout, int cin, void* stream);
 
 /* ---- backward of the fused generator (configs 3 and 5) -------------------- */
@@ -499,6 +503,9 @@ int e4s_create_masks_f32(const float* mask, float* border, float* full, float* w
 /* tensor2im (src/utils/torch_utils.py:63-69): NCHW fp32 [B,3,H,W] in [-1,1] -> HWC uint8 [B,H,W,3] (4x fewer bytes to
  * all-gather than the fp32 image) */
 int e4s_tensor2im_u8(const float* img, uint8_t* out, int B, int H, int W, void* stream);
+/* copy `bytes` (multiple of 16) with exactly `blocks` persistent 512-thread workgroups: the measurement stand-in for the RCCL copy kernels
+ * that land the peers' all-gather shards on a rank (bench.py `gather_contention`; ABI v12) */
+int e4s_stream_copy_u8(const void* src, void* dst, int64_t bytes, int blocks, void* stream);
 /* out = uint8(face * m + target * (1 - m)), m = bilinear(align_corners=False) resize of mask [B,Hm,Wm] to [H,W]
  * (scripts/face_swap.py:291-292,301-303); face/target/out HWC uint8 [B,H,W,3] */
 int e4s_paste_u8(const uint8_t* face, const uint8_t* target, const float* mask, uint8_t* out, int B, int H, int W,

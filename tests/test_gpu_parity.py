@@ -313,7 +313,11 @@ def _region_case(b, h, w, cin, cout, up, kind, R=12, seed=41):
     (2, 64, 64, 64, 128, False, "noise", 12), (2, 64, 64, 64, 128, False, "half-noise", 12), (2, 32, 48, 64, 128, False, "blocks", 16),
     (3, 128, 128, 128, 128, False, "face", 12),
     # launches of <= 128 tiles: the input channels split over blocks (slabs + second stage), variant rows inside each split
-    (1, 32, 32, 512, 512, False, "face", 12), (1, 16, 16, 512, 256, True, "blocks", 12), (2, 64, 64, 256, 128, False, "half-noise", 12)])
+    (1, 32, 32, 512, 512, False, "face", 12), (1, 16, 16, 512, 256, True, "blocks", 12), (2, 64, 64, 256, 128, False, "half-noise", 12),
+    # Cout % 256 == 0 and > 128 tiles without a K split: the one-wave-per-SIMD kernel (csrc/conv_region1w.hip; "1w" = asserted below):
+    # one and two column tiles, polyphase with partial tiles, 16 regions, a map that overflows the variant rows on one side
+    (8, 64, 64, 64, 256, False, "face", 12), (5, 64, 64, 96, 512, False, "blocks", 12), (3, 48, 40, 64, 256, True, "face", 12),
+    (11, 32, 48, 64, 256, False, "blocks", 16), (8, 64, 64, 64, 256, False, "half-noise", 12), (5, 33, 49, 32, 256, False, "face", 12)])
 def test_region_rows_kernel_vs_fp32_and_region_select(b, h, w, cin, cout, up, kind, R):
     """e4s_conv_region_bf16x3_f32 (variant rows: the halo scaled with each pixel's own region's style once, boundary pairs read extra
     rows) on masked StyledConv contractions, plain and polyphase, ragged maps, 16 regions: == the exact fp32 region kernel to 1e-4
@@ -324,6 +328,10 @@ def test_region_rows_kernel_vs_fp32_and_region_select(b, h, w, cin, cout, up, ki
     x, wt, kw = _region_case(b, h, w, cin, cout, up, kind, R)
     ws, ws16 = K.split_bf16x2(wt), K.split16_bf16x2(wt)
     y = K.conv_mfma(x, wt, cout, w_split=ws, w_split16=ws16, **kw)
+    # the kernel this case is here for (the K-split policy of csrc/conv_bf16x3.hip:few_tiles_split restated)
+    tiles, nchunk = b * ((h + 15) // 16) * ((w + 15) // 16) * (4 if up else 1) * (cout // 128), cin // 32
+    ksplit = tiles <= 128 and nchunk >= 4 and min(-(-256 // tiles), nchunk // 2) >= 2
+    assert K.LAST_REGION_PATH == (2 if (cout % 256 == 0 and not ksplit and K.REGION_1W) else 1)
     assert torch.equal(y, K.conv_mfma(x, wt, cout, w_split=ws, w_split16=ws16, **kw))
     ref = K.conv_mfma(x, wt, cout, **kw)
     sel = K.conv_mfma(x, wt, cout, w_split=ws, **kw)
@@ -1355,18 +1363,25 @@ def test_f32_conv_split_k_small_maps(cin, cout, h, w, stride):
                                                  (3, 64, 32, 64, 256, "in_prelu"), (1, 128, 128, 128, 128, "stats"),
                                                  (2, 16, 16, 96, 128, "bias_lrelu"),
                                                  # more tiles than CUs: the persistent blocks walk 2-3 tiles each, across samples
-                                                 (3, 256, 256, 64, 128, "in_prelu"), (5, 128, 128, 128, 128, "stats"), (9, 96, 96, 32, 256, "plain")])
-@pytest.mark.parametrize("wave_tile", [0, 1])
+                                                 (3, 256, 256, 64, 128, "in_prelu"), (5, 128, 128, 128, 128, "stats"), (9, 96, 96, 32, 256, "plain"),
+                                                 # > 128 tiles of >= 16 chunks: what the policy gives the one-wave-per-SIMD kernel
+                                                 (5, 64, 64, 256, 256, "in_prelu"), (5, 64, 64, 256, 256, "stats"), (3, 96, 96, 512, 128, "bias_lrelu")])
+@pytest.mark.parametrize("wave_tile", [0, 1, "1w"])
 def test_winograd_f23_conv_vs_fp64(b, h, w, cin, cout, mode, wave_tile, monkeypatch):
-    """wave_tile: both forms of the kernel on every shape (0: a wave owns 64 x 32 of all four positions; 1, round 5: 64 x 64 of two positions,
-    one position exchanged between the waves of a pair in the epilogue -- the policy picks it for the 512-channel layers only).
+    """wave_tile: every form of the kernel on every shape (0: a wave owns 64 x 32 of all four positions; 1, round 5: 64 x 64 of two positions,
+    one position exchanged between the waves of a pair in the epilogue -- the policy picks it for the 512-channel layers only; "1w", round 6:
+    csrc/conv_wino1w.hip, four waves of 64 x 64 x four positions, one per SIMD -- launches without a K split; split launches stay on 0 / 1).
     e4s_conv_wino_bf16x3_f32 (Winograd F(2,3) along the rows, split-bf16 MFMAs) vs F.conv2d in fp64 on the same operands: plain,
     with the InstanceNorm folded into the input transform + PReLU epilogue (the encoder unit's first conv, helpers.py:128-133), with the
     fused output statistics + SE gate (its second conv), with bias + leaky ReLU (the loss networks' convs).  Bound 3e-5 of the output
     scale (measured ~8e-6: 1.7x the direct split-bf16 kernel), statistics 2e-6 relative; bit-reproducible."""
     import torch.nn.functional as F
     from e4s_amd import kernels as K
-    monkeypatch.setenv("E4S_WINO_WT", str(wave_tile))
+    if wave_tile == "1w":
+        monkeypatch.setenv("E4S_WINO_1W", "1")
+    else:
+        monkeypatch.setenv("E4S_WINO_1W", "0")
+        monkeypatch.setenv("E4S_WINO_WT", str(wave_tile))
     g = torch.Generator().manual_seed(h * 7 + cin)
     x = torch.randn(b, cin, h, w, generator=g) * 1.3 + 0.4
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)

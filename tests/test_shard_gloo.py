@@ -195,6 +195,22 @@ def _worker_ddp(rank, world, port, q):
         if not p.requires_grad:
             continue
         ok = ok and p.grad is not None and bool(torch.allclose(p.grad, w, atol=1e-6, rtol=1e-5))
+    # configs[4] "bf16": the same averaging with a bf16 payload (half the bytes on the wire; fp32 gradients on both ends): every rank
+    # rounds its gradient to bf16 (2^-9 relative), the sum is rounded once more -> within 2^-7 of the tensor's scale, and identical on both ranks
+    model.zero_grad()
+    torch.nn.functional.mse_loss(model(x[lo:hi]), y[lo:hi]).backward()
+    if rank == 1:
+        model[2].bias.grad = None
+    avg16 = GradAverager(model.parameters(), bucket_mb=0.02, payload_dtype=torch.bfloat16)
+    ok = ok and len(avg16.buckets) >= 2 and avg16._buffer(0).dtype == torch.bfloat16
+    avg16.average()
+    flat16 = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad])
+    for p, w in zip(model.parameters(), want):
+        if p.requires_grad:
+            ok = ok and p.grad.dtype == torch.float32 and float((p.grad - w).abs().max()) <= 2 ** -7 * float(w.abs().max())
+    gathered = [torch.empty_like(flat16) for _ in range(world)]
+    dist.all_gather(gathered, flat16)
+    ok = ok and all(torch.equal(gathered[0], g_) for g_ in gathered)
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
