@@ -431,7 +431,7 @@ def stitch_leg(net, inputs, reps=10):
     return out
 
 
-def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3, train_G=True, time_d=True):
+def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3, train_G=True, time_d=True, bf16=False):
     """BASELINE.json configs[4] on ONE GPU -- the body of Coach.train() (coach.py:280-398) through e4s_amd.train.TrainIteration:
     G step = Net3.forward (train_G=True, the reference's default, train_options.py:32-33 / coach.py:324-331: encoder + LocalMLPs +
     the generator's convs[:K] / ToRGBs / constant input trainable, the mapping network and the layers past K frozen; train_G=False:
@@ -441,7 +441,10 @@ def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3, train_G=True
     backward through the HIP loss-network / generator / MLP / encoder kernels -> fused Adam -> EMA of the weights;
     D step (every d_every = 15th iteration) = Net3 forward without a graph + D(real) + D(fake) + AdvDLoss backward + fused
     Adam on D; R1 step (d_reg_every; off by default in the reference, timed here at 16) = the second-order pass.
-    `ms_per_step` is the G step (every iteration runs one); `ms_per_iteration_amortised` adds d_step / 15.
+    `ms_per_step` is the G step (every iteration runs one); `ms_per_iteration_amortised` adds d_step / 15.  The D and R1 steps are
+    replayed as HIP graphs too (graphed_d_step / graphed_r1_step; the eager timings beside them).
+    bf16=True: BASELINE.json configs[4] as it NAMES the step -- the activations parked for the backward stored as bf16 (e4s_amd/tape.py);
+    arithmetic, weights, moments and gradients fp32 as in the default leg (the reference trains fp32: coach.py has no autocast).
     losses = "mse": the l2 term alone, no Discriminator.  Synthetic weights everywhere; `warmup` untimed + `steps` timed."""
     import copy
     import types
@@ -469,11 +472,11 @@ def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3, train_G=True
         disc = Discriminator(SIZE)
         disc.load_state_dict(synth.synth_disc_state_dict(SIZE), strict=True)
         disc = disc.to(dev).train()
-        opt_d = FusedAdam(disc.parameters(), lr=1e-4)
+        opt_d = FusedAdam(disc.parameters(), lr=1e-4, capturable=True)
     else:
         lo.face_parsing_lambda = lo.id_lambda = lo.lpips_lambda = 0.0
     net_ema = copy.deepcopy(net).eval() if losses == "full" else None      # coach.py:60-67
-    it = TrainIteration(net, disc, crit, opt, opt_d, lo=lo, net_ema=net_ema)
+    it = TrainIteration(net, disc, crit, opt, opt_d, lo=lo, net_ema=net_ema, bf16_storage=bf16)
 
     def timed(fn, n, w):
         for _ in range(w):
@@ -491,6 +494,14 @@ def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3, train_G=True
     # BEFORE any eager step: autograd's AccumulateGrad nodes remember the stream they were created on, and nodes left over from eager
     # steps on the default stream break a later capture on the side stream
     gs = it.graphed_g_step(img, mask, warmup=warmup)
+    gd = gr = None
+    if disc is not None and time_d:
+        try:                                     # (captured before any eager step, like the G step)
+            gd = it.graphed_d_step(img, mask, warmup=1)
+            gr = it.graphed_r1_step(img, warmup=1)
+        except Exception as e:      # noqa: BLE001
+            gd = gr = None
+            d_capture_error = f"{type(e).__name__}: {e}"[:200]
     g_ms = timed(gs.step, steps, 1)
     gs.validate()
     g_eager_ms = timed(g_eager, steps, 1)
@@ -498,11 +509,20 @@ def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3, train_G=True
            "batch": batch, "steps": steps, "warmup": warmup,
            "images_per_s": round(batch * 1e3 / g_ms, 2), "trainable_parameters": int(sum(p.numel() for p in params)),
            "losses": losses, "ema": net_ema is not None, "train_G": bool(train_G), "train_D": disc is not None,
+           "activation_storage": "bf16" if bf16 else "fp32", "loss_networks_forked": bool(it.fork_losses),
            "trainable_generator_parameters": int(sum(p.numel() for p in net.G.parameters() if p.requires_grad))}
     if disc is not None and time_d:
-        d_ms = timed(lambda: it.d_step(img, mask), max(2, steps // 2), 1)
-        r1_ms = timed(lambda: it.r1_step(img), max(2, steps // 3), 1)
-        out.update(d_step_ms=round(d_ms, 2), r1_step_ms=round(r1_ms, 2), d_every=lo.d_every, d_reg_every=lo.d_reg_every,
+        d_eager = timed(lambda: it.d_step(img, mask), max(2, steps // 2), 1)
+        r1_eager = timed(lambda: it.r1_step(img), max(2, steps // 3), 1)
+        d_ms, r1_ms = d_eager, r1_eager
+        if gd is not None:
+            d_ms = timed(gd.step, max(2, steps // 2), 1)
+            r1_ms = timed(gr.step, max(2, steps // 3), 1)
+            gd.validate()
+        else:
+            out["d_capture_error"] = d_capture_error
+        out.update(d_step_ms=round(d_ms, 2), r1_step_ms=round(r1_ms, 2), d_step_graphed=gd is not None, d_step_eager_ms=round(d_eager, 2),
+                   r1_step_eager_ms=round(r1_eager, 2), d_every=lo.d_every, d_reg_every=lo.d_reg_every,
                    ms_per_iteration_amortised=round(g_ms + d_ms / lo.d_every, 2),
                    discriminator_parameters=int(sum(p.numel() for p in disc.parameters())))
     return out
@@ -631,6 +651,7 @@ def main():
         return
     if args.train_only:
         legs = {"full": ("config5_train_step_1gpu", lambda: train_leg(dev, lat, args.train_steps, losses="full", time_d=not args.train_g_only)),
+                "bf16": ("config5_train_step_1gpu_bf16", lambda: train_leg(dev, lat, args.train_steps, losses="full", time_d=False, bf16=True)),
                 "frozen": ("config5_train_step_1gpu_G_frozen", lambda: train_leg(dev, lat, args.train_steps, losses="full", train_G=False,
                                                                                  time_d=False)),
                 "mse": ("config5_train_step_1gpu_mse_only", lambda: train_leg(dev, lat, args.train_steps, losses="mse", train_G=False))}
@@ -795,6 +816,7 @@ def main():
             # the reference's default: train_G = train_D = True (train_options.py:32-33); the round-4 configuration (G frozen while D
             # trains, which coach.py:324 says must not be combined) stays beside it for continuity, G step only
             side("config5_train_step_1gpu", lambda: train_leg(dev, lat, args.train_steps, losses="full"))
+            side("config5_train_step_1gpu_bf16", lambda: train_leg(dev, lat, args.train_steps, losses="full", time_d=False, bf16=True))
             side("config5_train_step_1gpu_G_frozen", lambda: train_leg(dev, lat, args.train_steps, losses="full", train_G=False,
                                                                        time_d=False))
             side("config5_train_step_1gpu_mse_only", lambda: train_leg(dev, lat, args.train_steps, losses="mse", train_G=False))

@@ -16,6 +16,7 @@ import math
 import torch
 from torch.autograd.function import once_differentiable
 
+from .tape import Tape
 from . import kernels as K
 
 
@@ -128,7 +129,7 @@ class GeneratorFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, gen, latent, mask, noise, *params):
-        tape = []
+        tape = Tape()                                   # (activations stored as bf16 under tape.storage(): configs[4])
         lat = latent.detach().to(torch.float32).contiguous()
         image, feats = gen._fused_forward(lat, mask, noise, tape=tape)
         ctx.gen, ctx.tape, ctx.lat = gen, tape, lat

@@ -16,6 +16,7 @@ only through rounding residue; that path (O(1e-8) of the gradient) is dropped.""
 import torch
 from torch.autograd.function import once_differentiable
 
+from .tape import Tape, pack as pack_record
 from . import kernels as K
 from .ddp import notify_grad
 from .encoders import _pack3x3, _conv3x3, _conv_strided
@@ -133,7 +134,7 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, enc, x256, labels, num_regions, *params):
-        tape = []
+        tape = Tape()                                   # (activations stored as bf16 under tape.storage(): configs[4])
         conv0, prelu0 = enc.input_layer[0], enc.input_layer[2]
         c0 = K.conv3x3_small(x256, conv0.weight.detach())
         st0, _ = K.instnorm_stats(c0)
@@ -148,7 +149,7 @@ class EncoderFn(torch.autograd.Function):
                 K.region_mean_into(x, labels, codes, num_regions, off[i])
                 shapes[i] = tuple(x.shape)
         ctx.enc, ctx.tape, ctx.labels, ctx.R = enc, tape, labels, num_regions
-        ctx.stem = dict(x256=x256, c0=c0, st0=st0)
+        ctx.stem = pack_record(dict(x256=x256, c0=c0, st0=st0), tape._cache)
         ctx.off, ctx.shapes = off, shapes
         ctx.pidx = {id(p): i for i, p in enumerate(params)}
         ctx.nparams = len(params)

@@ -15,10 +15,13 @@
 
 The scalar glue on [B,1] logits (softplus, means, the loss sum) stays in torch: a handful of one-element launches that
 autograd differentiates as is.  Nothing here touches the control plane of the Coach (data loading, logging, checkpoints)."""
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
 from . import kernels as K
+from . import tape as _tape
 
 
 def requires_grad(model, flag=True):
@@ -109,8 +112,16 @@ class TrainIteration:
     (e4s_amd.criteria modules); opt / opt_d: optimisers over net's / disc's trainable parameters; averager / averager_d:
     ddp.GradAverager (N > 1) or None; net_ema: EMA copy of net or None; ema_decay: coach.py:29's ACCUM by default."""
 
-    def __init__(self, net, disc, crit, opt, opt_d, lo=None, averager=None, averager_d=None, net_ema=None, ema_decay=EMA_DECAY):
+    def __init__(self, net, disc, crit, opt, opt_d, lo=None, averager=None, averager_d=None, net_ema=None, ema_decay=EMA_DECAY,
+                 fork_losses=True, bf16_storage=False):
         self.net, self.disc, self.crit, self.opt, self.opt_d = net, disc, crit, opt, opt_d
+        # BASELINE.json configs[4] names bf16: True stores what the forward passes park in HBM for their backward (encoder / generator tapes,
+        # the loss networks' and D's saved tensors) as bf16 (e4s_amd/tape.py); arithmetic, weights, moments and gradients stay fp32.  Pair it
+        # with ddp.GradAverager(payload_dtype=torch.bfloat16) for the all-reduce payload.  The reference itself trains fp32: default False.
+        self.bf16_storage = bf16_storage
+        # calc_loss's loss networks (parsing UNet, IR-SE50, LPIPS x3) are independent chains of small launches: each on its own stream,
+        # forked from and joined to the step's stream (optim.forked_sum; eager and inside a capture) -- same terms, same order of addition
+        self.fork_losses = fork_losses
         self.lo = lo or LossOpts()
         self.averager, self.averager_d, self.net_ema, self.ema_decay = averager, averager_d, net_ema, ema_decay
         # `net` may be the reference's wrapper, nn.parallel.DistributedDataParallel(net, find_unused_parameters=True,
@@ -122,37 +133,50 @@ class TrainIteration:
 
     # ---- coach.py:403-453 -------------------------------------------------------------------------------------------
     def calc_loss(self, img, recon, latent=None):
-        lo, loss, terms = self.lo, 0.0, {}
+        lo, terms, fns = self.lo, {}, []
+
+        def term(key, weight, fn):
+            def run():
+                terms[key] = fn()
+                return terms[key] * weight
+            fns.append(run)
         if lo.face_parsing_lambda > 0 and "parsing" in self.crit:
-            terms["parsing"] = self.crit["parsing"](recon, img)[0]
-            loss = loss + terms["parsing"] * lo.face_parsing_lambda
+            term("parsing", lo.face_parsing_lambda, lambda: self.crit["parsing"](recon, img)[0])
         if lo.id_lambda > 0 and "id" in self.crit:
-            terms["id"] = self.crit["id"](recon, img)[0]
-            loss = loss + terms["id"] * lo.id_lambda
+            term("id", lo.id_lambda, lambda: self.crit["id"](recon, img)[0])
         if lo.l2_lambda > 0:
-            terms["l2"] = mse_loss(recon, img)
-            loss = loss + terms["l2"] * lo.l2_lambda
+            term("l2", lo.l2_lambda, lambda: mse_loss(recon, img))
         if lo.lpips_lambda > 0 and "lpips" in self.crit:
             # the three adaptive_avg_pool2d scales of coach.py:425-434, pooled inside the networks' first pass
-            terms["lpips"] = self.crit["lpips"].forward_pooled(recon, img, lo.lpips_sizes)
-            loss = loss + terms["lpips"] * lo.lpips_lambda
+            term("lpips", lo.lpips_lambda, lambda: self.crit["lpips"].forward_pooled(recon, img, lo.lpips_sizes))
         if lo.w_norm_lambda > 0:
             if latent is None:
                 raise RuntimeError("w_norm_lambda > 0 needs the latent (Net3.forward(..., return_latents=True))")
-            terms["w_norm"] = w_norm_loss(latent, self.core.latent_avg, getattr(self.core.opts, "start_from_latent_avg", True))
-            loss = loss + terms["w_norm"] * lo.w_norm_lambda
+            term("w_norm", lo.w_norm_lambda,
+                 lambda: w_norm_loss(latent, self.core.latent_avg, getattr(self.core.opts, "start_from_latent_avg", True)))
+        if self.fork_losses and recon.is_cuda and len(fns) > 1:
+            from .optim import forked_sum
+            loss = forked_sum(0.0, fns, inputs=(recon, img))      # ((0 + parsing) + id) + l2 + lpips: coach.py:403-453's order
+        else:
+            loss = 0.0
+            for fn in fns:
+                loss = loss + fn()
         return loss, terms
+
+    def _storage(self):
+        return _tape.storage(torch.bfloat16) if self.bf16_storage else contextlib.nullcontext()
 
     def generator_loss(self, img, onehot, **fwd):
         latent = None
-        if self.lo.w_norm_lambda > 0:
-            recon, _, latent = self.net(img, onehot, return_latents=True, **fwd)
-        else:
-            recon, _ = self.net(img, onehot, **fwd)
-        loss, terms = self.calc_loss(img, recon, latent)
-        if self.disc is not None:
-            terms["g_adv"] = adv_g_loss(self.disc(recon))
-            loss = loss + self.lo.g_adv_lambda * terms["g_adv"]
+        with self._storage():
+            if self.lo.w_norm_lambda > 0:
+                recon, _, latent = self.net(img, onehot, return_latents=True, **fwd)
+            else:
+                recon, _ = self.net(img, onehot, **fwd)
+            loss, terms = self.calc_loss(img, recon, latent)
+            if self.disc is not None:
+                terms["g_adv"] = adv_g_loss(self.disc(recon))
+                loss = loss + self.lo.g_adv_lambda * terms["g_adv"]
         return loss, terms, recon
 
     # ---- coach.py:290-307 -------------------------------------------------------------------------------------------
@@ -160,7 +184,8 @@ class TrainIteration:
         requires_grad(self.disc, True)
         with torch.no_grad():                       # torch_utils.requires_grad(self.net, False): no graph through the net
             recon, _ = self.net(img, onehot, **fwd)
-        d_loss = adv_d_loss(self.disc(img), self.disc(recon))
+        with self._storage():
+            d_loss = adv_d_loss(self.disc(img), self.disc(recon))
         self.disc.zero_grad()
         if self.averager_d is not None:
             self.averager_d.arm()
@@ -241,6 +266,29 @@ class TrainIteration:
             return loss
         ema = [p.detach() for p in self.net_ema.parameters()] if self.net_ema is not None else []
         return GraphedStep(self.opt, body, warmup=warmup, also_written=ema)
+
+    def graphed_d_step(self, img, onehot, warmup=1, **fwd):
+        """The D step (coach.py:290-307: Net3 forward without a graph, D(real), D(fake), AdvDLoss backward through the closed Function
+        families of disc_autograd, [bucketed all-reduces,] fused Adam on D) captured as ONE HIP graph -- ~2 000 launches eagerly.  Needs
+        opt_d = FusedAdam(capturable=True).  The net's weight packs are rebuilt inside the graph when the G step trains it between replays
+        (packs are keyed on versions; GraphedStep advances them)."""
+        from .optim import GraphedStep
+        from . import disc_autograd
+
+        def body():
+            disc_autograd.invalidate_packs(self.disc)
+            return self.d_step(img, onehot, **fwd)
+        return GraphedStep(self.opt_d, body, warmup=warmup)
+
+    def graphed_r1_step(self, img, warmup=1):
+        """The R1 step (coach.py:309-319: the second-order pass) as ONE HIP graph; same requirements as graphed_d_step."""
+        from .optim import GraphedStep
+        from . import disc_autograd
+
+        def body():
+            disc_autograd.invalidate_packs(self.disc)
+            return self.r1_step(img)
+        return GraphedStep(self.opt_d, body, warmup=warmup)
 
     def iteration(self, img, onehot, batch_idx=0, **fwd):
         """One pass of the loop body at self.global_step (coach.py:281-398)."""
