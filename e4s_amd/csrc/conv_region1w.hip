@@ -204,27 +204,40 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
         }
     }
 
-    // ---- tile setup 1: output pixels (offset, noise, region), halo pixels (own region) ----
-    if (tid < BM) {
-        const int ay = tyb * TH + tid / TW, ax = txb * TW + tid % TW;
-        const bool valid = ay < p.Ha && ax < p.Wa;
-        const int oy = ay * p.ostride + py, ox = ax * p.ostride + px;
-        s_out[tid] = valid ? (tb * p.Ho + oy) * p.Wo + ox : -1;
-        float nz = 0.f;
-        int r = 0;
-        if (valid) {
-            if (p.noise) nz = p.noise_w[0] * p.noise[(int64_t)tb * p.noise_bstride + (int64_t)oy * p.Wo + ox];
-            r = label_at(oy, ox);
+    // ---- tile setup 1: output pixels (offset, noise, region), halo pixels (own region).  Straight-line: the pixel's label and noise and the
+    // halo pixels' labels are ONE batch of global loads (clamped addresses, results selected afterwards), not three dependent round trips
+    // under exec masks -- nothing else runs on this CU while the tile is analysed ----
+    {
+        constexpr int HPT = (HALO + NTHR - 1) / NTHR;              // halo pixels per thread
+        const bool is_px = tid < BM;
+        const int ay = tyb * TH + (tid & (BM - 1)) / TW, ax = txb * TW + (tid & (BM - 1)) % TW;
+        const bool valid = is_px && ay < p.Ha && ax < p.Wa;
+        const int oy = valid ? ay * p.ostride + py : 0, ox = valid ? ax * p.ostride + px : 0;
+        const float nzr = p.noise ? p.noise[(int64_t)tb * p.noise_bstride + (int64_t)oy * p.Wo + ox] : 0.f;
+        const int rr = label_at(oy, ox);
+        int hl[HPT];
+        bool hin[HPT];
+#pragma unroll
+        for (int k = 0; k < HPT; ++k) {
+            const int h = tid + k * NTHR;
+            const int hy = h / HALO_W, hx = h - hy * HALO_W;
+            const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
+            hin[k] = h < HALO && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            hl[k] = label_at(hin[k] ? iy * p.ostride + py : 0, hin[k] ? ix * p.ostride + px : 0);
         }
-        s_nz[tid] = nz;
-        s_grp[tid] = (unsigned char)r;
-    }
-    for (int h = tid; h < HALO; h += NTHR) {
-        const int hy = h / HALO_W, hx = h - hy * HALO_W;
-        const int iy = tyb * TH + hy - 1, ix = txb * TW + hx - 1;
-        const bool inside = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        s_lab[h] = inside ? (unsigned char)label_at(iy * p.ostride + py, ix * p.ostride + px) : 0xFF;
-        s_need[h] = 0u;
+        if (is_px) {
+            s_out[tid] = valid ? (tb * p.Ho + oy) * p.Wo + ox : -1;
+            s_nz[tid] = (valid && p.noise) ? p.noise_w[0] * nzr : 0.f;
+            s_grp[tid] = (unsigned char)(valid ? rr : 0);
+        }
+#pragma unroll
+        for (int k = 0; k < HPT; ++k) {
+            const int h = tid + k * NTHR;
+            if (h < HALO) {
+                s_lab[h] = hin[k] ? (unsigned char)hl[k] : 0xFF;
+                s_need[h] = 0u;
+            }
+        }
     }
     __syncthreads();
     // ---- 2: which foreign regions read each halo pixel ----
@@ -342,9 +355,20 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
         a_styb[i] = (unsigned)a_sty[i] * 4u;
     }
     // ---- prologue: chunk 0's rows, the weights of taps 0 and 1 (tap 2's stay in pb) ----
+    {
+        // all 2 NIT loads first (items that do not exist read offset 0 and store to the dummy rows): one round trip, not NIT under exec masks
+        f32x8 px[NIT], ps[NIT];
 #pragma unroll
-    for (int i = 0; i < NIT; ++i)
-        if (a_dst[i] >= 0) scale_split_store(sA + a_dst[i], sA + (a_dst[i] ^ 32), load8(xb + a_src[i]), load8(stab + a_sty[i]));
+        for (int i = 0; i < NIT; ++i) {
+            px[i] = load8(xb + a_src[i]);
+            ps[i] = load8(stab + a_sty[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int d = a_dst[i] >= 0 ? a_dst[i] : OFF_DUMMY + lane * ROWB;
+            scale_split_store(smem + d, smem + (d ^ 32), px[i], ps[i]);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
         *reinterpret_cast<f32x4*>(sB + 0 * B_SLOT + b_dst + j * (NTHR / 4 * ROWB)) = pb1[j];
