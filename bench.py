@@ -130,8 +130,8 @@ def headline_probe(net, batch, mask, reps):
             # what `frac` could reach for a 3-MFMA-per-product kernel is 1780 / 3 / 2500 = 0.237
             "frac_of_power_limited_mfma_rate": round(3 * ach / 1780.0, 4),
             "traffic": None if traffic_stale else traffic.get("hbm_bytes_per_launch_bf16x3"), "traffic_stale": traffic_stale,
-            "traffic_source": "profiles/roofline_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of "
-                              "this kernel (separate passes, profiles/r04a_pmc_{fetch,write}.csv), valid for the kernel source whose "
+            "traffic_source": "profiles/roofline_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of this kernel ("
+                              + str(traffic.get("bf16x3_rows", {}).get("source", "separate passes")) + "), valid for the kernel source whose "
                               "sha256 the file records; a PMC pass cannot run inside this timed process",
             "avg_launch_ms": round(ms, 4), "flop_per_launch": flops, "exact_fp32_variant": exact}
 
