@@ -89,6 +89,14 @@ __global__ void wino_weights_kernel(const float* __restrict__ w9, unsigned char*
         unsigned char* row = out + ((((int64_t)ky * nchunk + chunk) * 4 + p) * Cout + co) * ROWB;
         reinterpret_cast<__bf16*>(row)[k] = h;
         reinterpret_cast<__bf16*>(row + 32)[k] = l;
+        // the same values fragment-major (conv_wino1w.hip reads its B fragments straight from global memory): behind the image above, per
+        // (ky, chunk, position, 32-channel block) 2 KB = [hi: lane -> (channel & 31, k-half)][lo], 16 bytes per lane
+        if (Cout % 32 == 0) {
+            unsigned char* fr = out + (int64_t)3 * nchunk * 4 * Cout * ROWB +
+                                (((((int64_t)ky * nchunk + chunk) * 4 + p) * (Cout / 32) + co / 32) * 2 * 1024) + ((k >> 3) * 32 + (co & 31)) * 16;
+            reinterpret_cast<__bf16*>(fr)[k & 7] = h;
+            reinterpret_cast<__bf16*>(fr + 1024)[k & 7] = l;
+        }
     }
 }
 
@@ -698,7 +706,7 @@ bool wino_covers(const e4s_conv_params& p) {
 
 extern "C" int64_t e4s_wino_weights_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0 || Cin % KC) return -1;
-    return (int64_t)3 * (Cin / KC) * 4 * Cout * ROWB;
+    return (int64_t)3 * (Cin / KC) * 4 * Cout * ROWB * (Cout % 32 == 0 ? 2 : 1);       // plane-major image [+ fragment-major image]
 }
 
 extern "C" int e4s_wino_weights_f32(const float* w9, void* out, int Cout, int Cin, void* stream) {
@@ -752,13 +760,14 @@ extern "C" int e4s_conv_wino_bf16x3_f32(const e4s_conv_params* pp, void* stream)
 #undef WV
     }
 #endif
-    // launches without a K split and with >= 16 chunks per tile (Cin >= 256): the one-wave-per-SIMD kernel (conv_wino1w.hip).  Measured
-    // (profiles/r06_wino1w.json, 16 images, InstanceNorm+PReLU form / statistics form): 512 -> 512 @32^2 -6.4 / -7.5 %, 256 -> 256 @64^2 -6.5 / -6 %,
-    // 256 -> 512 @64^2 -6 / -4 %; 128 -> 128 @128^2 -1 / +2 %, 64 -> 128 @256^2 +4 / +5 % (short tiles: its register epilogue is not covered by a
-    // SIMD partner).  E4S_WINO_1W = 0 / 1 forces one of them (read per launch, so that a test can run both in one process)
+    // launches without a K split and with >= 8 chunks per tile (Cin >= 128): the one-wave-per-SIMD kernel (conv_wino1w.hip).  Measured
+    // (profiles/r06_wino1w.json, 16 images, InstanceNorm+PReLU form / statistics form, against this file's kernel): 512 -> 512 @32^2 -12 / -14 %,
+    // 256 -> 256 @64^2 -10 / -11 %, 256 -> 512 @64^2 -11 / -10 %, 128 -> 128 @128^2 -3 / -3 %, 128 -> 256 @128^2 -3 / -3 %; 64 -> 128 @256^2 +4 / +5 %
+    // (four chunks per tile: its register epilogue is not covered by a SIMD partner).  E4S_WINO_1W = 0 / 1 forces one of them (read per launch,
+    // so that a test can run both in one process)
     {
         const char* e1 = getenv("E4S_WINO_1W");
-        const bool want = e1 ? atoi(e1) != 0 : p.Cin / KC >= 16;
+        const bool want = e1 ? atoi(e1) != 0 : (p.Cin / KC >= 8 && p.Cout % 32 == 0);
         if (ksplit == 1 && want) return e4s_launch_wino1w(p, ntn, tx_n, per_img, (int)tiles, (int)grid, as_stream(stream));
     }
     // wave tile (see the kernel): 64 x 64 x two positions where a tile has enough K stages to pay for the exchange in its epilogue

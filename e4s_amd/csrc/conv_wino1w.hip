@@ -1,23 +1,25 @@
-// Winograd F(2,3)-along-the-rows 3x3 convolution (conv_wino.hip: algebra, operand layouts, epilogue forms), re-cut for ONE wave per SIMD
+// Winograd F(2,3)-along-the-rows 3x3 convolution (conv_wino.hip: algebra, V layout, epilogue forms), re-cut for ONE wave per SIMD
 // (round 6; the encoder's stride-1 convs are 43 % of a face swap's GPU time).
 //
 // conv_wino_kernel: 8 waves of 64 rows x 32 channels x 4 positions, two per SIMD inside 256 registers: 24 ds_read_b128 per 24 MFMAs, a
-// barrier every 24 MFMAs per wave, the input transform on three "storer" waves per stage.  Here a 256-thread block owns the whole 512-entry
-// register file: wave (wm, wn) of 2 x 2 holds 64 rows x 64 channels of ALL four positions = 16 accumulator tiles (256 AGPRs), so a stage
-// (one vertical tap x 16 channels) is 48 MFMAs per wave with 32 fragment reads (0.67 per MFMA instead of 1), the output transform still
-// happens in registers, and the block tile (128 GEMM rows x 128 channels x 4 positions) and every operand layout are unchanged.
-// Pipeline, as conv_region1w.hip's (everything in the shadow of the wave's own MFMAs; the issue order is pinned slot by slot):
-//   * ONE barrier per stage, after position 1; the fragments of position p + 1 (of the next stage after position 3) are read under the
-//     MFMAs of position p;
-//   * U (weights): a ring of EIGHT position planes (8 KB each) in LDS, staged through registers: in the first half of stage s a thread stores
-//     the eight 16-byte pieces of the planes (s, 3), (s + 1, 0..2) -- fetched one stage earlier, their slots released by the barrier of stage
-//     s - 1, first read behind the barrier of stage s -- and fetches the next eight.  (First version: LDS-DMA with vmcnt(0) in front of the
-//     barrier -- 23 % SLOWER than the 8-wave kernel: a DMA needs ~1.1 us from issue to landed and this ring gives it at most one stage.)
-//   * V (transformed input), double buffered by chunk: 576 items (V-pixel, 4 channels) = two per thread (A, B) + 64 left over, which are cut
-//     into their four positions so that every thread takes one quarter (Q: wave w computes position w); an item is fetched in the second
-//     half of a stage and transformed + stored in the second half of the next one (A and Q in the chunk's first stage, B in its second).
-//     Addresses are a per-thread constant + a wave-uniform tile / chunk base, padding is two flag words: no integer multiplies, no branches.
-// Split-K launches (<= 128 tiles) stay on conv_wino_kernel.
+// barrier every 24 MFMAs per wave, the weights by LDS-DMA, the input transform on three "storer" waves per stage.  Here a 256-thread block
+// owns the whole 512-entry register file: wave w holds ALL 128 GEMM rows x channels 32 w .. 32 w + 31 x four positions = 16 accumulator
+// tiles (256 AGPRs); a stage (one vertical tap x 16 channels) is 48 MFMAs per wave; the output transform still happens in registers and the
+// block tile (128 GEMM rows x 128 channels x 4 positions) is unchanged.
+//   * U (weights) does NOT go through the LDS: a wave needs only its own 32 channels, so it loads them straight into its B fragment
+//     registers from a fragment-major image (1 KB contiguous per instruction), position p of the NEXT stage behind the MFMAs of position p
+//     of this one.  History: LDS-DMA into a ring of planes with vmcnt(0) before the barrier: 23 % SLOWER than the 8-wave kernel (a DMA
+//     needs ~1.1 us from issue to landed); register-staged ring (load -> ds_write_b128 -> ds_read_b128): -6 % -- the LDS write port, ~79
+//     B/clk per CU, was 415 of the 1 070 LDS cycles of a stage; direct: see profiles/r06_wino1w.json.
+//   * V (transformed input) in LDS, double buffered by chunk, ONE barrier per stage after position 1; the A fragments of position p + 1 (of
+//     the next stage after position 3) are read under the MFMAs of position p; every wave reads the whole V tile (the same LDS read
+//     traffic as A + B fragments of a 64 x 64 wave tile).
+//   * Input transform: 576 items (V-pixel, 4 channels) per chunk = two per thread (A, B) + 64 left over, which are cut into their four
+//     positions so that every thread takes one quarter (Q: wave w computes position w); an item is fetched in the second half of a stage
+//     and transformed + stored in the second half of the next one (A and Q in the chunk's first stage, B in its second).  Addresses are a
+//     per-thread constant + a wave-uniform tile / chunk base, padding is two flag words: no integer multiplies, no branches.
+//   * The issue order is pinned slot by slot (one MFMA + at most one LDS / global instruction + a few VALU, sched_barrier(0)).
+// Split-K launches (<= 128 tiles) and short-K layers stay on conv_wino_kernel.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -34,11 +36,15 @@ constexpr int TH = 16, TW = 16, NPAIR = TW / 2;
 constexpr int VROWS = (TH + 2) * NPAIR;          // 144 V-pixels per position and chunk
 constexpr int BN = 128, KC = 16, ROWB = 64;
 constexpr int A_PLANE = VROWS * ROWB, A_BYTES = 4 * A_PLANE;        // 36 864
-constexpr int B_PLANE = BN * ROWB, NBP = 8;                         // 8 KB per (stage, position) plane; ring of 8
-constexpr int OFF_B = 2 * A_BYTES;
-constexpr int OFF_ST = OFF_B + NBP * B_PLANE;                       // double [2 wm][BN][2]
-constexpr int OFF_IN = OFF_ST + 2 * BN * 2 * 8;                     // XF == 2: float [2 tile parities][Cin][{mean, rstd}]
+constexpr int OFF_IN = 2 * A_BYTES;                                 // XF == 2: float [2 tile parities][Cin][{mean, rstd}]
 constexpr int SMEM_1W = OFF_IN;
+#ifndef E4S_WINO_BPF
+#define E4S_WINO_BPF 1
+#endif
+// B fragments are fetched this many stages ahead.  2 (three register sets) measured SLOWER in the step, same box, two alternations:
+// encoder convs 6.95 vs 6.85 ms, step 16.40 vs 16.31 ms (profiles/r06_wino1w.json) -- one stage of flight covers the weight stream
+constexpr int BPF = E4S_WINO_BPF;
+static_assert(BPF == 1 || BPF == 2, "B prefetch distance");
 
 __device__ __forceinline__ int swz(int row, int g) { return row * ROWB + ((g ^ ((row >> 2) & 3)) << 4); }
 
@@ -53,8 +59,8 @@ struct WTile {
     int n0, tb, ty0, tx0, slot;
 };
 
-struct AF { bf16x8 h[2], l[2]; };
-struct BF { bf16x8 h[2], l[2]; };
+struct AF { bf16x8 h[4], l[4]; };          // the four 32-row groups of a position
+struct BF { bf16x8 h, l; };                // one position of this wave's 32 channels
 
 // v = (a - m) + sg (b - m) [m = 0, sg = -1: a - b exactly; m = mean, sg = +1: position 1 of the InstanceNorm form], * rs, split to hi / lo bf16
 template <int XF>
@@ -78,14 +84,12 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void conv_wino1w_kernel(const e4s_conv_params p, const int ntn, const int tx_n, const int per_img, const int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                                  // [2][4 pos][144][64]
-    unsigned char* sB = smem + OFF_B;                          // [8 planes][128][64]
-    double* s_st = reinterpret_cast<double*>(smem + OFF_ST);
     float* s_in = reinterpret_cast<float*>(smem + OFF_IN);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wn = wave;                                       // this wave: all 128 GEMM rows x channels 32 wn .. 32 wn + 31, four positions
     const int G = gridDim.x;
     const int first = xcd_remap(blockIdx.x, G);
     const int mtiles = ntiles / ntn;
@@ -182,14 +186,14 @@ void conv_wino1w_kernel(const e4s_conv_params p, const int ntn, const int tx_n, 
         }
     };
 
-    // ---- weight planes: plane (ky, chunk, ps) of a column tile = 128 rows x 64 B, contiguous in global memory; piece jj of a thread = the
-    // 16 bytes at index jj * 256 + tid: row (jj * 64 + tid / 4), granule tid & 3 ----
-    const size_t u_pos = (size_t)p.Cout * ROWB;                          // bytes per position plane in global memory
-    const int u_dst = swz(tid >> 2, tid & 3);                            // + 64 rows per jj: same swizzle class
-    auto u_src = [&](int ky, int chunk, int ps, int n0) -> const unsigned char* {
-        return ub + (((size_t)ky * nchunk + chunk) * 4 + ps) * u_pos + (size_t)n0 * ROWB;
+    // ---- weights: straight from global memory into the B fragments of the wave that uses them (no LDS round trip: the LDS write port --
+    // ~79 B/clk per CU -- was 415 of the 1 070 LDS cycles of a stage).  The fragment-major image (wino_weights_kernel writes it behind the
+    // plane-major one): per (ky, chunk, position, 32-channel block) 2 KB = [hi: lane l -> channel l & 31, k-half l >> 5][lo: the same], so a
+    // wave's fragment load is 1 KB contiguous ----
+    const unsigned char* uf = ub + (size_t)3 * nchunk * 4 * p.Cout * ROWB;                          // behind the plane-major image
+    auto uf_src = [&](int ky, int chunk, int ps, int n0) -> const unsigned char* {
+        return uf + ((((size_t)ky * nchunk + chunk) * 4 + ps) * (p.Cout / 32) + (n0 / 32 + wn)) * 2048 + lane * 16;
     };
-
     if (first >= ntiles) return;
     WTile cur = decode(first);
     int t_next = first + G;
@@ -201,7 +205,6 @@ void conv_wino1w_kernel(const e4s_conv_params p, const int ntn, const int tx_n, 
     Item I;                            // item A / B in flight
     f32x4 Qa, Qb;                      // quarter item in flight: the two pixels of this wave's position
     bool Qoka = true, Qokb = true;
-    f32x4 u[8];                        // weight pieces in flight
     I.okmask = 0;
     load_stats(cur, 0);
     if (XF == 2) __syncthreads();
@@ -226,17 +229,6 @@ void conv_wino1w_kernel(const e4s_conv_params p, const int ntn, const int tx_n, 
                 *reinterpret_cast<u32x2*>(sA + (a ^ 32)) = u32x2{l[0], l[1]};
             }
         }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-                *reinterpret_cast<f32x4*>(sB + pl * B_PLANE + u_dst + jj * 64 * ROWB) =
-                    *reinterpret_cast<const f32x4*>(u_src(0, 0, pl, cur.n0) + (jj * NTHR + tid) * 16);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int pl = j >> 1, jj = j & 1;
-            u[j] = *reinterpret_cast<const f32x4*>((pl == 0 ? u_src(0, 0, 3, cur.n0) : u_src(1, 0, pl - 1, cur.n0)) + (jj * NTHR + tid) * 16);
-        }
         const float* xb1 = xbase_of(cur, 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) item_load_part(I, xb1, relA, flgA & edge, i);
@@ -245,34 +237,36 @@ void conv_wino1w_kernel(const e4s_conv_params p, const int ntn, const int tx_n, 
     }
     __syncthreads();
 
-    int aoff[2][3], boff[2];
+    int aoff[4][3];
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) aoff[tm][ky] = swz(wm * 64 + tm * 32 + li + 8 * ky, kh);
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) boff[tn] = swz(wn * 64 + tn * 32 + li, kh);
+        for (int ky = 0; ky < 3; ++ky) aoff[tm][ky] = swz(tm * 32 + li + 8 * ky, kh);
 
-    f32x16 acc[4][2][2];
+    f32x16 acc[4][4];                 // [position][32-row group]
     AF Af[2];
-    BF Bf[2];
-    auto ldA = [&](AF& F, const unsigned char* Abuf, int ps, int ky, int part) {      // part: 0 h[0], 1 l[0], 2 h[1], 3 l[1]
+    // B fragments.  BPF = 1: one set, position p re-filled for the NEXT stage as soon as its MFMAs have issued (a stage of flight); BPF = 2: three
+    // sets rotating with the vertical tap, position p of the stage AFTER the next fetched under position p of this one
+    BF Bf[BPF == 1 ? 1 : 3][4];
+    auto ldA = [&](AF& F, const unsigned char* Abuf, int ps, int ky, int part) {      // part: 2 tm + {0: h, 1: l}
         const unsigned char* a = Abuf + ps * A_PLANE;
         const int tm = part >> 1;
         if (part & 1) F.l[tm] = *reinterpret_cast<const bf16x8*>(a + (aoff[tm][ky] ^ 32));
         else F.h[tm] = *reinterpret_cast<const bf16x8*>(a + aoff[tm][ky]);
     };
-    auto ldB = [&](BF& F, int plane_slot, int part) {
-        const unsigned char* b = sB + plane_slot * B_PLANE;
-        const int tn = part >> 1;
-        if (part & 1) F.l[tn] = *reinterpret_cast<const bf16x8*>(b + (boff[tn] ^ 32));
-        else F.h[tn] = *reinterpret_cast<const bf16x8*>(b + boff[tn]);
-    };
-    // fragments of (stage 0, position 0)
+    // fragments of (stage 0, position 0); the B fragments of all of stage 0
 #pragma unroll
-    for (int part = 0; part < 4; ++part) {
-        ldA(Af[0], sA, 0, 0, part);
-        ldB(Bf[0], 0, part);
+    for (int part = 0; part < 8; ++part) ldA(Af[0], sA, 0, 0, part);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const unsigned char* b = uf_src(0, 0, ps, cur.n0);
+        Bf[0][ps].h = *reinterpret_cast<const bf16x8*>(b);
+        Bf[0][ps].l = *reinterpret_cast<const bf16x8*>(b + 1024);
+        if (BPF == 2) {
+            const unsigned char* b1 = uf_src(1, 0, ps, cur.n0);
+            Bf[1][ps].h = *reinterpret_cast<const bf16x8*>(b1);
+            Bf[1][ps].l = *reinterpret_cast<const bf16x8*>(b1 + 1024);
+        }
     }
 
     unsigned sg = 0, cg = 0;         // running stage / chunk counters: the LDS buffer parities and the plane ring continue across tiles
@@ -285,11 +279,9 @@ void conv_wino1w_kernel(const e4s_conv_params p, const int ntn, const int tx_n, 
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[ps][tm][tn][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[ps][tm][r] = 0.f;
 
         for (int chunk = 0; chunk < nchunk; ++chunk) {
             const bool in_tile = chunk + 1 < nchunk;            // the next chunk belongs to this tile
@@ -309,46 +301,38 @@ void conv_wino1w_kernel(const e4s_conv_params p, const int ntn, const int tx_n, 
             // would index aoff[][] dynamically -- scratch)
             auto stage = [&](auto ts_c) {
                 constexpr int ts = decltype(ts_c)::value;
-                // plane ring: plane (stage s, position q) lives in slot (4 s + q) & 7
-                const int sl0 = (int)((sg & 1) * 4);            // slot of (this stage, position 0); the next stage's is sl0 ^ 4
-                // the round fetched in this stage's first half: planes (sg + 1, 3), (sg + 2, 0..2); stage sg + 1 = (chunk, ts + 1) or
-                // (next chunk, 0), stage sg + 2 likewise
-                constexpr int ky1 = (ts + 1) % 3, ky2 = (ts + 2) % 3;
-                const int ch1 = ts + 1 < 3 ? chunk : c_n, n01 = ts + 1 < 3 ? cur.n0 : Tn.n0;
-                const int ch2 = ts + 2 < 3 ? chunk : c_n, n02 = ts + 2 < 3 ? cur.n0 : Tn.n0;
-                const unsigned char* us1 = u_src(ky1, ch1, 3, n01);
-                const unsigned char* us2 = u_src(ky2, ch2, 0, n02);
+                // the next stage = (chunk, ts + 1) or (next chunk, 0): where its B fragments come from
+                // the stage whose B fragments are fetched now: BPF stages ahead = (chunk, ts + BPF) or (next chunk, ts + BPF - 3)
+                constexpr int ky1 = (ts + BPF) % 3;
+                const int ch1 = ts + BPF < 3 ? chunk : c_n, n01 = ts + BPF < 3 ? cur.n0 : Tn.n0;
+                constexpr int bs_cur = BPF == 1 ? 0 : ts, bs_ld = BPF == 1 ? 0 : (ts + 2) % 3;
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
                     AF& Ac = Af[ps & 1];
                     AF& Ax = Af[(ps + 1) & 1];
-                    BF& Bc = Bf[ps & 1];
-                    BF& Bx = Bf[(ps + 1) & 1];
-                    // next fragments: position ps + 1 of this stage, or position 0 of the next stage (its V: this chunk's buffer with the next
-                    // vertical tap, or the next chunk's; its U plane: slot sl0 ^ 4)
+                    const BF Bc = Bf[bs_cur][ps];
+                    // next A fragments: position ps + 1 of this stage, or position 0 of the next stage (its V: this chunk's buffer with the next
+                    // vertical tap, or the next chunk's)
                     const unsigned char* nA = ps < 3 ? Ab : (ts < 2 ? Ab : An);
                     const int nps = (ps + 1) & 3, nky = ps < 3 ? ts : (ts + 1) % 3;
-                    const int nslot = ps < 3 ? sl0 + ps + 1 : (sl0 ^ 4);
+                    const unsigned char* nb = uf_src(ky1, ch1, ps, n01);
 #pragma unroll
                     for (int k = 0; k < 12; ++k) {
-                        const int prod = k >> 2, tm = (k >> 1) & 1, tn = k & 1;
-                        acc[ps][tm][tn] = prod == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[tm], Bc.l[tn], acc[ps][tm][tn], 0, 0, 0)
-                                        : prod == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[tm], Bc.h[tn], acc[ps][tm][tn], 0, 0, 0)
-                                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[tm], Bc.h[tn], acc[ps][tm][tn], 0, 0, 0);
-                        // slots 0..7: one fragment read each
+                        const int prod = k >> 2, tm = k & 3;
+                        acc[ps][tm] = prod == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[tm], Bc.l, acc[ps][tm], 0, 0, 0)
+                                    : prod == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l[tm], Bc.h, acc[ps][tm], 0, 0, 0)
+                                                : __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h[tm], Bc.h, acc[ps][tm], 0, 0, 0);
+                        // slots 0..7: one A fragment read each
                         if (VAR == 4) {
-                            if (k == 0) { Ax = Ac; Bx = Bc; }
-                        } else if (k < 4) ldA(Ax, nA, nps, nky, k);
-                        else if (k < 8) ldB(Bx, nslot, k - 4);
-                        if (ps < 2) {
-                            // ---- first half, slots 8..11: store weight piece j of this stage's round, fetch piece j of the next round ----
-                            if (k >= 8 && (VAR == 0 || VAR == 2)) {
-                                const int j = ps * 4 + (k - 8), pl = j >> 1, jj = j & 1;
-                                const int slot = pl == 0 ? sl0 + 3 : (sl0 ^ 4) + pl - 1;
-                                *reinterpret_cast<f32x4*>(sB + slot * B_PLANE + u_dst + jj * 64 * ROWB) = u[j];
-                                u[j] = *reinterpret_cast<const f32x4*>((pl == 0 ? us1 : us2 + (size_t)(pl - 1) * u_pos) + (jj * NTHR + tid) * 16);
-                            }
-                        } else if (VAR == 0 || VAR == 1) {
+                            if (k == 0) Ax = Ac;
+                        } else if (k < 8) ldA(Ax, nA, nps, nky, k);
+                        // this position's B fragment for the NEXT stage, behind the sweeps that used the current one last (lo: hi x lo, slots 0..3;
+                        // hi: slots 4..11): a whole stage of flight
+                        if (VAR == 0 || VAR == 2) {
+                            if (k == 8) Bf[bs_ld][ps].l = *reinterpret_cast<const bf16x8*>(nb + 1024);
+                            if (k == 11) Bf[bs_ld][ps].h = *reinterpret_cast<const bf16x8*>(nb);
+                        }
+                        if (ps >= 2 && (VAR == 0 || VAR == 1)) {
                             // ---- second half, slots n = 0..23: the input transform ----
                             const int n = (ps - 2) * 12 + k;
                             if (ts < 2 && n < 16) {              // item A (ts 0) / B (ts 1) of the next chunk: per position {pair, pair, store, store}
@@ -393,69 +377,56 @@ void conv_wino1w_kernel(const e4s_conv_params p, const int ntn, const int tx_n, 
             ++cg;
         }
 
-        // ---- epilogue of the tile: output transform in registers, bias, activation, statistics, NHWC stores (conv_wino.hip's, two column tiles) ----
+        // ---- epilogue of the tile: output transform in registers, bias, activation, statistics, NHWC stores.  A wave holds ALL 128 rows of its
+        // 32 channels: the per-(sample, channel, tile) statistics slot is complete inside the wave (no LDS, no barrier) ----
         {
             const float gain = (p.act == 1) ? p.gain : 1.f;
             const bool do_act = p.act != 0;
             const bool stats = p.stats_ws != nullptr;
             float* yb = p.y + (size_t)cur.tb * p.Ho * p.Wo * p.Cout;
+            const int co = cur.n0 + wn * 32 + li;
+            const float bsv = p.bias ? p.bias[co] : 0.f;
+            const float slp = (p.act == 2) ? p.slope[co] : p.alpha;
+            double st_s = 0.0, st_q = 0.0;
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                const int co = cur.n0 + wn * 64 + tn * 32 + li;
-                const float bsv = p.bias ? p.bias[co] : 0.f;
-                const float slp = (p.act == 2) ? p.slope[co] : p.alpha;
-                double st_s = 0.0, st_q = 0.0;
+            for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
+                for (int g = 0; g < 4; ++g) {
+                    float y0[4], y1[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float y0[4], y1[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int r = 4 * g + i;
-                            const float m0 = acc[0][tm][tn][r], m1 = acc[1][tm][tn][r], m2 = acc[2][tm][tn][r], m3 = acc[3][tm][tn][r];
-                            float a = (m0 + m1) + m2 + bsv;
-                            float b = (m1 - m2) - m3 + bsv;
-                            if (do_act) {
-                                a = (a > 0.f ? a : a * slp) * gain;
-                                b = (b > 0.f ? b : b * slp) * gain;
-                            }
-                            y0[i] = a;
-                            y1[i] = b;
-                            if (stats) {
-                                st_s += (double)a + (double)b;
-                                st_q += (double)a * (double)a + (double)b * (double)b;
-                            }
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;
+                        const float m0 = acc[0][tm][r], m1 = acc[1][tm][r], m2 = acc[2][tm][r], m3 = acc[3][tm][r];
+                        float a = (m0 + m1) + m2 + bsv;
+                        float b = (m1 - m2) - m3 + bsv;
+                        if (do_act) {
+                            a = (a > 0.f ? a : a * slp) * gain;
+                            b = (b > 0.f ? b : b * slp) * gain;
                         }
-                        quad_transpose4(y0[0], y0[1], y0[2], y0[3], li);
-                        quad_transpose4(y1[0], y1[1], y1[2], y1[3], li);
-                        const int m = wm * 64 + tm * 32 + (li & 3) + 8 * g + 4 * kh;
-                        const int oy = cur.ty0 + (m >> 3), ox = cur.tx0 + 2 * (m & 7);
-                        float* dst = yb + ((size_t)oy * p.Wo + ox) * p.Cout + (co - (li & 3));
-                        *reinterpret_cast<f32x4*>(dst) = f32x4{y0[0], y0[1], y0[2], y0[3]};
-                        *reinterpret_cast<f32x4*>(dst + p.Cout) = f32x4{y1[0], y1[1], y1[2], y1[3]};
+                        y0[i] = a;
+                        y1[i] = b;
+                        if (stats) {
+                            st_s += (double)a + (double)b;
+                            st_q += (double)a * (double)a + (double)b * (double)b;
+                        }
                     }
-                }
-                if (stats) {
-                    st_s += __shfl_xor(st_s, 32, 64);
-                    st_q += __shfl_xor(st_q, 32, 64);
-                    if (kh == 0) {
-                        const int col = wn * 64 + tn * 32 + li;
-                        s_st[(wm * BN + col) * 2] = st_s;
-                        s_st[(wm * BN + col) * 2 + 1] = st_q;
-                    }
+                    quad_transpose4(y0[0], y0[1], y0[2], y0[3], li);
+                    quad_transpose4(y1[0], y1[1], y1[2], y1[3], li);
+                    const int m = tm * 32 + (li & 3) + 8 * g + 4 * kh;
+                    const int oy = cur.ty0 + (m >> 3), ox = cur.tx0 + 2 * (m & 7);
+                    float* dst = yb + ((size_t)oy * p.Wo + ox) * p.Cout + (co - (li & 3));
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{y0[0], y0[1], y0[2], y0[3]};
+                    *reinterpret_cast<f32x4*>(dst + p.Cout) = f32x4{y1[0], y1[1], y1[2], y1[3]};
                 }
             }
             if (stats) {
-                __syncthreads();
-                if (tid < BN) {
-                    const double a = s_st[tid * 2] + s_st[(BN + tid) * 2];
-                    const double q = s_st[tid * 2 + 1] + s_st[(BN + tid) * 2 + 1];
-                    double* slot = p.stats_ws + (((size_t)cur.tb * p.Cout + cur.n0 + tid) * p.stats_slots + cur.slot) * 2;
-                    slot[0] = a;
-                    slot[1] = q;
+                st_s += __shfl_xor(st_s, 32, 64);            // the two k-halves of a lane pair hold rows 4 kh .. of the same channel
+                st_q += __shfl_xor(st_q, 32, 64);
+                if (kh == 0) {
+                    double* slot = p.stats_ws + (((size_t)cur.tb * p.Cout + co) * p.stats_slots + cur.slot) * 2;
+                    slot[0] = st_s;
+                    slot[1] = st_q;
                 }
-                // (the next write of s_st is a whole tile of barriers away)
             }
         }
         if (!has_next) break;

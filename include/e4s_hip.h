@@ -431,7 +431,8 @@ int e4s_ema_multi_f32(int count, float* const* dst, const float* const* src, con
 /* 3x3 stride-1 conv as Winograd F(2,3) along the image rows on the split-bf16 matrix-core path (csrc/conv_wino.hip): 1.5x fewer MFMAs than
  * e4s_conv_bf16x3_f32 for the encoder's Conv2d(3x3, stride 1) layers (src/models/encoders/helpers.py:128-137).
  * e4s_wino_weights_f32: w9 [9][Cout][Cin] (tap-packed, e4s_pack_taps_f32) -> the kernel's transformed, hi/lo-split operand
- * (e4s_wino_weights_bytes(Cout, Cin) bytes, opaque).
+ * (e4s_wino_weights_bytes(Cout, Cin) bytes, opaque: the plane-major image [3 ky][Cin/16][4 positions][Cout][16 hi | 16 lo] and, for Cout % 32 == 0,
+ * behind it the same values fragment-major, which the one-wave-per-SIMD kernel of csrc/conv_wino1w.hip loads straight into its B fragments).
  * e4s_conv_wino_bf16x3_f32: p->x / p->y NHWC, p->w = that operand; covered: istride = ostride = 1, ntaps 9, ncls 1, H % 16 == W % 16 == 0,
  * Cin % 16 == 0 (>= 32), Cout % 128 == 0, no styles / labels / noise / plan / y_cstride; launches of <= 128 tiles split the input channels over blocks (p->splitk_ws:
  * e4s_conv_wino_ws_floats floats; stats_ws is ignored then); honoured: in_stats (InstanceNorm folded
