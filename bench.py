@@ -120,7 +120,7 @@ def headline_probe(net, batch, mask, reps):
         name = "conv_region_rows_kernel"
     ms, ach = timed(extra)
     if sg2.REGION_ROWS and K.LAST_REGION_PATH == 2:
-        name = "conv_region_rows1w_kernel<2 x 2 waves, one per SIMD, 256 x 256 tile>"
+        name = "conv_region_rows1w_kernel<1 x 4 waves, one per SIMD, 256 x 256 tile, B fragments from global>"
     return {"bound": "mfma", "kernel": name + " (3x v_mfma_f32_32x32x16_bf16 per product) " + what,
             "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "frac_ceiling": round(1.0 / 3.0, 4),

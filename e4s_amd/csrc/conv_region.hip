@@ -460,7 +460,7 @@ __global__ __launch_bounds__(NTHR) void conv_region_rows_kernel(const e4s_conv_p
 
 // fp32 weights [rows = ncls * 9][Cout][Cin] -> [rows][Cin/16][Cout][16 hi | 16 lo] bf16; one thread per (row, chunk, co, 8 channels)
 __global__ void split16_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, const int64_t n, const int cout,
-                               const int cin) {
+                               const int cin, const int64_t nrows, const int frag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int q = (int)(i & 1);
@@ -477,16 +477,28 @@ __global__ void split16_kernel(const float* __restrict__ w, unsigned char* __res
     unsigned char* dst = out + (((size_t)row * nch + c) * cout + co) * 64 + q * 16;
     *reinterpret_cast<bf16x8*>(dst) = h;
     *reinterpret_cast<bf16x8*>(dst + 32) = l;
+    // the same 8 + 8 values fragment-major (conv_region1w.hip loads its B fragments straight from global memory): behind the image above,
+    // per (row, chunk, 32-column block) 2 KB = [hi: lane -> (column & 31, k-half q)][lo], 16 bytes per lane
+    if (frag) {
+        unsigned char* fr = out + (size_t)nrows * nch * cout * 64 + (((size_t)row * nch + c) * (cout / 32) + co / 32) * 2048 + (q * 32 + (co & 31)) * 16;
+        *reinterpret_cast<bf16x8*>(fr) = h;
+        *reinterpret_cast<bf16x8*>(fr + 1024) = l;
+    }
 }
 
 }  // namespace
+
+extern "C" int64_t e4s_split16_bytes(int64_t rows, int cout, int cin) {
+    if (cin % KC || rows < 0 || cout <= 0) return -1;
+    return rows * cout * cin * 4 * (cout % 32 == 0 ? 2 : 1);           // plane-major image [+ fragment-major image]
+}
 
 extern "C" int e4s_split16_bf16x2_f32(const float* w, void* out, int64_t rows, int cout, int cin, void* stream) {
     if (cin % KC || rows < 0 || cout <= 0) return (int)hipErrorInvalidValue;
     const int64_t n = rows * (cin / 8) * cout;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(split16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w,
-                       reinterpret_cast<unsigned char*>(out), n, cout, cin);
+                       reinterpret_cast<unsigned char*>(out), n, cout, cin, rows, cout % 32 == 0 ? 1 : 0);
     E4S_CHECK_LAUNCH();
     return 0;
 }

@@ -18,7 +18,12 @@
 //   * ONE barrier per tap, in the MIDDLE of its MFMA stream: what was stored in a tap's first group becomes visible there and is first
 //     read in the NEXT tap's last group, and the only LDS reads in flight at the barrier are the two just issued for the next group --
 //     a barrier at the end of the tap would expose the latency of the whole fragment refill once per tap.
-// LDS: rows 2 x 36 KB + weights 3 x 16 KB + d[region][256] 16 KB + tile tables = 142 KB.  Row layout, swizzle, variant-row logic, weight image
+// B-DIRECT layout (the default, template <WM, WN> = <1, 4>): each wave owns all 256 pixels x 64 channels (8 x 2 accumulator tiles) and loads its B
+// fragments straight from a FRAGMENT-MAJOR copy of the weights (e4s_split16_bf16x2_f32 writes it behind the plane-major image: one wave
+// instruction = 1 KB contiguous), a tap ahead, into one of three register sets -- no weight ring, no LDS stores or barrier dependence for the
+// weights, no spills; the rows, their staging and the mid-tap barrier are the same.  Measured level with the ring form on the headline launch
+// (0.334-0.342 ms both, one box) and 0-5 % ahead on the polyphase layers; E4S_REGION_1W=3 keeps the ring form selectable.
+// LDS: rows 2 x 36 KB + weights 3 x 16 KB (ring form only) + d[region][256] 16 KB + tile tables = 142 KB.  Row layout, swizzle, variant-row logic, weight image
 // ([tap][Cin/16][Cout][16 hi | 16 lo], e4s_split16_bf16x2_f32) and the flag table for tiles with > VMAX variant rows are conv_region.hip's.
 #include "common.h"
 #include <stdlib.h>
@@ -40,6 +45,19 @@ constexpr int MAXR = 16;
 #define E4S_1W_PFD 1
 #endif
 constexpr int PFD = E4S_1W_PFD;
+// B-direct layout (1 x 4 waves): B fragments of tap g + BDPF are loaded during tap g; slot of a tap where the next staging item's four loads
+// start (ILD) and where the previous item's conversion + two LDS stores start (IST .. IST + 12)
+#ifndef E4S_1W_BDPF
+#define E4S_1W_BDPF 1
+#endif
+#ifndef E4S_1W_ILD
+#define E4S_1W_ILD 14
+#endif
+#ifndef E4S_1W_IST
+#define E4S_1W_IST 18
+#endif
+constexpr int BDPF = E4S_1W_BDPF, ILD = E4S_1W_ILD, IST = E4S_1W_IST;
+static_assert((BDPF == 1 || BDPF == 2) && ILD >= 0 && ILD + 3 < 48 && IST >= 0 && IST + 12 < 48, "B-direct pipeline slots");
 static_assert(PFD == 1 || PFD == 2, "weight prefetch distance");
 
 __device__ __forceinline__ int swz(int row, int g) { return row * ROWB + ((g ^ ((row >> 2) & 3)) << 4); }
@@ -139,7 +157,11 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
     constexpr int NTHR = 64 * WM * WN, TM = BM / 32 / WM, TN = BN / 32 / WN;
     constexpr int BJ = BN * 4 / NTHR;                                      // 16-byte weight pieces per thread and tap
     constexpr int NIT = (2 * (HALO + VMAX) + NTHR - 1) / NTHR;             // staging items (LDS row, 8-channel half) per thread and chunk
-    static_assert(NIT + 1 <= 7 && TM >= 2 && TN == 4, "pipeline shape");
+    // BD ("B direct", 1 x 4 waves of 256 pixels x 64 channels): a wave needs only its own 64 columns of the weights, so it loads them straight
+    // into its B fragment registers from the fragment-major image behind the plane-major one (e4s_split16_bf16x2_f32 writes both), a tap
+    // ahead -- no LDS ring, no ds_write_b128 of weights (the LDS write port is ~79 B/clk per CU), no B fragment reads
+    constexpr bool BD = WM == 1 && WN == 4;
+    static_assert(NIT + 1 <= 7 && TM >= 2 && (TN == 4 || (BD && TN == 2)), "pipeline shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                          // [2][NROW][ROWB]
     unsigned char* sB = smem + OFF_B;                  // [NB][BN][ROWB]
@@ -187,9 +209,14 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
     const int b_dst = swz(tid >> 2, tid & 3);             // + NTHR / 4 rows per piece: same swizzle class
 
     // ---- loads that do not depend on the label map: the weights of taps 0..2 of chunk 0, the d table ----
+    // BD: fragment-major image: per (class, tap, chunk, 32-column block) 2 KB = [hi: lane l -> column l & 31, k-half l >> 5][lo: the same]
+    const unsigned char* wf = w16 + (size_t)p.ncls * 9 * nchunk * p.Cout * 64;
+    auto wf_src = [&](int tap, int chunk, int tn) -> const unsigned char* {
+        return wf + ((((size_t)cls * 9 + tap) * nchunk + chunk) * (p.Cout / 32) + (n0 / 32 + wn * TN + tn)) * 2048 + lane * 16;
+    };
     f32x4 pbs[3][BJ], pb1[BJ], pb2[BJ];       // pbs[k]: weights in flight, set (tap + 2) % 3 for the tap they belong to (PFD = 1 uses one set at a time)
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) {
+    for (int j = 0; j < (BD ? 0 : BJ); ++j) {
         pb1[j] = *reinterpret_cast<const f32x4*>(wb + (w_voff + j * (NTHR * 16)));
         pb2[j] = *reinterpret_cast<const f32x4*>(wb + wtap + (w_voff + j * (NTHR * 16)));
         pbs[2][j] = *reinterpret_cast<const f32x4*>(wb + 2 * wtap + (w_voff + j * (NTHR * 16)));
@@ -310,6 +337,20 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
             ro[tm][tap] = swz(row, kh);
         }
     }
+    // 1 x 4 waves (TM = 8): the 72 row offsets (< 2^16 each) packed two per register (groups 2 j and 2 j + 1) -- 36 registers instead of 72
+    unsigned rop[TM / 2][9];
+#pragma unroll
+    for (int j = 0; j < TM / 2; ++j)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) rop[j][tap] = (unsigned)ro[2 * j][tap] | ((unsigned)ro[2 * j + 1][tap] << 16);
+    auto ro_of = [&](int tm, int tap) -> int {
+        if (TM == 8) {
+            unsigned pk = rop[tm >> 1][tap];
+            asm volatile("" : "+v"(pk));            // (opaque: otherwise the loop-invariant halves are hoisted out of the K loop -- 72 registers again)
+            return (tm & 1) ? (int)(pk >> 16) : (int)(pk & 0xffffu);
+        }
+        return ro[tm][tap];
+    };
     const int brow = swz(wn * (TN * 32) + li, kh);         // + 32 rows (2 KB) per tn: same swizzle class
 
     // staging item i of a chunk: LDS row j = (tid + NTHR i) / 2, 8-channel half q
@@ -370,7 +411,7 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
         }
     }
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) {
+    for (int j = 0; j < (BD ? 0 : BJ); ++j) {
         *reinterpret_cast<f32x4*>(sB + 0 * B_SLOT + b_dst + j * (NTHR / 4 * ROWB)) = pb1[j];
         *reinterpret_cast<f32x4*>(sB + 1 * B_SLOT + b_dst + j * (NTHR / 4 * ROWB)) = pb2[j];
     }
@@ -386,13 +427,23 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
 
     // fragments of (chunk 0, tap 0)
     Frag Bf[TN], Af[2];
+    Frag Bd[3][TN];                // BD: B fragments by tap % 3 (two sets live at a time: this tap's and the next one's in flight)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        Bf[tn].h = *reinterpret_cast<const bf16x8*>(sB + brow + tn * (32 * ROWB));
-        Bf[tn].l = *reinterpret_cast<const bf16x8*>(sB + (brow ^ 32) + tn * (32 * ROWB));
+        if (BD) {
+            Bd[0][tn].h = *reinterpret_cast<const bf16x8*>(wf_src(0, 0, tn));
+            Bd[0][tn].l = *reinterpret_cast<const bf16x8*>(wf_src(0, 0, tn) + 1024);
+            if (BDPF == 2) {
+                Bd[1][tn].h = *reinterpret_cast<const bf16x8*>(wf_src(1, 0, tn));
+                Bd[1][tn].l = *reinterpret_cast<const bf16x8*>(wf_src(1, 0, tn) + 1024);
+            }
+        } else {
+            Bf[tn].h = *reinterpret_cast<const bf16x8*>(sB + brow + tn * (32 * ROWB));
+            Bf[tn].l = *reinterpret_cast<const bf16x8*>(sB + (brow ^ 32) + tn * (32 * ROWB));
+        }
     }
-    Af[0].h = *reinterpret_cast<const bf16x8*>(sA + ro[0][0]);
-    Af[0].l = *reinterpret_cast<const bf16x8*>(sA + (ro[0][0] ^ 32));
+    Af[0].h = *reinterpret_cast<const bf16x8*>(sA + ro_of(0, 0));
+    Af[0].l = *reinterpret_cast<const bf16x8*>(sA + (ro_of(0, 0) ^ 32));
 
     if (VAR == 9) tstamp[2] = __builtin_amdgcn_s_memtime();
     f32x8 ix[2], is[2];            // staging items in flight (x, style); two waves per SIMD: only [0]
@@ -401,6 +452,9 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // (Measured and dropped: one instantiation of the K loop per number of staging items the tile really has, 3 .. NIT -- the dummy items of the
+    // branch-free staging cost nothing measurable: 0.3838 vs 0.3799 ms, and the ring layout then spills.)
+    constexpr int NITB = NIT;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool have_nc = chunk + 1 < nchunk;
         const unsigned char* Ab = sA + (chunk & 1) * A_BYTES;
@@ -423,10 +477,10 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
             const unsigned char* Bn = sB + ((t + 1) % 3) * B_SLOT;
             const unsigned char* Anx = t == 8 ? An : Ab;
             const int tnx = (t + 1) % 9;
-            const int it = t - 1 >= 0 && t - 1 < NIT ? t - 1 : 0;
-            const bool st_item = t >= 1 && t <= NIT && (VAR < 2 || VAR == 6 || VAR == 9);
-            const bool ld_item = t < NIT && (VAR < 2 || VAR == 6 || VAR == 9);
-            const int li_ = t < NIT ? t : 0;
+            const int it = t - 1 >= 0 && t - 1 < NITB ? t - 1 : 0;
+            const bool st_item = t >= 1 && t <= NITB && (VAR < 2 || VAR == 6 || VAR == 9);
+            const bool ld_item = t < NITB && (VAR < 2 || VAR == 6 || VAR == 9);
+            const int li_ = t < NITB ? t : 0;
             const int ib = TM > 2 ? (it & 1) : 0, lb = TM > 2 ? (t & 1) : 0;       // register set of the item stored / fetched in this tap
             int d_item = 0;
             if (st_item) d_item = a_dst[it] >= 0 ? an_off + a_dst[it] : dummy;
@@ -502,6 +556,60 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
                     }
                 }
             };
+            if constexpr (BD) {
+                // ---- 1 x 4 waves: 8 groups of 32 pixels x 6 MFMAs (2 column tiles x {hi x lo, lo x hi, hi x hi}); slot n = 6 tm + k.  The A
+                // fragment of the next group rides behind the group's first two MFMAs; the four B fragment loads of the NEXT tap (set (t + 1) % 3,
+                // a tap of flight) and the row staging are spread over the slots; barrier after group 3 ----
+                const int tpf = (t + BDPF) % 9;
+                const unsigned char* wnx0 = wf_src(tpf, t + BDPF >= 9 ? (have_nc ? chunk + 1 : 0) : chunk, 0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    Frag& Ac = Af[tm & 1];
+                    Frag& Ax = Af[(tm + 1) & 1];
+                    const bool last = tm + 1 == TM;
+                    const unsigned char* ap = last ? Anx : Ab;
+                    const int ao = last ? ro_of(0, tnx) : ro_of(last ? 0 : tm + 1, t);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int sweep = k >> 1, tn = k & 1, n = tm * 6 + k;
+                        const Frag& Bc = Bd[t % 3][tn];
+                        acc[tm][tn] = sweep == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h, Bc.l, acc[tm][tn], 0, 0, 0)
+                                    : sweep == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.l, Bc.h, acc[tm][tn], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.h, Bc.h, acc[tm][tn], 0, 0, 0);
+                        if (VAR == 4) {
+                            if (k == 0) Ax = Ac;
+                        } else {
+                            if (k == 0) Ax.h = *reinterpret_cast<const bf16x8*>(ap + ao);
+                            if (k == 1) Ax.l = *reinterpret_cast<const bf16x8*>(ap + (ao ^ 32));
+                        }
+                        if (VAR < 2 || VAR == 5 || VAR == 9) {                     // B fragments of tap t + BDPF: one 1 KB-contiguous load per slot
+                            if (n == 2) Bd[(t + BDPF) % 3][0].h = *reinterpret_cast<const bf16x8*>(wnx0);
+                            if (n == 3) Bd[(t + BDPF) % 3][0].l = *reinterpret_cast<const bf16x8*>(wnx0 + 1024);
+                            if (n == 8) Bd[(t + BDPF) % 3][1].h = *reinterpret_cast<const bf16x8*>(wnx0 + 2048);
+                            if (n == 9) Bd[(t + BDPF) % 3][1].l = *reinterpret_cast<const bf16x8*>(wnx0 + 3072);
+                        }
+                        if (VAR < 2 || VAR == 6 || VAR == 9) {
+                            if (ld_item) {
+                                if (n == ILD + 0) x_fetch(0);
+                                if (n == ILD + 1) x_fetch(1);
+                                if (n == ILD + 2) s_fetch(0);
+                                if (n == ILD + 3) s_fetch(1);
+                            }
+                            if (st_item) {
+                                if (n >= IST && n < IST + 4) hi_pair(n - IST);
+                                if (n == IST + 4) st_hi();
+                                if (n >= IST + 8 && n < IST + 12) lo_pair(n - IST - 8);
+                                if (n == IST + 12) st_lo();
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (tm == TM / 2 - 1 && VAR != 1 && VAR != 3 && VAR != 4) {
+                        lds_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 Frag& Ac = Af[tm & 1];
@@ -535,6 +643,7 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            }
         }
     }
 
@@ -556,7 +665,19 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
                 const int r = 4 * g + i;
                 const int row = (wm * TM + tm) * 32 + i + 8 * g + 4 * kh;
                 const float nz = s_nz[row];
-                const f32x4 d4 = scaled ? *reinterpret_cast<const f32x4*>(sD + ((s_grp[row] * WN + wn) * 32 + li) * TN) : f32x4{1.f, 1.f, 1.f, 1.f};
+                float d4[TN];
+                {
+                    const float* dp = sD + ((s_grp[row] * WN + wn) * 32 + li) * TN;
+                    if (TN == 4) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(dp);
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) d4[tn] = scaled ? v4[tn] : 1.f;
+                    } else {
+                        const float2 v2 = *reinterpret_cast<const float2*>(dp);
+                        d4[0] = scaled ? v2.x : 1.f;
+                        d4[TN - 1] = scaled ? v2.y : 1.f;
+                    }
+                }
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     float t = acc[tm][tn][r] * d4[tn];
@@ -588,10 +709,10 @@ void conv_region_rows1w_kernel(const e4s_conv_params p, const unsigned char* __r
 }  // namespace
 
 // conv_region.hip: launches the 256 x 256-tile kernel for a layer region_rows_ok() accepted, no K split; the caller runs the
-// region-select fallback over the flag table afterwards.  E4S_REGION_1W selects the wave layout: 1 = 2 x 2 waves (one per SIMD),
-// 2 = 4 x 2 waves (two per SIMD)
+// region-select fallback over the flag table afterwards.  E4S_REGION_1W selects the wave layout: 1 = 1 x 4 waves, B-direct (one per SIMD),
+// 2 = 4 x 2 waves (two per SIMD), 3 = 2 x 2 waves with the weight ring
 bool e4s_region_rows1w_ok(const e4s_conv_params& p) {
-    return p.Cout % BN == 0 && p.Cin % 32 == 0 && p.groups_per_batch <= MAXR && (int64_t)p.Hi * p.Wi * p.Cin < (1ll << 30);
+    return p.Cout % BN == 0 && p.Cin % 32 == 0 && p.groups_per_batch <= MAXR && (int64_t)p.Hi * p.Wi * p.Cin < (1ll << 30);       // (Cout % 32 == 0: the fragment-major weight image exists)
 }
 
 template <int WM, int WN>
@@ -629,5 +750,7 @@ static int launch1w(const e4s_conv_params& p, const void* w16, int* flags, hipSt
 }
 
 int e4s_launch_region_rows1w(const e4s_conv_params& p, const void* w16, int* flags, hipStream_t st, int layout) {
-    return layout == 2 ? launch1w<4, 2>(p, w16, flags, st) : launch1w<2, 2>(p, w16, flags, st);
+    // layout (E4S_REGION_1W): 1 = 1 x 4 waves, weights straight into the B fragments (the default); 2 = 4 x 2 waves, two per SIMD (spills:
+    // measurement only); 3 = 2 x 2 waves with the weight ring in LDS (the round's first form)
+    return layout == 2 ? launch1w<4, 2>(p, w16, flags, st) : layout == 3 ? launch1w<2, 2>(p, w16, flags, st) : launch1w<1, 4>(p, w16, flags, st);
 }

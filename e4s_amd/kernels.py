@@ -448,13 +448,22 @@ def split_bf16x2(w, out=None):
     return out
 
 
+def split16_shape(w_shape):
+    """Shape of the opaque fp32-typed tensor split16_bf16x2 fills for tap-packed weights of shape w_shape: (k,) + w_shape, k = 2 when Cout % 32 == 0
+    (plane-major image + fragment-major image, e4s_split16_bytes), else 1."""
+    return (2 if w_shape[-2] % 32 == 0 else 1,) + tuple(w_shape)
+
+
 def split16_bf16x2(w, out=None):
-    """fp32 tap-packed weights [ncls, 9, Cout, Cin] -> the [ncls*9][Cin/16][Cout][16 hi | 16 lo] split image
-    e4s_conv_region_bf16x3_f32 reads (opaque, same byte size)."""
+    """fp32 tap-packed weights [ncls, 9, Cout, Cin] -> the split images e4s_conv_region_bf16x3_f32 reads (opaque): [ncls*9][Cin/16][Cout][16 hi | 16 lo]
+    and, for Cout % 32 == 0, behind it the same values fragment-major (the one-wave-per-SIMD kernel's B fragments come straight from it)."""
     w = _f32(w)
-    out = _into(out, tuple(w.shape), w.device)
+    out = _into(out, split16_shape(w.shape), w.device)
     cout, cin = w.shape[-2], w.shape[-1]
-    call("e4s_split16_bf16x2_f32", fptr(w), ptr(out), w.numel() // (cout * cin), cout, cin, stream())
+    rows = w.numel() // (cout * cin)
+    if lib.load().e4s_split16_bytes(rows, cout, cin) != out.numel() * 4:
+        raise RuntimeError("split16_bf16x2: buffer size")
+    call("e4s_split16_bf16x2_f32", fptr(w), ptr(out), rows, cout, cin, stream())
     return out
 
 

@@ -90,6 +90,7 @@ SIGNATURES = {
     "e4s_conv_region_bf16x3_f32": [ctypes.POINTER(ConvParams), c_p, c_p],
     "e4s_conv_region_ws_floats": [ctypes.POINTER(ConvParams)],
     "e4s_conv_region_path": [ctypes.POINTER(ConvParams)],
+    "e4s_split16_bytes": [ctypes.c_int64, c_i, c_i],
     "e4s_split16_bf16x2_f32": [c_p, c_p, c_l, c_i, c_i, c_p],
     "e4s_upconv_blocks_per_cu": [],
     "e4s_instnorm_ws_doubles": [c_i, c_i, c_i],
@@ -205,7 +206,7 @@ SIGNATURES = {
     "e4s_cosine_bwd_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_l, c_i, c_p],
 }
 
-INT64_RETURN = {"e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats", "e4s_conv_region_ws_floats", "e4s_lpips_layer_ws_doubles", "e4s_conv_mfma_ws_floats",
+INT64_RETURN = {"e4s_split16_bytes", "e4s_instnorm_ws_doubles", "e4s_conv_bwd_ws_floats", "e4s_grouped_linear_t_ws_floats", "e4s_reduce_parts_ws_floats", "e4s_instnorm_bwd_ws_doubles", "e4s_prelu_bwd_ws_floats", "e4s_conv_wgrad_ws_floats", "e4s_conv_bf16x3_ws_floats", "e4s_conv_region_ws_floats", "e4s_lpips_layer_ws_doubles", "e4s_conv_mfma_ws_floats",
                 "e4s_cosine_ws_doubles", "e4s_colsum_ws_floats", "e4s_scale_dot_ws_floats", "e4s_wino_weights_bytes", "e4s_conv_wino_ws_floats"}       # size queries: return a count, not an error code
 
 _lib = None

@@ -246,7 +246,7 @@ class ModulatedConv2d(nn.Module):
 
     def split_weights16(self):
         """16-channel-chunk split image of packed()["w"] for e4s_conv_region_bf16x3_f32 (masked layers; cached with the pack)."""
-        return self._derived("w_split16", lambda pk: K.split16_bf16x2(pk["w"], out=self._buf("w_split16", tuple(pk["w"].shape), pk["w"].device)))
+        return self._derived("w_split16", lambda pk: K.split16_bf16x2(pk["w"], out=self._buf("w_split16", K.split16_shape(pk["w"].shape), pk["w"].device)))
 
     def scatter_taps(self):
         """packed()["w"] [ncls,9,Cout,Cin] as the operand of the scatter-form input gradient (autograd.styled_conv_backward, masked

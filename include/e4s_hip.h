@@ -205,7 +205,9 @@ int e4s_split_bf16x2_f32(const float* w, void* out, int64_t rows, int cin, void*
  * rows, and launches of <= 128 tiles that split K, run on the region-select kernel); w16 = the e4s_split16_bf16x2_f32 image of
  * the same tap-packed weights; p->splitk_ws = e4s_conv_region_ws_floats(p) floats of scratch (tile flags or split-K slabs).
  * e4s_split16_bf16x2_f32: w fp32 [rows][Cout][Cin] (rows = ncls * 9) -> out [rows][Cin/16][Cout][16 hi bf16 | 16 lo bf16]
- * (same byte size), Cin % 16 == 0.
+ * (the byte size of w), Cin % 16 == 0 -- and, ABI v12, for Cout % 32 == 0 behind it the same values fragment-major ([rows][Cin/16][Cout/32]
+ * [hi: 64 lanes x 16 B | lo]), which the one-wave-per-SIMD kernel loads straight into its B fragments: `out` holds e4s_split16_bytes(rows,
+ * Cout, Cin) bytes (twice the size of w then).
  * Which kernel a launch takes (host-side policy, no launch; ABI v12): e4s_conv_region_path(p) = 0 not covered, 1 the 8-wave kernel
  * (256 pixels x 128 channels per block, two waves per SIMD; with a K split for launches of <= 128 tiles), 2 the one-wave-per-SIMD
  * kernel (csrc/conv_region1w.hip: 256 x 256 tiles, 16 accumulator tiles per wave; Cout % 256 == 0 and no K split). */
@@ -213,6 +215,7 @@ int e4s_conv_region_bf16x3_f32(const e4s_conv_params* p, const void* w16, void* 
 int64_t e4s_conv_region_ws_floats(const e4s_conv_params* p);
 int e4s_conv_region_path(const e4s_conv_params* p);
 int e4s_split16_bf16x2_f32(const float* w, void* out, int64_t rows, int cout, int cin, void* stream);
+int64_t e4s_split16_bytes(int64_t rows, int cout, int cin);
 
 /* ---- backward of the fused generator (configs 3 and 5) -------------------- */
 typedef struct {
