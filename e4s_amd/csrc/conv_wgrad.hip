@@ -1,4 +1,6 @@
-// Weight gradient of the 3x3 / 1x1 convolutions on fp32 MFMA (SURVEY.md 8(f) N1 "wgrad"; config 5):
+// Weight gradient of the 3x3 / 1x1 convolutions (SURVEY.md 8(f) N1 "wgrad"; config 5).  Two kernels: the exact-fp32 MFMA kernel right below
+// (region maps, stride 2, 1x1) and, since round 6, conv_wgrad_bf16x3_kernel (3x3, stride 1, no region map: split-bf16 operands on the bf16
+// matrix cores; e4s_conv_wgrad_path tells which one a launch takes).  The contraction:
 //   dW[tap][co][ci] = sum over anchors a of  G[a][co] * X[a (+) tap][ci]
 //   G[a][co] = gz[o(a)][co] * d[g(a)][co],   X[a (+) tap][ci] = x[a*istride + tap - 1][ci] * s[g(a)][ci]
 // with o(a) = a*ostride + phase the output pixel of anchor a (ostride 2 = one phase of the polyphase up-conv) and g(a) its
@@ -10,6 +12,7 @@
 // views, the gz tile once.  Split-K over anchor tiles; the partial [tap][co][ci] slabs are added in a fixed order
 // (e4s_reduce_parts_f32): the result is bit-reproducible.  ~78 KB of LDS: two blocks per CU overlap staging and MFMAs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -130,10 +133,223 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_kernel(const e4s_conv_wgra
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same contraction on the bf16 matrix cores with split operands (round 6; 3x3, input stride 1, no region map): G = hi + lo and
+// X = hi + lo as bf16, three v_mfma_f32_32x32x16_bf16 per product (hi x lo, lo x hi, hi x hi; fp32 accumulate) -- the arithmetic of the
+// forward kernels.  The contraction index is the PIXEL, and the bf16 MFMA wants 8 consecutive k per lane, so the staging TRANSPOSES:
+// a thread owns one channel and 8 consecutive pixels of a row (8 coalesced 4-byte loads, 256 B per wave and pixel), scales by the sample's
+// s / d, splits and writes two 16-byte LDS vectors -- channel-major rows of [16 hi | 16 lo] (G) and [24 hi | 24 lo] per halo row (X).
+// A k-step is one anchor row of 16 pixels; the three column taps of a row are the same two 16-byte chunks shifted by 0 / 1 / 2 elements in
+// registers (v_alignbit), so X is read once per (k-step, tap row), not once per tap.  Anchor tile 4 x 16 (K = 64), X halo 6 x 18,
+// block = 4 waves = 64 (co) x 64 (ci) x 9 taps as above; 55 KB of LDS: two blocks per CU.  Split-K slabs and the ordered reduction are
+// the fp32 kernel's.  Error vs fp64: the 2^-17-class rounding of the split (tests/test_gpu_train.py: <= 2e-5 of max |dW|, as before).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WB_TH = 4, WB_TW = 16, WB_HH = WB_TH + 2, WB_HW = WB_TW + 2;
+constexpr int WB_GROW = WB_TH * 64 + 16;             // bytes per co: [ay][16 hi | 16 lo] + pad (bank spread)
+constexpr int WB_XROW = WB_HH * 96 + 16;             // bytes per ci: [hy][3 chunks hi | 3 chunks lo] + pad
+constexpr int WB_SMEM = BC * (WB_GROW + WB_XROW);          // (+ 64 bytes of region labels behind it)
+
+__device__ __forceinline__ void split8_store(unsigned char* hi_dst, unsigned char* lo_dst, const float (&v)[8]) {
+    u32x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bf16x2 hh = __builtin_convertvector(f32x2{v[2 * j], v[2 * j + 1]}, bf16x2);
+        const unsigned hb = __builtin_bit_cast(unsigned, hh);
+        const float h0 = __builtin_bit_cast(float, hb << 16), h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
+        const bf16x2 ll = __builtin_convertvector(f32x2{v[2 * j] - h0, v[2 * j + 1] - h1}, bf16x2);
+        h[j] = hb;
+        l[j] = __builtin_bit_cast(unsigned, ll);
+    }
+    *reinterpret_cast<u32x4*>(hi_dst) = h;
+    *reinterpret_cast<u32x4*>(lo_dst) = l;
+}
+
+// elements tx .. tx + 7 of the 16 bf16 in (c0, c1)
+template <int TX>
+__device__ __forceinline__ bf16x8 shifted(const u32x4 c0, const u32x4 c1) {
+    u32x4 r;
+    if (TX == 0) r = c0;
+    else if (TX == 2) r = u32x4{c0[1], c0[2], c0[3], c1[0]};
+    else r = u32x4{__builtin_amdgcn_alignbit(c0[1], c0[0], 16), __builtin_amdgcn_alignbit(c0[2], c0[1], 16),
+                   __builtin_amdgcn_alignbit(c0[3], c0[2], 16), __builtin_amdgcn_alignbit(c1[0], c0[3], 16)};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(NTHR, 2) void conv_wgrad_bf16x3_kernel(const e4s_conv_wgrad_params p, const int nct, const int nnt, const int nsplit,
+                                                                    const int tx_n, const int per_img) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* sG = smem_raw;                       // [64 co][WB_GROW]
+    unsigned char* sX = smem_raw + BC * WB_GROW;        // [64 ci][WB_XROW]
+    signed char* sgrp = reinterpret_cast<signed char*>(smem_raw + WB_SMEM);       // MASKED: region of the tile's 64 anchors (-1: outside)
+    const int tid = threadIdx.x, lane0 = tid & 63, wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = lane0, wave = wave0;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;
+    const int split = bid % nsplit; bid /= nsplit;
+    const int nt = bid % nnt, ct = bid / nnt;
+    const int co0 = ct * BC, ci0 = nt * BC;
+    const int ntiles = p.B * per_img;
+    const int R = MASKED ? p.R : 1;
+    const bool co_ok = co0 + lane < p.Cout, ci_ok = ci0 + lane < p.Cin;
+    const bool wave_live = co0 + wm * 32 < p.Cout && ci0 + wn * 32 < p.Cin;       // (Cin or Cout = 32, 96, 160: half tiles)
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        const int tb = tile / per_img;
+        const int rem = tile - tb * per_img;
+        const int tyb = rem / tx_n, txb = rem - tyb * tx_n;
+        int glane = 0;
+        if (MASKED) {
+            // The style of a product belongs to the ANCHOR (model.py:386-400), so a halo pixel is scaled differently by anchors of different
+            // regions: a tile is contracted once per region PRESENT in it -- G masked to the region's anchors (x d[region]), the whole halo
+            // x s[region], k-steps (anchor rows) without an anchor of the region skipped.  Interior tiles have one region: one pass, the
+            // unmasked kernel's work.
+            __syncthreads();                                    // the previous tile's last reader of sgrp is past its ballots
+            if (tid < WB_TH * WB_TW) {
+                const int ya = tyb * WB_TH + tid / WB_TW, xa = txb * WB_TW + tid % WB_TW;
+                sgrp[tid] = (ya < p.Ha && xa < p.Wa) ? (signed char)label_of(p, tb, ya * p.ostride + p.py, xa * p.ostride + p.px) : (signed char)-1;
+            }
+            __syncthreads();
+            glane = sgrp[lane];
+        }
+        for (int g = 0; g < R; ++g) {
+            unsigned long long m = ~0ull;                       // anchors of this pass (bit = 16 ay + ax), block-uniform
+            if (MASKED) {
+                m = __builtin_amdgcn_ballot_w64(glane == g);
+                if (m == 0) continue;
+            }
+            const int grp = tb * R + g;
+            __syncthreads();                                    // previous tile / pass fully consumed
+            // (opaque copies: everything below that depends only on the lane / wave is loop-invariant, and with three loop levels the compiler
+            // hoists it all in front of the tile loop -- 100+ values that then live in scratch across the MFMAs)
+            int lane = lane0, wave = wave0;
+            asm volatile("" : "+v"(lane));
+            asm volatile("" : "+s"(wave));
+            // ---- G: lane = co; wave w takes the (anchor row, half) pairs w and w + 4: 8 anchors each.  Addresses: a wave-uniform base per sample
+            // and ONE 32-bit element offset per row, stepped by a uniform stride (64-bit per-load addresses spilled 100+ registers here) ----
+            const float dv = (p.d && co_ok) ? p.d[(size_t)grp * p.Cout + co0 + lane] : 1.f;
+            const float* gzb = p.gz + (size_t)tb * p.Ho * p.Wo * p.Cout;
+            const float* xsb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin;
+            const int gstep = p.ostride * p.Cout;
+            float gv[2][8];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int j = wave + 4 * r, ay = j >> 1, half = j & 1;
+                const int ya = tyb * WB_TH + ay, xa0 = txb * WB_TW + half * 8;
+                const unsigned mj = (unsigned)(m >> (ay * 16 + half * 8)) & 0xffu;          // wave-uniform
+                int off = ((ya * p.ostride + p.py) * p.Wo + xa0 * p.ostride + p.px) * p.Cout + co0 + lane;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool on = MASKED ? ((mj >> e) & 1u) != 0 : (ya < p.Ha && xa0 + e < p.Wa);
+                    gv[r][e] = (co_ok && on) ? gzb[off] : 0.f;
+                    off += gstep;
+                }
+            }
+            // ---- X: lane = ci; the 18 (halo row, 8-pixel chunk) pairs over the waves ----
+            const float sv = (p.s && ci_ok) ? p.s[(size_t)grp * p.Cin + ci0 + lane] : 1.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[r][e] *= dv;
+                const int j = wave + 4 * r, ay = j >> 1, half = j & 1;
+                unsigned char* d = sG + lane * WB_GROW + ay * 64 + half * 16;
+                split8_store(d, d + 32, gv[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int j = wave + 4 * r;                         // wave-uniform
+                if (j < WB_HH * 3) {
+                    const int hy = j / 3, ch = j - hy * 3;
+                    const int iy = tyb * WB_TH + hy - 1 + p.tap_shift, ix0 = txb * WB_TW + ch * 8 - 1 + p.tap_shift;
+                    const bool row_ok = ci_ok && (unsigned)iy < (unsigned)p.Hi;
+                    int off = (iy * p.Wi + ix0) * p.Cin + ci0 + lane;
+                    float xv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        xv[e] = (row_ok && ch * 8 + e < WB_HW && (unsigned)(ix0 + e) < (unsigned)p.Wi) ? xsb[off] : 0.f;
+                        off += p.Cin;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[e] *= sv;
+                    unsigned char* d = sX + lane * WB_XROW + hy * 96 + ch * 16;
+                    split8_store(d, d + 48, xv);
+                }
+            }
+            __syncthreads();
+            if (!wave_live) continue;
+            // ---- contraction: k-step = anchor row ay (16 anchors), 9 taps x 3 MFMAs ----
+            const unsigned char* gb = sG + (wm * 32 + li) * WB_GROW + kh * 16;
+            const unsigned char* xb = sX + (wn * 32 + li) * WB_XROW + kh * 16;
+#pragma unroll
+            for (int ay = 0; ay < WB_TH; ++ay) {
+                if (MASKED && ((m >> (ay * 16)) & 0xffffull) == 0) continue;           // no anchor of the region in this row: G is zero (-8 % on the step's masked layers)
+                const bf16x8 Gh = *reinterpret_cast<const bf16x8*>(gb + ay * 64), Gl = *reinterpret_cast<const bf16x8*>(gb + ay * 64 + 32);
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) {
+                    const unsigned char* xr = xb + (ay + ty) * 96;
+                    const u32x4 h0 = *reinterpret_cast<const u32x4*>(xr), h1 = *reinterpret_cast<const u32x4*>(xr + 16);
+                    const u32x4 l0 = *reinterpret_cast<const u32x4*>(xr + 48), l1 = *reinterpret_cast<const u32x4*>(xr + 64);
+                    const bf16x8 Xh[3] = {shifted<0>(h0, h1), shifted<1>(h0, h1), shifted<2>(h0, h1)};
+                    const bf16x8 Xl[3] = {shifted<0>(l0, l1), shifted<1>(l0, l1), shifted<2>(l0, l1)};
+                    // small products first; consecutive MFMAs go to different accumulators
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Gh, Xl[tx], acc[ty * 3 + tx], 0, 0, 0);
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Gl, Xh[tx], acc[ty * 3 + tx], 0, 0, 0);
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Gh, Xh[tx], acc[ty * 3 + tx], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial slab of this split: ws[split][tap][co][ci]; 4x4 quad transposes turn four 4-byte stores into one of 16 bytes (common.h) ----
+    const size_t slab = (size_t)9 * p.Cout * p.Cin;
+    float* out = p.ws + (size_t)split * slab;
+    const int ci = ci0 + wn * 32 + (li & ~3);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float a0 = acc[t][4 * g], a1 = acc[t][4 * g + 1], a2 = acc[t][4 * g + 2], a3 = acc[t][4 * g + 3];
+            quad_transpose4(a0, a1, a2, a3, lane);
+            const int co = co0 + wm * 32 + 8 * g + 4 * kh + (lane & 3);
+            if (co < p.Cout && ci < p.Cin) *reinterpret_cast<f32x4*>(out + ((size_t)t * p.Cout + co) * p.Cin + ci) = f32x4{a0, a1, a2, a3};
+        }
+}
+
 template <int IS>
 constexpr int wg_smem() { return (WgTile<IS>::NA * BC + WgTile<IS>::NH * BC + MAXR * BC) * 4 + WgTile<IS>::NA * 4; }
 
+static bool wg_bf16x3(const e4s_conv_wgrad_params& p) {            // E4S_WGRAD_BF16X3 (A/B switch): 0 = the exact-fp32 kernel everywhere, 2 = only without a region map
+    static const int on = [] { const char* e = getenv("E4S_WGRAD_BF16X3"); return e ? atoi(e) : 1; }();
+    static const int min_masked = [] { const char* e = getenv("E4S_WGRAD_MASKED_MIN_ANCHORS"); return e ? atoi(e) : 0; }();
+    return on && p.ntaps == 9 && p.istride == 1 && (!p.labels || (on == 1 && p.Ha * p.Wa >= min_masked));
+}
+
 int wg_nsplit(const e4s_conv_wgrad_params& p) {
+    if (wg_bf16x3(p)) {
+        // two blocks per CU, but at least 4 anchor tiles (K = 256) per block where the layer has them: a block's 147 KB slab (write, read by the
+        // reduction) and its 36 wide stores per lane cost about what two tiles of MFMAs do
+        static const int target = [] { const char* e = getenv("E4S_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+        const int ntiles = p.B * ((p.Ha + WB_TH - 1) / WB_TH) * ((p.Wa + WB_TW - 1) / WB_TW);
+        const int ctiles = ((p.Cout + BC - 1) / BC) * ((p.Cin + BC - 1) / BC);
+        int ns = (target + ctiles - 1) / ctiles;
+        const int per_block = p.labels ? 1 : 4;               // (a masked tile is contracted once per region present in it: 2-4 passes at low resolutions)
+        if (ns > (ntiles + per_block - 1) / per_block) ns = (ntiles + per_block - 1) / per_block;
+        if (ns > 2048) ns = 2048;
+        return ns < 1 ? 1 : ns;
+    }
     const int th = p.istride == 1 ? 8 : 4, tw = p.istride == 1 ? 16 : 8;
     const int ntiles = p.B * ((p.Ha + th - 1) / th) * ((p.Wa + tw - 1) / tw);
     const int ctiles = ((p.Cout + BC - 1) / BC) * ((p.Cin + BC - 1) / BC);
@@ -157,11 +373,25 @@ int launch_wg(const e4s_conv_wgrad_params& p, hipStream_t st) {
     return 0;
 }
 
+int launch_wg_bf16x3(const e4s_conv_wgrad_params& p, hipStream_t st) {
+    auto kern = p.labels ? conv_wgrad_bf16x3_kernel<true> : conv_wgrad_bf16x3_kernel<false>;
+    static std::atomic<uint64_t> smem_set[2] = {{0}, {0}};
+    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), WB_SMEM + 64, smem_set[p.labels ? 1 : 0])) return e;
+    const int nct = (p.Cout + BC - 1) / BC, nnt = (p.Cin + BC - 1) / BC;
+    const int tx_n = (p.Wa + WB_TW - 1) / WB_TW, per_img = ((p.Ha + WB_TH - 1) / WB_TH) * tx_n;
+    const int ns = wg_nsplit(p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nct * nnt * ns)), dim3(NTHR), WB_SMEM + 64, st, p, nct, nnt, ns, tx_n, per_img);
+    E4S_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int64_t e4s_conv_wgrad_ws_floats(const e4s_conv_wgrad_params* p) {
     return e4s_reduce_parts_ws_floats(wg_nsplit(*p), (int64_t)p->ntaps * p->Cout * p->Cin);
 }
+
+extern "C" int e4s_conv_wgrad_path(const e4s_conv_wgrad_params* p) { return p && wg_bf16x3(*p) ? 1 : 0; }
 
 extern "C" int e4s_conv_wgrad_f32(const e4s_conv_wgrad_params* pp, void* stream) {
     const e4s_conv_wgrad_params& p = *pp;
@@ -171,7 +401,9 @@ extern "C" int e4s_conv_wgrad_f32(const e4s_conv_wgrad_params* pp, void* stream)
     if ((p.Ha - 1) * p.ostride + p.py >= p.Ho || (p.Wa - 1) * p.ostride + p.px >= p.Wo) return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
     int rc;
-    if (p.istride == 1) rc = p.ntaps == 9 ? launch_wg<1, 9>(p, st) : launch_wg<1, 1>(p, st);
+    if (wg_bf16x3(p) && ((int64_t)p.Ho * p.Wo * p.Cout >= (1ll << 31) || (int64_t)p.Hi * p.Wi * p.Cin >= (1ll << 31))) return (int)hipErrorInvalidValue;
+    if (wg_bf16x3(p)) rc = launch_wg_bf16x3(p, st);
+    else if (p.istride == 1) rc = p.ntaps == 9 ? launch_wg<1, 9>(p, st) : launch_wg<1, 1>(p, st);
     else rc = p.ntaps == 9 ? launch_wg<2, 9>(p, st) : launch_wg<2, 1>(p, st);
     if (rc) return rc;
     return e4s_reduce_parts_f32(p.ws, p.dw, wg_nsplit(p), (int64_t)p.ntaps * p.Cout * p.Cin, 1.f, stream);

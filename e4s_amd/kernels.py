@@ -960,6 +960,9 @@ def ema_(dst, src, decay):
     return dst
 
 
+LAST_WGRAD_PATH = 0            # which kernel the last conv_wgrad launch took (e4s_conv_wgrad_path)
+
+
 def conv_wgrad(gz, x, *, ntaps=9, istride=1, anchors=None, ostride=1, phase=(0, 0), s=None, d=None, labels=None,
                num_regions=1, tap_shift=0):
     """dw [ntaps, Cout, Cin] of a 3x3 / 1x1 conv (see e4s_conv_wgrad_f32): gz NHWC [B,Ho,Wo,Cout], x NHWC [B,Hi,Wi,Cin].
@@ -979,6 +982,8 @@ def conv_wgrad(gz, x, *, ntaps=9, istride=1, anchors=None, ostride=1, phase=(0, 
     p.istride, p.ostride, p.py, p.px, p.ntaps = istride, ostride, phase[0], phase[1], ntaps
     p.tap_shift = int(tap_shift)
     p.ws = None
+    global LAST_WGRAD_PATH
+    LAST_WGRAD_PATH = lib.load().e4s_conv_wgrad_path(ctypes.byref(p))          # 1: split-bf16 kernel, 0: exact-fp32 kernel (tests)
     ws = torch.empty(lib.load().e4s_conv_wgrad_ws_floats(ctypes.byref(p)), device=x.device, dtype=torch.float32)
     p.ws = fptr(ws)
     call("e4s_conv_wgrad_f32", ctypes.byref(p), stream())

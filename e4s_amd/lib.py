@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E4S_LIB_PATH") or os.path.join(_HERE, "libe4s_hip.so")      # (E4S_LIB_PATH: A/B runs of two builds)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -165,6 +165,7 @@ SIGNATURES = {
     "e4s_region_mean_f32": [c_p, c_p, c_i, c_i, c_p] + [c_i] * 7 + [c_p],
     "e4s_conv_wgrad_f32": [ctypes.POINTER(ConvWgradParams), c_p],
     "e4s_conv_wgrad_ws_floats": [ctypes.POINTER(ConvWgradParams)],
+    "e4s_conv_wgrad_path": [ctypes.POINTER(ConvWgradParams)],
     "e4s_instnorm_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "e4s_instnorm_bwd_ws_doubles": [c_i, c_i, c_i],
     "e4s_prelu_f32": [c_p, c_p, c_p, c_l, c_i, c_p],

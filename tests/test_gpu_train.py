@@ -214,10 +214,85 @@ def test_conv_wgrad_kernel_vs_fp64(b, h, w, cin, cout, stride, ntaps):
     gz = torch.randn(y.shape, generator=g, dtype=torch.float64)
     (y * gz).sum().backward()
     dw = K.conv_wgrad(K.nchw_to_nhwc(gz.float().to(DEV)), K.nchw_to_nhwc(x.float().to(DEV)), ntaps=ntaps, istride=stride)
+    assert K.LAST_WGRAD_PATH == (1 if (ntaps == 9 and stride == 1) else 0)      # 3x3 stride 1 without a region map: the split-bf16 kernel
     got = dw.permute(1, 2, 0).reshape(cout, cin, k, k)
     assert maxabs(got, wt.grad) < 2e-5 * float(wt.grad.abs().max())
     dw2 = K.conv_wgrad(K.nchw_to_nhwc(gz.float().to(DEV)), K.nchw_to_nhwc(x.float().to(DEV)), ntaps=ntaps, istride=stride)
     assert torch.equal(dw, dw2)                                        # ordered split-K: bit-reproducible
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,os_,shift", [(2, 8, 16, 64, 64, 1, 0), (3, 13, 37, 96, 160, 1, 0), (2, 9, 20, 128, 32, 2, 0), (1, 12, 18, 32, 64, 1, 1),
+                                                       (2, 32, 32, 512, 512, 1, 0)])
+def test_conv_wgrad_bf16x3_kernel_scales_phases_and_ragged_tiles_vs_fp64(b, h, w, cin, cout, os_, shift):
+    """conv_wgrad_bf16x3_kernel (csrc/conv_wgrad.hip; model.py:386-400's weight gradient without a region map): per-sample modulation s and
+    demodulation d folded into the staged operands, one phase of the polyphase up-conv (ostride 2: anchors = input pixels, gz read at
+    2a + phase), the padding-0 tap origin (tap_shift 1), anchor grids that are not multiples of the 4 x 16 tile, 32- / 96- / 160-channel
+    operands (half tiles), and the encoder's 512 x 512 @ 32^2 layer (K = 2048 pixels, 8 slabs).  Reference: the same sum in fp64 on the CPU.
+    <= 2e-5 of max |dW| (the 2^-17-class rounding of the split, as for the exact-fp32 kernel's test above); bit-reproducible."""
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(b, h, w, cin, generator=g, dtype=torch.float64)
+    ha, wa = (h, w) if shift == 0 else (h - 2, w - 2)
+    gz = torch.randn(b, ha * os_, wa * os_, cout, generator=g, dtype=torch.float64)
+    sm = torch.rand(b, cin, generator=g, dtype=torch.float64) + 0.5
+    dm = torch.rand(b, cout, generator=g, dtype=torch.float64) + 0.5
+    ph = (1, 0) if os_ == 2 else (0, 0)
+    G = gz[:, ph[0]::os_, ph[1]::os_, :] * dm[:, None, None, :]                    # [b, ha, wa, cout]
+    X = x * sm[:, None, None, :]
+    Xp = torch.nn.functional.pad(X, (0, 0, 1, 1, 1, 1)) if shift == 0 else X       # tap t reads x[a + t - 1 + shift]
+    ref = torch.zeros(9, cout, cin, dtype=torch.float64)
+    for t in range(9):
+        ty, tx = divmod(t, 3)
+        ref[t] = torch.einsum("bhwo,bhwi->oi", G, Xp[:, ty:ty + ha, tx:tx + wa, :])
+    kw = dict(ntaps=9, istride=1, ostride=os_, phase=ph, anchors=(ha, wa), s=sm.float().to(DEV), d=dm.float().to(DEV), tap_shift=shift)
+    dw = K.conv_wgrad(gz.float().to(DEV), x.float().to(DEV), **kw)
+    assert K.LAST_WGRAD_PATH == 1
+    assert maxabs(dw, ref) < 2e-5 * float(ref.abs().max())
+    assert torch.equal(dw, K.conv_wgrad(gz.float().to(DEV), x.float().to(DEV), **kw))
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,os_,R,mapkind", [(2, 16, 32, 64, 64, 1, 12, "blocks"), (1, 13, 37, 96, 32, 1, 5, "noise"), (2, 12, 24, 64, 128, 2, 12, "blocks"),
+                                                          (1, 32, 32, 128, 64, 2, 16, "half"), (2, 64, 64, 128, 128, 1, 12, "face")])
+def test_conv_wgrad_bf16x3_kernel_with_region_map_vs_fp64(b, h, w, cin, cout, os_, R, mapkind):
+    """The masked StyledConv's weight gradient (model.py:386-400: style and demodulation of a product belong to the OUTPUT pixel's region) on
+    conv_wgrad_bf16x3_kernel<MASKED>: one pass per region present in a 4 x 16 anchor tile (G masked to the region's anchors, the halo
+    scaled by the region's style).  Maps: coarse blocks (1-4 regions per tile), per-pixel noise (every region in every tile), a map at half
+    the output resolution (legacy-nearest lookup, model.py:391), a face-like map; same-resolution layers and one polyphase phase
+    (ostride 2).  Reference: the same sum in fp64 on the CPU.  <= 2e-5 of max |dW|; bit-reproducible."""
+    from e4s_amd import kernels as K
+    g = torch.Generator().manual_seed(31)
+    ho, wo = h * os_, w * os_
+    if mapkind == "blocks":
+        lab = torch.randint(0, R, (b, (ho + 5) // 6, (wo + 6) // 7), generator=g).repeat_interleave(6, 1).repeat_interleave(7, 2)[:, :ho, :wo]
+    elif mapkind == "noise":
+        lab = torch.randint(0, R, (b, ho, wo), generator=g)
+    elif mapkind == "half":
+        lab = torch.randint(0, R, (b, ho // 2, wo // 2), generator=g)
+    else:
+        lab = synth.synth_labels_face(b, ho, seed=3)[:, 0, :ho, :wo]
+    lab = lab.to(torch.uint8).contiguous()
+    hm, wm = lab.shape[1:]
+    x = torch.randn(b, h, w, cin, generator=g, dtype=torch.float64)
+    gz = torch.randn(b, ho, wo, cout, generator=g, dtype=torch.float64)
+    sm = torch.rand(b * R, cin, generator=g, dtype=torch.float64) + 0.5
+    dm = torch.rand(b * R, cout, generator=g, dtype=torch.float64) + 0.5
+    ph = (1, 0) if os_ == 2 else (0, 0)
+    oy = torch.arange(h) * os_ + ph[0]
+    ox = torch.arange(w) * os_ + ph[1]
+    sy = torch.clamp(torch.floor(oy.float() * (float(hm) / float(ho))).long(), max=hm - 1)      # csrc label_of: fp32 arithmetic
+    sx = torch.clamp(torch.floor(ox.float() * (float(wm) / float(wo))).long(), max=wm - 1)
+    la = lab.long()[:, sy][:, :, sx] + (torch.arange(b) * R)[:, None, None]                      # group of every anchor [b, h, w]
+    G = gz[:, ph[0]::os_, ph[1]::os_, :] * dm[la]
+    Xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
+    ref = torch.zeros(9, cout, cin, dtype=torch.float64)
+    for t in range(9):
+        ty, tx = divmod(t, 3)
+        ref[t] = torch.einsum("bhwo,bhwi->oi", G, Xp[:, ty:ty + h, tx:tx + w, :] * sm[la])
+    kw = dict(ntaps=9, istride=1, ostride=os_, phase=ph, anchors=(h, w), s=sm.float().to(DEV), d=dm.float().to(DEV), labels=lab.to(DEV), num_regions=R)
+    dw = K.conv_wgrad(gz.float().to(DEV), x.float().to(DEV), **kw)
+    assert K.LAST_WGRAD_PATH == 1
+    assert maxabs(dw, ref) < 2e-5 * float(ref.abs().max())
+    assert torch.equal(dw, K.conv_wgrad(gz.float().to(DEV), x.float().to(DEV), **kw))
 
 
 def _loss_modules(size):
