@@ -331,22 +331,27 @@ int linear_t_nsplit(int R, int O, int K) {
 // then through the modulation EqualLinear into the layer's latent slot.  Per layer that was 2 transposed contractions with their ordered
 // second stages and 3-5 ATen glue launches -- ~170 launches of 5-10 us in an l2-only latent-optimisation step of 472.  The jobs travel BY VALUE
 // in the kernel arguments (a HIP-graph capture bakes them in; the addresses of a captured step are stable under replay).
+constexpr int SG_U = 8;          // weight rows in flight per wave in both stages
+constexpr int SG_CL = 16, SG_NG = 256 / SG_CL;      // a block = 16 lanes x 4 output columns, 16 groups of lanes over the contraction
+constexpr int SG_CH = 512;       // channels of coefficients staged in LDS per pass (TB x SG_CH floats inside the 60 KB reduction buffer)
+static_assert(TB * SG_CH * 4 <= (SG_NG - 1) * TB * SG_CL * 16 && (SG_NG - 1) * TB * SG_CL * 16 <= 64 * 1024, "staging aliases the reduction buffer");
 struct StyleGradJobs {
     e4s_style_grad_job j[E4S_STYLE_GRAD_MAX_JOBS];
-    int blk0[E4S_STYLE_GRAD_MAX_JOBS + 1];      // stage 1: first block of job i (256 input channels per block)
+    int blk0[E4S_STYLE_GRAD_MAX_JOBS + 1];      // stage 1: first block of job i (64 input channels per block)
     int n;
 };
 
 // stage 1: ds_total[g][ci] = ds_raw[g][ci] - s[g][ci] * sum_co (dd_d[g][co] d[g][co]^2) Wsq[co][ci]          (StyledConv)
 //          ds_total[g][ci] = conv_scale * ((dws[g][0][ci] w3[0][ci] + dws[g][1][ci] w3[1][ci]) + dws[g][2][ci] w3[2][ci])   (ToRGB)
-// block = (job, 256 input channels): four waves walk Cout (wave w takes rows w, w + 4, ...), 16 rows g per pass, cross-wave sum in order
+// block = (job, 64 input channels): 16 lanes x 4 channels, SG_NG = 16 groups of lanes walk Cout (group w takes rows w, w + 16, ...), 16 rows g per
+// pass, cross-group sum in order (round 6: 64- instead of 256-channel blocks -- ~200 blocks instead of ~50 for a latency-bound loop)
 __global__ __launch_bounds__(256) void style_grad_stage1_kernel(const StyleGradJobs J) {
-    __shared__ f32x4 red[3][TB][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ f32x4 red[SG_NG - 1][TB][SG_CL];
+    const int lane = threadIdx.x & (SG_CL - 1), wv = threadIdx.x / SG_CL;
     int ji = 0;
     while (ji + 1 < J.n && (int)blockIdx.x >= J.blk0[ji + 1]) ++ji;
     const e4s_style_grad_job& q = J.j[ji];
-    const int k = (((int)blockIdx.x - J.blk0[ji]) * 64 + lane) * 4;
+    const int k = (((int)blockIdx.x - J.blk0[ji]) * SG_CL + lane) * 4;
     const bool live = k < q.Cin;
     if (q.dws) {                                             // ToRGB: elementwise
         if (wv == 0 && live)
@@ -360,21 +365,43 @@ __global__ __launch_bounds__(256) void style_grad_stage1_kernel(const StyleGradJ
         return;
     }
     const float* wr = q.wsq + (live ? k : 0);
+    float* sc = reinterpret_cast<float*>(&red[0][0][0]);     // [TB][SG_CH] staged coefficients; the same LDS serves the cross-wave sum afterwards
     for (int g0 = 0; g0 < q.G; g0 += TB) {
         const int nb = min(TB, q.G - g0);
         f32x4 acc[TB];
 #pragma unroll
         for (int b = 0; b < TB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int co = wv; co < q.Cout; co += 4) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + (int64_t)co * q.Cin);
+        // The coefficients dd d^2 of a chunk of output channels go through LDS (coalesced loads, then broadcast reads) and SG_U weight rows are
+        // in flight per wave: the loop used to be one exposed round trip per output channel (wave-uniform global loads inside it): 261 us
+        // for ~50 blocks.  Products and the order of the additions are unchanged.
+        for (int c0 = 0; c0 < q.Cout; c0 += SG_CH) {
+            const int cw = min(SG_CH, q.Cout - c0);
+            __syncthreads();                                 // previous chunk / pass consumed
+            for (int i = threadIdx.x; i < nb * cw; i += 256) {
+                const int b = i / cw, c = i - b * cw;
+                const float dd = q.dd_d[(int64_t)(g0 + b) * q.Cout + c0 + c], dv = q.d[(int64_t)(g0 + b) * q.Cout + c0 + c];
+                sc[b * SG_CH + c] = dd * (dv * dv);
+            }
+            __syncthreads();
+            for (int cb = wv; cb < cw; cb += SG_NG * SG_U) {
+                f32x4 w4[SG_U];
 #pragma unroll
-            for (int b = 0; b < TB; ++b)
-                if (b < nb) {
-                    const float dd = q.dd_d[(int64_t)(g0 + b) * q.Cout + co], dv = q.d[(int64_t)(g0 + b) * q.Cout + co];
-                    acc[b] += (dd * (dv * dv)) * w4;                     // wave-uniform scalar
+                for (int u = 0; u < SG_U; ++u) {
+                    const int c = cb + SG_NG * u;
+                    w4[u] = c < cw ? *reinterpret_cast<const f32x4*>(wr + (int64_t)(c0 + c) * q.Cin) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+#pragma unroll
+                for (int u = 0; u < SG_U; ++u) {
+                    const int c = cb + SG_NG * u;
+                    if (c < cw) {
+#pragma unroll
+                        for (int b = 0; b < TB; ++b)
+                            if (b < nb) acc[b] += sc[b * SG_CH + c] * w4[u];
+                    }
+                }
+            }
         }
-        __syncthreads();                                     // (red is re-used by the next pass)
+        __syncthreads();                                     // (the staging buffer becomes the reduction buffer)
         if (wv > 0) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) red[wv - 1][b][lane] = acc[b];
@@ -384,7 +411,9 @@ __global__ __launch_bounds__(256) void style_grad_stage1_kernel(const StyleGradJ
 #pragma unroll
             for (int b = 0; b < TB; ++b)
                 if (b < nb) {
-                    const f32x4 v = ((acc[b] + red[0][b][lane]) + red[1][b][lane]) + red[2][b][lane];
+                    f32x4 v = acc[b];
+#pragma unroll
+                    for (int w = 0; w < SG_NG - 1; ++w) v += red[w][b][lane];
                     const int64_t o = (int64_t)(g0 + b) * q.Cin + k;
                     *reinterpret_cast<f32x4*>(q.ds_total + o) =
                         *reinterpret_cast<const f32x4*>(q.ds_raw + o) - *reinterpret_cast<const f32x4*>(q.s + o) * v;
@@ -395,35 +424,61 @@ __global__ __launch_bounds__(256) void style_grad_stage1_kernel(const StyleGradJ
 
 // stage 2: dlat[b][r][slot][:] = sum over the jobs of that slot, in job order, of mod_scale * ds_total[g] @ Wmod   (Wmod [Cin][S]).
 // A masked job's row g = b * R + r feeds dlat[b][r]; an unmasked job's row g = b feeds dlat[b][0].  Every (row, slot) is written, zeros
-// included.  grid = (NL * ceil(S / 256), ceil(B * R / 16)); the four waves walk Cin, cross-wave sum in order.
+// included.  grid = (NL * ceil(S / 64), ceil(B * R / 16)); 16 lanes x 4 columns, the SG_NG = 16 lane groups walk Cin, cross-group sum in order.
 __global__ __launch_bounds__(256) void style_grad_stage2_kernel(const StyleGradJobs J, float* __restrict__ dlat, const int BR,
                                                                 const int R, const int NL, const int S) {
-    __shared__ f32x4 red[3][TB][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int kblk = (S + 255) / 256;
+    __shared__ f32x4 red[SG_NG - 1][TB][SG_CL];
+    const int lane = threadIdx.x & (SG_CL - 1), wv = threadIdx.x / SG_CL;
+    const int kblk = (S + 4 * SG_CL - 1) / (4 * SG_CL);
     const int slot = blockIdx.x / kblk;
-    const int k = ((blockIdx.x - slot * kblk) * 64 + lane) * 4;
+    const int k = ((blockIdx.x - slot * kblk) * SG_CL + lane) * 4;
     const bool live = k < S;
     const int r0 = blockIdx.y * TB;                          // first dlat row (b * R + r) of this block
     f32x4 acc[TB];
 #pragma unroll
     for (int b = 0; b < TB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* sc = reinterpret_cast<float*>(&red[0][0][0]);     // [TB][SG_CH] staged rows of ds_total * mod_scale; the reduction buffer afterwards
     for (int ji = 0; ji < J.n; ++ji) {
         const e4s_style_grad_job& q = J.j[ji];
         if (q.slot != slot) continue;
         const float* wr = q.wmod + (live ? k : 0);
-        for (int ci = wv; ci < q.Cin; ci += 4) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + (int64_t)ci * S);
+        unsigned use = 0;                                    // rows of this block the job feeds
 #pragma unroll
-            for (int b = 0; b < TB; ++b) {
+        for (int b = 0; b < TB; ++b)
+            if (r0 + b < BR && (q.masked || (r0 + b) % R == 0)) use |= 1u << b;
+        // ds_total rows through LDS, SG_U rows of Wmod in flight per wave (the loop was one exposed round trip per input channel: 560 us for
+        // 36 blocks); products and the order of the additions are unchanged
+        for (int c0 = 0; c0 < q.Cin; c0 += SG_CH) {
+            const int cw = min(SG_CH, q.Cin - c0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < TB * cw; i += 256) {
+                const int b = i / cw, c = i - b * cw;
                 const int row = r0 + b;
-                if (row < BR) {
-                    if (q.masked) acc[b] += (q.ds_total[(int64_t)row * q.Cin + ci] * q.mod_scale) * w4;
-                    else if (row % R == 0) acc[b] += (q.ds_total[(int64_t)(row / R) * q.Cin + ci] * q.mod_scale) * w4;
+                float v = 0.f;
+                if ((use >> b) & 1u) v = q.ds_total[(int64_t)(q.masked ? row : row / R) * q.Cin + c0 + c] * q.mod_scale;
+                sc[b * SG_CH + c] = v;
+            }
+            __syncthreads();
+            for (int cb = wv; cb < cw; cb += SG_NG * SG_U) {
+                f32x4 w4[SG_U];
+#pragma unroll
+                for (int u = 0; u < SG_U; ++u) {
+                    const int c = cb + SG_NG * u;
+                    w4[u] = c < cw ? *reinterpret_cast<const f32x4*>(wr + (int64_t)(c0 + c) * S) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < SG_U; ++u) {
+                    const int c = cb + SG_NG * u;
+                    if (c < cw) {
+#pragma unroll
+                        for (int b = 0; b < TB; ++b)
+                            if ((use >> b) & 1u) acc[b] += sc[b * SG_CH + c] * w4[u];
+                    }
                 }
             }
         }
     }
+    __syncthreads();                                         // (the staging buffer becomes the reduction buffer)
     if (wv > 0) {
 #pragma unroll
         for (int b = 0; b < TB; ++b) red[wv - 1][b][lane] = acc[b];
@@ -433,9 +488,12 @@ __global__ __launch_bounds__(256) void style_grad_stage2_kernel(const StyleGradJ
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
             const int row = r0 + b;
-            if (row < BR)
-                *reinterpret_cast<f32x4*>(dlat + ((int64_t)row * NL + slot) * S + k) =
-                    ((acc[b] + red[0][b][lane]) + red[1][b][lane]) + red[2][b][lane];
+            if (row < BR) {
+                f32x4 v = acc[b];
+#pragma unroll
+                for (int w = 0; w < SG_NG - 1; ++w) v += red[w][b][lane];
+                *reinterpret_cast<f32x4*>(dlat + ((int64_t)row * NL + slot) * S + k) = v;
+            }
         }
     }
 }
@@ -648,7 +706,7 @@ extern "C" int e4s_style_grad_multi_f32(const e4s_style_grad_job* jobs, int njob
             return (int)hipErrorInvalidValue;
         J.j[i] = q;
         J.blk0[i] = blocks;
-        blocks += (q.Cin + 255) / 256;
+        blocks += (q.Cin + 4 * SG_CL - 1) / (4 * SG_CL);
     }
     J.blk0[njobs] = blocks;
     hipStream_t st = as_stream(stream);
@@ -657,7 +715,7 @@ extern "C" int e4s_style_grad_multi_f32(const e4s_style_grad_job* jobs, int njob
         E4S_CHECK_LAUNCH();
     }
     const int BR = B * R;
-    hipLaunchKernelGGL(style_grad_stage2_kernel, dim3((unsigned)(NL * ((S + 255) / 256)), (unsigned)((BR + TB - 1) / TB)), dim3(256), 0,
+    hipLaunchKernelGGL(style_grad_stage2_kernel, dim3((unsigned)(NL * ((S + 4 * SG_CL - 1) / (4 * SG_CL))), (unsigned)((BR + TB - 1) / TB)), dim3(256), 0,
                        st, J, dlat, BR, R, NL, S);
     E4S_CHECK_LAUNCH();
     return 0;
