@@ -43,8 +43,7 @@ def styled_conv_backward(rec, dy, num_regions, extras=None, defer=None):
         # exact-fp32 dx + ds kernel ran the 64->64@512^2 / 32->32@1024^2 dgrads of the optimisation step at 0.69 / 0.71 ms, the forward
         # kernels take ~0.1); ds = sum_p x * (the same contraction) leaves the pass that applies s
         if "wt_fwd" not in pk:
-            wp = K.pack_taps(conv.weight.detach()[0].float().flip(2, 3).transpose(0, 1).contiguous(),
-                             out=conv._buf("wt_fwd", (1, 9, cin, cout), x.device))                          # [1,9,Cin,Cout]
+            wp = K.pack_taps_bwd(pk["w"], out=conv._buf("wt_fwd", (1, 9, cin, cout), x.device))           # [1,9,Cin,Cout], taps flipped (one launch)
             pk["wt_fwd"] = (wp, K.split_bf16x2(wp, out=conv._buf("wt_fwd_split", (1, 9, cin, cout), x.device)))
         wp, wps = pk["wt_fwd"]
         if cout == 32 and cin % 32 == 0:

@@ -57,7 +57,10 @@ def _pack(w, cache=None):
 
 
 def _pack_t(w, cache=None):
-    make = lambda: K.pack_taps(w.detach().float().flip(2, 3).transpose(0, 1).contiguous())
+    if w.shape[2] == 3:          # one launch from the forward pack (was flip + transpose copy + pack)
+        make = lambda: K.pack_taps_bwd(_pack(w, cache))
+    else:
+        make = lambda: K.pack_taps(w.detach().float().flip(2, 3).transpose(0, 1).contiguous())
     return cache[0].get(cache[1], "bwd", make) if cache is not None else make()
 
 

@@ -52,7 +52,7 @@ def _dgrad3x3(gz, conv, x):
         key = _pack3x3(conv) is not None and conv._e4s_pack[0]
         cached = getattr(conv, "_e4s_wt_fwd", None)
         if cached is None or cached[0] != key:
-            wp = K.pack_taps(conv.weight.detach().float().flip(2, 3).transpose(0, 1).contiguous())      # [1,9,Cin,Cout]
+            wp = K.pack_taps_bwd(_pack3x3(conv))      # [1,9,Cin,Cout], taps flipped: one launch from the forward pack (was flip + transpose copy + pack)
             conv._e4s_wt_fwd = cached = (key, wp, K.split_bf16x2(wp), {})
         if K.wino_eligible(b, h, w, cy, cx):       # Winograd F(2,3) form of the same convolution (csrc/conv_wino.hip): 1.5x fewer MFMAs
             if "u" not in cached[3]:

@@ -295,6 +295,16 @@ def test_conv_wgrad_bf16x3_kernel_with_region_map_vs_fp64(b, h, w, cin, cout, os
     assert torch.equal(dw, K.conv_wgrad(gz.float().to(DEV), x.float().to(DEV), **kw))
 
 
+def test_backward_pack_from_the_forward_pack_equals_the_pack_of_the_flipped_transposed_weight():
+    """The dgrad-as-forward-conv operand (encoder_autograd._dgrad3x3, autograd.styled_conv_backward, disc_autograd._pack_t) is built in ONE
+    launch from the forward pack (e4s_pack_taps_bwd_f32); it must be bit-identical to packing w.flip(2, 3).transpose(0, 1)."""
+    from e4s_amd import kernels as K
+    w = torch.randn(96, 160, 3, 3, generator=torch.Generator().manual_seed(5)).to(DEV)
+    a = K.pack_taps_bwd(K.pack_taps(w.contiguous()))
+    b = K.pack_taps(w.flip(2, 3).transpose(0, 1).contiguous())
+    assert a.shape == b.shape == (1, 9, 160, 96) and torch.equal(a, b)
+
+
 def _loss_modules(size):
     """The generator step's loss networks + Discriminator on seeded synthetic weights (modules on the GPU, state dicts for the
     oracle)."""
