@@ -60,6 +60,30 @@ __global__ void reduce_chunks_kernel(const float* __restrict__ part, float* __re
 
 // out[i] = base[i] + mul[i] * scale * gate(i) * sum_{s < nparts} part[s * n + i]      (parts added in order)
 // gate: ref ? (ref[i] > 0 ? 1 : alpha) : 1  (leaky-ReLU derivative keyed on the saved activation)
+// The plain sum (no base / mul / gate), four outputs per thread and eight parts in flight, added in part order like the scalar kernels
+// below (the same result bit for bit; n % 4 == 0 and 16-byte aligned buffers).  One 4-byte load per dependent add ran the weight-gradient
+// slabs (8 x 9.4 MB) at ~1.8 TB/s; ~300 of these launches per config-5 G step.
+template <bool CHUNKS>
+__global__ __launch_bounds__(256) void reduce_parts_v4_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int64_t n4,
+                                                              float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int p0 = CHUNKS ? blockIdx.y * RCHUNK : 0, p1 = CHUNKS ? min(p0 + RCHUNK, nparts) : nparts;
+    const f32x4* src = reinterpret_cast<const f32x4*>(part) + i;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    for (int p = p0; p < p1; p += U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = p + u < p1 ? src[(int64_t)(p + u) * n4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (p + u < p1) s += v[u];
+    }
+    if (!CHUNKS) s *= scale;
+    reinterpret_cast<f32x4*>(out)[(CHUNKS ? (int64_t)blockIdx.y * n4 : 0) + i] = s;
+}
+
 __global__ void reduce_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int64_t n,
                                     float scale, const float* __restrict__ base, const float* __restrict__ mul,
                                     const float* __restrict__ ref, float alpha) {
@@ -110,8 +134,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = min(r0 + rpb, rows);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (rl < lanes)
-        for (int64_t r = r0 + rl; r < r1; r += lanes) acc += *reinterpret_cast<const f32x4*>(x + r * C + c4 * 4);
+    if (rl < lanes) {
+        // eight rows in flight per thread, added in row order (one load per dependent add ran the 2 M-row sums of the Discriminator's 1024^2 layers
+        // at 0.64 TB/s: 421 us)
+        constexpr int U = 8;
+        const float* xp = x + c4 * 4;
+        for (int64_t r = r0 + rl; r < r1; r += (int64_t)lanes * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t rr = r + (int64_t)u * lanes;
+                v[u] = rr < r1 ? *reinterpret_cast<const f32x4*>(xp + rr * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (r + (int64_t)u * lanes < r1) acc += v[u];
+        }
+    }
     sm[threadIdx.x] = acc;
     __syncthreads();
     if (rl == 0) {
@@ -531,14 +570,21 @@ extern "C" int e4s_reduce_parts_f32(float* parts, float* out, int nparts, int64_
     if (nparts > RCHUNK * RCHUNK * 4) return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
     const float* src = parts;
+    const bool v4 = n % 4 == 0 && ((uintptr_t)parts & 15) == 0 && ((uintptr_t)out & 15) == 0;
     if (nparts > RCHUNK) {      // two levels, both in part order: chunk sums first (parallel over chunks), then the chunks
         const int nch = (nparts + RCHUNK - 1) / RCHUNK;
         float* lvl = parts + (int64_t)nparts * n;
-        hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, st, parts, lvl,
+        if (v4) hipLaunchKernelGGL(reduce_parts_v4_kernel<true>, dim3((unsigned)((n / 4 + 255) / 256), nch), dim3(256), 0, st, parts, lvl, nparts, n / 4, 1.f);
+        else hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, st, parts, lvl,
                            nparts, n);
         E4S_CHECK_LAUNCH();
         src = lvl;
         nparts = nch;
+    }
+    if (v4) {
+        hipLaunchKernelGGL(reduce_parts_v4_kernel<false>, grid1(n / 4), dim3(256), 0, st, src, out, nparts, n / 4, scale);
+        E4S_CHECK_LAUNCH();
+        return 0;
     }
     hipLaunchKernelGGL(reduce_parts_kernel, grid1(n), dim3(256), 0, st, src, out, nparts, n, scale,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
