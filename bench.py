@@ -775,6 +775,22 @@ def main():
             img1 = swap1(*one[:5], noise=one[5])
         torch.cuda.synchronize()
         out["latency_b1_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+        if graphed is not None:
+            # the same step FED every time: 22 device-to-device copies of a fresh batch into the graph's input buffers + the replay +
+            # the uint8 pack -- what a pipeline pays whose previous stage does not write into `graphed.static` itself
+            def fed():
+                im = graphed(*inputs[:5], inputs[5])
+                return im if pack is None else (pack(im) if packed[0] is None else pack(im, out=packed[0]))
+            for _ in range(2):
+                fed()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fed()
+            torch.cuda.synchronize()
+            dtf = (time.perf_counter() - t0) / args.steps
+            out["value_with_input_copies"] = round(B / dtf, 3)
+            out["ms_per_step_with_input_copies"] = round(dtf * 1e3, 3)
         out["roofline"] = headline_probe(net, B, inputs[4], args.probe_reps)
         try:
             out.update(step_rooflines(net, inputs))

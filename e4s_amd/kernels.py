@@ -25,7 +25,7 @@ BM = 128          # GEMM row tile of e4s_conv_mfma_f32
 PRECISION = os.environ.get("E4S_PRECISION", "auto")
 if PRECISION not in ("f32", "bf16x3", "auto"):
     raise RuntimeError(f"E4S_PRECISION must be f32, bf16x3 or auto, got {PRECISION!r}")
-BF16X3_MIN_BLOCKS = 128
+BF16X3_MIN_BLOCKS = int(os.environ.get("E4S_BF16X3_MIN_BLOCKS", "128"))          # (env: policy experiments, tools/; the default is what is tested)
 LRELU_GAIN = math.sqrt(2.0)
 
 
@@ -1174,6 +1174,9 @@ def col2im_region_ok(c):
 SCATTER_DGRAD = os.environ.get("E4S_SCATTER_DGRAD", "1") != "0"
 
 
+SCATTER_DGRAD_MAX_BYTES = int(os.environ.get("E4S_SCATTER_DGRAD_MAX_BYTES", str(6 << 30)))      # 6 GiB: batch 2 of the 1024^2 generator's largest masked layer is 2.4 GB
+
+
 def scatter_dgrad_wanted(b, h, w, cy, cx):
     """Policy of the scatter-form input gradient of a masked StyledConv (x [b,h,w,cx] -> cy channels; for an up-conv h, w are the INPUT
     grid and one launch runs per output phase): a 1x1 split-bf16 contraction [b h w, cy] x [cy, 9 cx] on the gather kernel (256-row x
@@ -1181,6 +1184,8 @@ def scatter_dgrad_wanted(b, h, w, cy, cx):
     (the exact-fp32 dx + ds kernel)."""
     if not SCATTER_DGRAD or PRECISION == "f32" or cy % 32 or (9 * cx) % 128 or not col2im_region_ok(cx):
         return False
+    if 4 * b * h * w * 9 * cx * 4 > SCATTER_DGRAD_MAX_BYTES:          # the product tensor G [ncls <= 4, b, h, w, 9 cx] fp32 (a captured step's pool keeps it)
+        return False                                                    # -> the exact-fp32 dx + ds kernel, which needs no scratch
     if PRECISION == "bf16x3":
         return True
     return (b * h * w + 255) // 256 * ((9 * cx) // 128) >= BF16X3_MIN_BLOCKS

@@ -159,7 +159,8 @@ def swap_comp_style_vector(style_vectors1, style_vectors2, comp_indices, belowFa
     """scripts/face_swap.py:117-146, applied per sample so that batches work.
     style_vectors1 = target, style_vectors2 = source/driven."""
     r = style_vectors1.shape[1]
-    if style_vectors1.is_cuda and style_vectors1.dtype == torch.float32 and style_vectors2.shape == style_vectors1.shape and r > 9:
+    if (style_vectors1.is_cuda and style_vectors1.dtype == torch.float32 and style_vectors2.dtype == torch.float32
+            and style_vectors2.device == style_vectors1.device and style_vectors2.shape == style_vectors1.shape and 9 < r <= 32):
         # one native launch (the torch statement below is ~13 tiny ATen launches in the replayed graph); same results bit for bit
         return K.swap_styles(style_vectors1, style_vectors2, comp_indices, belowFace_interpolation)
     key = (style_vectors1.device, r, tuple(sorted(comp_indices)))

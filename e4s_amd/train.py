@@ -53,7 +53,7 @@ class _MseFn(torch.autograd.Function):
     def forward(ctx, a, b):
         d = a.detach() - b.detach()
         ctx.save_for_backward(d)
-        ctx.need = (a.requires_grad, b.requires_grad)
+        ctx.need = tuple(ctx.needs_input_grad[:2])
         return K.sum_all(d * d) / d.numel()
 
     @staticmethod
@@ -65,7 +65,9 @@ class _MseFn(torch.autograd.Function):
 
 def mse_loss(input, target):
     """nn.MSELoss() of coach.py:147 / F.mse_loss of scripts/optimization.py:95 on device tensors of one shape."""
-    if input.shape != target.shape or not input.is_cuda:
+    native = (input.shape == target.shape and input.is_cuda and input.device == target.device
+              and input.dtype == torch.float32 and target.dtype == torch.float32)
+    if not native:                    # other dtypes / mixed devices / broadcasting: ATen's rules (and its errors), as before the native path existed
         return F.mse_loss(input, target)
     return _MseFn.apply(input, target)
 
