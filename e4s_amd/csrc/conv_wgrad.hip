@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_kernel(const e4s_conv_wgra
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The same contraction on the bf16 matrix cores with split operands (round 6; 3x3, input stride 1, no region map): G = hi + lo and
 // X = hi + lo as bf16, three v_mfma_f32_32x32x16_bf16 per product (hi x lo, lo x hi, hi x hi; fp32 accumulate) -- the arithmetic of the
-// forward kernels.  The contraction index is the PIXEL, and the bf16 MFMA wants 8 consecutive k per lane, so the staging TRANSPOSES:
+// forward kernels (stride-2 3x3 convs too: see WB<IS> below).  The contraction index is the PIXEL, and the bf16 MFMA wants 8 consecutive k per lane, so the staging TRANSPOSES:
 // a thread owns one channel and 8 consecutive pixels of a row (8 coalesced 4-byte loads, 256 B per wave and pixel), scales by the sample's
 // s / d, splits and writes two 16-byte LDS vectors -- channel-major rows of [16 hi | 16 lo] (G) and [24 hi | 24 lo] per halo row (X).
 // A k-step is one anchor row of 16 pixels; the three column taps of a row are the same two 16-byte chunks shifted by 0 / 1 / 2 elements in
@@ -148,10 +148,22 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WB_TH = 4, WB_TW = 16, WB_HH = WB_TH + 2, WB_HW = WB_TW + 2;
-constexpr int WB_GROW = WB_TH * 64 + 16;             // bytes per co: [ay][16 hi | 16 lo] + pad (bank spread)
-constexpr int WB_XROW = WB_HH * 96 + 16;             // bytes per ci: [hy][3 chunks hi | 3 chunks lo] + pad
-constexpr int WB_SMEM = BC * (WB_GROW + WB_XROW);          // (+ 64 bytes of region labels behind it)
+// IS = 1: anchor tile 4 x 16, X halo 6 x 18 as three 8-pixel chunks per row.  IS = 2 (the stride-2 3x3 convs of encoder and Discriminator): anchor tile
+// 2 x 16, X halo 5 x 33 DE-INTERLEAVED per row into the even columns (17 -> three chunks) and the odd columns (16 -> two chunks): tap column 0 reads
+// even[a], 1 reads odd[a], 2 reads even[a + 1] -- the same aligned-chunk-plus-register-shift scheme.
+constexpr int WB_TW = 16;
+template <int IS>
+struct WB {
+    static constexpr int TH = IS == 1 ? 4 : 2;
+    static constexpr int HH = TH * IS + 2 - (IS - 1);                   // 6 | 5 halo rows
+    static constexpr int NCH = IS == 1 ? 3 : 5;                         // 8-pixel chunks per halo row (IS = 2: 3 even + 2 odd)
+    static constexpr int RB = NCH * 32;                                 // bytes per (ci, halo row): [NCH chunks hi | NCH chunks lo]
+    static constexpr int GROW = TH * 64 + 16;                           // bytes per co: [ay][16 hi | 16 lo] + pad (bank spread)
+    static constexpr int XROW = HH * RB + 16;                           // bytes per ci + pad
+    static constexpr int SMEM = BC * (GROW + XROW);                     // (+ 64 bytes of region labels behind it)
+    static constexpr int XTASKS = HH * NCH, XROUNDS = (XTASKS + 3) / 4, GTASKS = TH * 2, GROUNDS = (GTASKS + 3) / 4;
+};
+constexpr int WB_TH = WB<1>::TH;                      // (the masked form exists for IS = 1 only: 64 anchors = one ballot)
 
 __device__ __forceinline__ void split8_store(unsigned char* hi_dst, unsigned char* lo_dst, const float (&v)[8]) {
     u32x4 h, l;
@@ -179,13 +191,15 @@ __device__ __forceinline__ bf16x8 shifted(const u32x4 c0, const u32x4 c1) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <bool MASKED>
+template <bool MASKED, int IS>
 __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_bf16x3_kernel(const e4s_conv_wgrad_params p, const int nct, const int nnt, const int nsplit,
                                                                     const int tx_n, const int per_img) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned char* sG = smem_raw;                       // [64 co][WB_GROW]
-    unsigned char* sX = smem_raw + BC * WB_GROW;        // [64 ci][WB_XROW]
-    signed char* sgrp = reinterpret_cast<signed char*>(smem_raw + WB_SMEM);       // MASKED: region of the tile's 64 anchors (-1: outside)
+    using T = WB<IS>;
+    static_assert(!MASKED || IS == 1, "region maps: stride-1 layers only");
+    unsigned char* sG = smem_raw;                       // [64 co][GROW]
+    unsigned char* sX = smem_raw + BC * T::GROW;        // [64 ci][XROW]
+    signed char* sgrp = reinterpret_cast<signed char*>(smem_raw + T::SMEM);       // MASKED: region of the tile's 64 anchors (-1: outside)
     const int tid = threadIdx.x, lane0 = tid & 63, wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = lane0, wave = wave0;
     const int li = lane & 31, kh = lane >> 5;
@@ -242,12 +256,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_bf16x3_kernel(const e4s_co
             const float* gzb = p.gz + (size_t)tb * p.Ho * p.Wo * p.Cout;
             const float* xsb = p.x + (size_t)tb * p.Hi * p.Wi * p.Cin;
             const int gstep = p.ostride * p.Cout;
-            float gv[2][8];
+            float gv[T::GROUNDS][8];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < T::GROUNDS; ++r) {
                 const int j = wave + 4 * r, ay = j >> 1, half = j & 1;
-                const int ya = tyb * WB_TH + ay, xa0 = txb * WB_TW + half * 8;
-                const unsigned mj = (unsigned)(m >> (ay * 16 + half * 8)) & 0xffu;          // wave-uniform
+                const int ya = tyb * T::TH + ay, xa0 = txb * WB_TW + half * 8;
+                const unsigned mj = (unsigned)(m >> ((ay * 16 + half * 8) & 63)) & 0xffu;          // wave-uniform
                 int off = ((ya * p.ostride + p.py) * p.Wo + xa0 * p.ostride + p.px) * p.Cout + co0 + lane;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -256,52 +270,64 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_bf16x3_kernel(const e4s_co
                     off += gstep;
                 }
             }
-            // ---- X: lane = ci; the 18 (halo row, 8-pixel chunk) pairs over the waves ----
+            // ---- X: lane = ci; the (halo row, 8-pixel chunk) pairs over the waves ----
             const float sv = (p.s && ci_ok) ? p.s[(size_t)grp * p.Cin + ci0 + lane] : 1.f;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < T::GROUNDS; ++r) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gv[r][e] *= dv;
                 const int j = wave + 4 * r, ay = j >> 1, half = j & 1;
-                unsigned char* d = sG + lane * WB_GROW + ay * 64 + half * 16;
+                unsigned char* d = sG + lane * T::GROW + ay * 64 + half * 16;
                 split8_store(d, d + 32, gv[r]);
             }
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
+            for (int r = 0; r < T::XROUNDS; ++r) {
                 const int j = wave + 4 * r;                         // wave-uniform
-                if (j < WB_HH * 3) {
-                    const int hy = j / 3, ch = j - hy * 3;
-                    const int iy = tyb * WB_TH + hy - 1 + p.tap_shift, ix0 = txb * WB_TW + ch * 8 - 1 + p.tap_shift;
+                if (j < T::XTASKS) {
+                    const int hy = j / T::NCH, ch = j - hy * T::NCH;
+                    // halo pixel (hy, hx) = input (IS * tile origin + hy - 1 + tap_shift, ... + hx ...); IS = 2: chunk ch < 3 holds hx = 2 (8 ch + e),
+                    // chunk ch >= 3 holds hx = 2 (8 (ch - 3) + e) + 1
+                    const int hx0 = IS == 1 ? ch * 8 : (ch < 3 ? 16 * ch : 16 * (ch - 3) + 1);
+                    const int nvalid = IS == 1 ? 18 - ch * 8 : (ch < 3 ? 17 - ch * 8 : 8);       // chunk entries that exist
+                    const int iy = tyb * T::TH * IS + hy - 1 + p.tap_shift, ix0 = txb * WB_TW * IS + hx0 - 1 + p.tap_shift;
                     const bool row_ok = ci_ok && (unsigned)iy < (unsigned)p.Hi;
                     int off = (iy * p.Wi + ix0) * p.Cin + ci0 + lane;
                     float xv[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        xv[e] = (row_ok && ch * 8 + e < WB_HW && (unsigned)(ix0 + e) < (unsigned)p.Wi) ? xsb[off] : 0.f;
-                        off += p.Cin;
+                        xv[e] = (row_ok && e < nvalid && (unsigned)(ix0 + IS * e) < (unsigned)p.Wi) ? xsb[off] : 0.f;
+                        off += IS * p.Cin;
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) xv[e] *= sv;
-                    unsigned char* d = sX + lane * WB_XROW + hy * 96 + ch * 16;
-                    split8_store(d, d + 48, xv);
+                    unsigned char* d = sX + lane * T::XROW + hy * T::RB + ch * 16;
+                    split8_store(d, d + T::NCH * 16, xv);
                 }
             }
             __syncthreads();
             if (!wave_live) continue;
             // ---- contraction: k-step = anchor row ay (16 anchors), 9 taps x 3 MFMAs ----
-            const unsigned char* gb = sG + (wm * 32 + li) * WB_GROW + kh * 16;
-            const unsigned char* xb = sX + (wn * 32 + li) * WB_XROW + kh * 16;
+            const unsigned char* gb = sG + (wm * 32 + li) * T::GROW + kh * 16;
+            const unsigned char* xb = sX + (wn * 32 + li) * T::XROW + kh * 16;
 #pragma unroll
-            for (int ay = 0; ay < WB_TH; ++ay) {
-                if (MASKED && ((m >> (ay * 16)) & 0xffffull) == 0) continue;           // no anchor of the region in this row: G is zero (-8 % on the step's masked layers)
+            for (int ay = 0; ay < T::TH; ++ay) {
+                if (MASKED && ((m >> ((ay * 16) & 63)) & 0xffffull) == 0) continue;           // no anchor of the region in this row: G is zero (-8 % on the step's masked layers)
                 const bf16x8 Gh = *reinterpret_cast<const bf16x8*>(gb + ay * 64), Gl = *reinterpret_cast<const bf16x8*>(gb + ay * 64 + 32);
 #pragma unroll
                 for (int ty = 0; ty < 3; ++ty) {
-                    const unsigned char* xr = xb + (ay + ty) * 96;
+                    const unsigned char* xr = xb + (ay * IS + ty) * T::RB;
+                    constexpr int LO = T::NCH * 16;
                     const u32x4 h0 = *reinterpret_cast<const u32x4*>(xr), h1 = *reinterpret_cast<const u32x4*>(xr + 16);
-                    const u32x4 l0 = *reinterpret_cast<const u32x4*>(xr + 48), l1 = *reinterpret_cast<const u32x4*>(xr + 64);
-                    const bf16x8 Xh[3] = {shifted<0>(h0, h1), shifted<1>(h0, h1), shifted<2>(h0, h1)};
-                    const bf16x8 Xl[3] = {shifted<0>(l0, l1), shifted<1>(l0, l1), shifted<2>(l0, l1)};
+                    const u32x4 l0 = *reinterpret_cast<const u32x4*>(xr + LO), l1 = *reinterpret_cast<const u32x4*>(xr + LO + 16);
+                    bf16x8 Xh[3], Xl[3];
+                    if (IS == 1) {
+                        Xh[0] = shifted<0>(h0, h1), Xh[1] = shifted<1>(h0, h1), Xh[2] = shifted<2>(h0, h1);
+                        Xl[0] = shifted<0>(l0, l1), Xl[1] = shifted<1>(l0, l1), Xl[2] = shifted<2>(l0, l1);
+                    } else {                                        // even[a], odd[a], even[a + 1]
+                        const u32x4 oh = *reinterpret_cast<const u32x4*>(xr + 48), ol = *reinterpret_cast<const u32x4*>(xr + LO + 48);
+                        Xh[0] = shifted<0>(h0, h1), Xh[1] = __builtin_bit_cast(bf16x8, oh), Xh[2] = shifted<1>(h0, h1);
+                        Xl[0] = shifted<0>(l0, l1), Xl[1] = __builtin_bit_cast(bf16x8, ol), Xl[2] = shifted<1>(l0, l1);
+                    }
                     // small products first; consecutive MFMAs go to different accumulators
 #pragma unroll
                     for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Gh, Xl[tx], acc[ty * 3 + tx], 0, 0, 0);
@@ -334,7 +360,9 @@ constexpr int wg_smem() { return (WgTile<IS>::NA * BC + WgTile<IS>::NH * BC + MA
 static bool wg_bf16x3(const e4s_conv_wgrad_params& p) {            // E4S_WGRAD_BF16X3 (A/B switch): 0 = the exact-fp32 kernel everywhere, 2 = only without a region map
     static const int on = [] { const char* e = getenv("E4S_WGRAD_BF16X3"); return e ? atoi(e) : 1; }();
     static const int min_masked = [] { const char* e = getenv("E4S_WGRAD_MASKED_MIN_ANCHORS"); return e ? atoi(e) : 0; }();
-    return on && p.ntaps == 9 && p.istride == 1 && (!p.labels || (on == 1 && p.Ha * p.Wa >= min_masked));
+    if (!on || p.ntaps != 9) return false;
+    if (p.istride == 2) return !p.labels && on != 3;                        // (3: stride 1 only, the A/B switch of the stride-2 form)
+    return !p.labels || (on == 1 && p.Ha * p.Wa >= min_masked);
 }
 
 int wg_nsplit(const e4s_conv_wgrad_params& p) {
@@ -342,10 +370,12 @@ int wg_nsplit(const e4s_conv_wgrad_params& p) {
         // two blocks per CU, but at least 4 anchor tiles (K = 256) per block where the layer has them: a block's 147 KB slab (write, read by the
         // reduction) and its 36 wide stores per lane cost about what two tiles of MFMAs do
         static const int target = [] { const char* e = getenv("E4S_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
-        const int ntiles = p.B * ((p.Ha + WB_TH - 1) / WB_TH) * ((p.Wa + WB_TW - 1) / WB_TW);
+        const int th = p.istride == 2 ? WB<2>::TH : WB<1>::TH;
+        const int ntiles = p.B * ((p.Ha + th - 1) / th) * ((p.Wa + WB_TW - 1) / WB_TW);
         const int ctiles = ((p.Cout + BC - 1) / BC) * ((p.Cin + BC - 1) / BC);
         int ns = (target + ctiles - 1) / ctiles;
-        const int per_block = p.labels ? 1 : 4;               // (a masked tile is contracted once per region present in it: 2-4 passes at low resolutions)
+        // (a masked tile is contracted once per region present in it: 2-4 passes at low resolutions; a stride-2 tile holds 32 anchors, not 64)
+        const int per_block = p.labels ? 1 : p.istride == 2 ? 8 : 4;
         if (ns > (ntiles + per_block - 1) / per_block) ns = (ntiles + per_block - 1) / per_block;
         if (ns > 2048) ns = 2048;
         return ns < 1 ? 1 : ns;
@@ -373,16 +403,23 @@ int launch_wg(const e4s_conv_wgrad_params& p, hipStream_t st) {
     return 0;
 }
 
-int launch_wg_bf16x3(const e4s_conv_wgrad_params& p, hipStream_t st) {
-    auto kern = p.labels ? conv_wgrad_bf16x3_kernel<true> : conv_wgrad_bf16x3_kernel<false>;
-    static std::atomic<uint64_t> smem_set[2] = {{0}, {0}};
-    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), WB_SMEM + 64, smem_set[p.labels ? 1 : 0])) return e;
+template <bool MASKED, int IS>
+int launch_wg_bf16x3_t(const e4s_conv_wgrad_params& p, hipStream_t st) {
+    using T = WB<IS>;
+    auto kern = conv_wgrad_bf16x3_kernel<MASKED, IS>;
+    static std::atomic<uint64_t> smem_set{0};
+    if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), T::SMEM + 64, smem_set)) return e;
     const int nct = (p.Cout + BC - 1) / BC, nnt = (p.Cin + BC - 1) / BC;
-    const int tx_n = (p.Wa + WB_TW - 1) / WB_TW, per_img = ((p.Ha + WB_TH - 1) / WB_TH) * tx_n;
+    const int tx_n = (p.Wa + WB_TW - 1) / WB_TW, per_img = ((p.Ha + T::TH - 1) / T::TH) * tx_n;
     const int ns = wg_nsplit(p);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nct * nnt * ns)), dim3(NTHR), WB_SMEM + 64, st, p, nct, nnt, ns, tx_n, per_img);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nct * nnt * ns)), dim3(NTHR), T::SMEM + 64, st, p, nct, nnt, ns, tx_n, per_img);
     E4S_CHECK_LAUNCH();
     return 0;
+}
+
+int launch_wg_bf16x3(const e4s_conv_wgrad_params& p, hipStream_t st) {
+    if (p.istride == 2) return launch_wg_bf16x3_t<false, 2>(p, st);
+    return p.labels ? launch_wg_bf16x3_t<true, 1>(p, st) : launch_wg_bf16x3_t<false, 1>(p, st);
 }
 
 }  // namespace

@@ -260,9 +260,9 @@ typedef struct {
 } e4s_conv_wgrad_params;
 int e4s_conv_wgrad_f32(const e4s_conv_wgrad_params* p, void* stream);
 int64_t e4s_conv_wgrad_ws_floats(const e4s_conv_wgrad_params* p);
-/* Which kernel e4s_conv_wgrad_f32 launches (host-side policy, no launch; ABI v13): 1 = the split-bf16 kernel (3x3, istride 1, labels == NULL:
- * both operands as hi + lo bf16, three bf16 MFMAs per product, fp32 accumulate -- the forward kernels' arithmetic, 2^-17-class rounding);
- * 0 = the exact-fp32 MFMA kernel (region maps, stride 2, 1x1; everything with env E4S_WGRAD_BF16X3=0). */
+/* Which kernel e4s_conv_wgrad_f32 launches (host-side policy, no launch; ABI v13): 1 = the split-bf16 kernel (3x3; istride 1 with or without a
+ * region map, istride 2 without: both operands as hi + lo bf16, three bf16 MFMAs per product, fp32 accumulate -- the forward kernels'
+ * arithmetic, 2^-17-class rounding); 0 = the exact-fp32 MFMA kernel (1x1; everything with env E4S_WGRAD_BF16X3=0). */
 int e4s_conv_wgrad_path(const e4s_conv_wgrad_params* p);
 /* forward-packed weights [ncls][9][Cout][Cin] -> backward layout [ncls][9][Cin][Cout], taps flipped */
 int e4s_pack_taps_bwd_f32(const float* w, float* wt, int ncls, int cout, int cin, void* stream);

@@ -214,7 +214,7 @@ def test_conv_wgrad_kernel_vs_fp64(b, h, w, cin, cout, stride, ntaps):
     gz = torch.randn(y.shape, generator=g, dtype=torch.float64)
     (y * gz).sum().backward()
     dw = K.conv_wgrad(K.nchw_to_nhwc(gz.float().to(DEV)), K.nchw_to_nhwc(x.float().to(DEV)), ntaps=ntaps, istride=stride)
-    assert K.LAST_WGRAD_PATH == (1 if (ntaps == 9 and stride == 1) else 0)      # 3x3 stride 1 without a region map: the split-bf16 kernel
+    assert K.LAST_WGRAD_PATH == (1 if ntaps == 9 else 0)                        # every 3x3: the split-bf16 kernel; 1x1: exact fp32
     got = dw.permute(1, 2, 0).reshape(cout, cin, k, k)
     assert maxabs(got, wt.grad) < 2e-5 * float(wt.grad.abs().max())
     dw2 = K.conv_wgrad(K.nchw_to_nhwc(gz.float().to(DEV)), K.nchw_to_nhwc(x.float().to(DEV)), ntaps=ntaps, istride=stride)
@@ -249,6 +249,30 @@ def test_conv_wgrad_bf16x3_kernel_scales_phases_and_ragged_tiles_vs_fp64(b, h, w
     assert K.LAST_WGRAD_PATH == 1
     assert maxabs(dw, ref) < 2e-5 * float(ref.abs().max())
     assert torch.equal(dw, K.conv_wgrad(gz.float().to(DEV), x.float().to(DEV), **kw))
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,pad", [(2, 16, 32, 64, 64, 1), (1, 21, 37, 96, 160, 1), (2, 19, 35, 32, 64, 0), (2, 64, 64, 128, 128, 1), (1, 256, 256, 32, 32, 0)])
+def test_conv_wgrad_bf16x3_kernel_stride2_vs_fp64(b, h, w, cin, cout, pad):
+    """Stride-2 3x3 weight gradients (helpers.py:125-137 stride-2 units; the Discriminator's blurred padding-0 down-convs, model.py:683-689) on
+    conv_wgrad_bf16x3_kernel<false, 2>: the halo row de-interleaved into even / odd columns at staging time so that the three column taps are
+    aligned chunks (+ one register shift).  padding 1 (tap origin -1) and padding 0 (tap_shift 1), odd and ragged sizes, 32- / 96- / 160-channel
+    half tiles, per-sample s / d.  Reference: torch's fp64 conv weight gradient of the scaled operands.  <= 2e-5 of max |dW|; bit-reproducible."""
+    from e4s_amd import kernels as K
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(37)
+    x = torch.randn(b, cin, h, w, generator=g, dtype=torch.float64)
+    sm = torch.rand(b, cin, generator=g, dtype=torch.float64) + 0.5
+    dm = torch.rand(b, cout, generator=g, dtype=torch.float64) + 0.5
+    wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    y = F.conv2d(x * sm[:, :, None, None], wt, stride=2, padding=pad)
+    gz = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    (y * gz * dm[:, :, None, None]).sum().backward()
+    kw = dict(ntaps=9, istride=2, anchors=tuple(y.shape[2:]), tap_shift=1 - pad, s=sm.float().to(DEV), d=dm.float().to(DEV))
+    dw = K.conv_wgrad(K.nchw_to_nhwc(gz.float().to(DEV)), K.nchw_to_nhwc(x.float().to(DEV)), **kw)
+    assert K.LAST_WGRAD_PATH == 1
+    got = dw.permute(1, 2, 0).reshape(cout, cin, 3, 3)
+    assert maxabs(got, wt.grad) < 2e-5 * float(wt.grad.abs().max())
+    assert torch.equal(dw, K.conv_wgrad(K.nchw_to_nhwc(gz.float().to(DEV)), K.nchw_to_nhwc(x.float().to(DEV)), **kw))
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,os_,R,mapkind", [(2, 16, 32, 64, 64, 1, 12, "blocks"), (1, 13, 37, 96, 32, 1, 5, "noise"), (2, 12, 24, 64, 128, 2, 12, "blocks"),
