@@ -16,6 +16,7 @@
 The scalar glue on [B,1] logits (softplus, means, the loss sum) stays in torch: a handful of one-element launches that
 autograd differentiates as is.  Nothing here touches the control plane of the Coach (data loading, logging, checkpoints)."""
 import contextlib
+import os
 
 import torch
 import torch.nn.functional as F
@@ -123,7 +124,7 @@ class TrainIteration:
         self.bf16_storage = bf16_storage
         # calc_loss's loss networks (parsing UNet, IR-SE50, LPIPS x3) are independent chains of small launches: each on its own stream,
         # forked from and joined to the step's stream (optim.forked_sum; eager and inside a capture) -- same terms, same order of addition
-        self.fork_losses = fork_losses
+        self.fork_losses = fork_losses and os.environ.get("E4S_FORK_LOSSES", "1") != "0"        # (env: A/B switch, tools/)
         self.lo = lo or LossOpts()
         self.averager, self.averager_d, self.net_ema, self.ema_decay = averager, averager_d, net_ema, ema_decay
         # `net` may be the reference's wrapper, nn.parallel.DistributedDataParallel(net, find_unused_parameters=True,
@@ -241,7 +242,7 @@ class TrainIteration:
             if hasattr(c, "_target"):
                 c._target = None
 
-    def graphed_g_step(self, img, onehot, warmup=2, **fwd):
+    def graphed_g_step(self, img, onehot, warmup=2, fork_losses_in_graph=False, **fwd):
         """The G step (forward, every loss term incl. the target features, backward, [bucketed gradient all-reduces,] fused Adam, EMA)
         captured as ONE HIP graph: returns an optim.GraphedStep; `.step()` replays it on whatever `img` / `onehot` hold then (static
         buffers, refilled in place).  Needs FusedAdam(capturable=True).  With a ddp.GradAverager the RCCL all-reduces are captured with
@@ -264,7 +265,15 @@ class TrainIteration:
             self.forget_targets()
             if self.disc is not None:
                 disc_autograd.invalidate_packs(self.disc)
-            loss, _ = self.g_step(img, onehot, **fwd)
+            # The loss networks are NOT forked inside the capture (they are in the eager step): a replayed hipGraph with side branches is
+            # spread over several hardware queues and pays for every cross-queue edge -- measured on the batch-2 step at 1024^2, three
+            # alternations on one box: 60.6-62.6 ms forked vs 54.2-54.4 ms as one chain (DEBUG_HIP_FORCE_GRAPH_QUEUES=1 gives the forked graph
+            # the same 54.5 ms).  Same terms, same order of addition either way (optim.forked_sum's contract).
+            fork, self.fork_losses = self.fork_losses, self.fork_losses and fork_losses_in_graph
+            try:
+                loss, _ = self.g_step(img, onehot, **fwd)
+            finally:
+                self.fork_losses = fork
             return loss
         ema = [p.detach() for p in self.net_ema.parameters()] if self.net_ema is not None else []
         return GraphedStep(self.opt, body, warmup=warmup, also_written=ema)
