@@ -471,11 +471,28 @@ __global__ void region_mean_kernel(const float* __restrict__ feats, const uint8_
     const int HW = H * W;
     const float* fb = feats + (int64_t)b * HW * C + slab * 64 + cl;
     float* mine = sums + (pg * R) * 64 + cl;
-    for (int p = pg; p < HW; p += NPG) {
-        const int yy = p / W, xx = p - yy * W;
-        const int lab = labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)];
-        mine[lab * 64] += fb[(int64_t)p * C];
-        if (cl == 0) atomicAdd(&cnt[lab], 1);
+    // eight pixels in flight per thread (feature + label loads first, then the LDS sums in pixel order: the same additions in the same order; the
+    // one-load-per-dependent-add loop read the 134 MB of a 512-channel 64^2 level at 0.96 TB/s)
+    constexpr int U = 8;
+    for (int p0 = pg; p0 < HW; p0 += NPG * U) {
+        float v[U];
+        int lab[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * NPG;
+            const bool ok = p < HW;
+            const int pp = ok ? p : 0;
+            const int yy = pp / W, xx = pp - yy * W;
+            lab[u] = ok ? labels[((int64_t)b * Hm + nearest_src(yy, Hm, H)) * Wm + nearest_src(xx, Wm, W)] : -1;
+            v[u] = ok ? fb[(int64_t)pp * C] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (lab[u] >= 0) {
+                mine[lab[u] * 64] += v[u];
+                if (cl == 0) atomicAdd(&cnt[lab[u]], 1);
+            }
+        }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < R * 64; t += blockDim.x) {
