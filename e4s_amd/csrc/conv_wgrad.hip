@@ -361,6 +361,7 @@ static bool wg_bf16x3(const e4s_conv_wgrad_params& p) {            // E4S_WGRAD_
     static const int on = [] { const char* e = getenv("E4S_WGRAD_BF16X3"); return e ? atoi(e) : 1; }();
     static const int min_masked = [] { const char* e = getenv("E4S_WGRAD_MASKED_MIN_ANCHORS"); return e ? atoi(e) : 0; }();
     if (!on || p.ntaps != 9) return false;
+    if ((int64_t)p.Ho * p.Wo * p.Cout >= (1ll << 31) || (int64_t)p.Hi * p.Wi * p.Cin >= (1ll << 31)) return false;      // 32-bit element offsets per sample
     if (p.istride == 2) return !p.labels && on != 3;                        // (3: stride 1 only, the A/B switch of the stride-2 form)
     return !p.labels || (on == 1 && p.Ha * p.Wa >= min_masked);
 }
@@ -438,7 +439,6 @@ extern "C" int e4s_conv_wgrad_f32(const e4s_conv_wgrad_params* pp, void* stream)
     if ((p.Ha - 1) * p.ostride + p.py >= p.Ho || (p.Wa - 1) * p.ostride + p.px >= p.Wo) return (int)hipErrorInvalidValue;
     hipStream_t st = as_stream(stream);
     int rc;
-    if (wg_bf16x3(p) && ((int64_t)p.Ho * p.Wo * p.Cout >= (1ll << 31) || (int64_t)p.Hi * p.Wi * p.Cin >= (1ll << 31))) return (int)hipErrorInvalidValue;
     if (wg_bf16x3(p)) rc = launch_wg_bf16x3(p, st);
     else if (p.istride == 1) rc = p.ntaps == 9 ? launch_wg<1, 9>(p, st) : launch_wg<1, 1>(p, st);
     else rc = p.ntaps == 9 ? launch_wg<2, 9>(p, st) : launch_wg<2, 1>(p, st);
