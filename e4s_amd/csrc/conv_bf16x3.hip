@@ -984,6 +984,10 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(p.w);
     const size_t wrow = (size_t)p.Cin * 4;
     const int bq = (tid & 7) * 16, br0 = tid >> 3;
+    // Cout = 64 (the encoder's first stride-2 unit): ONE half-used 128-column tile -- the waves of the upper 64 columns stage and synchronise
+    // with the rest but issue no MFMAs and store nothing (this layer ran on the exact-fp32 gather path: 206 us at 16 images)
+    const int ncols = min(BN, p.Cout - n0);
+    const bool cols_live = wn * TN * 32 < ncols;
     const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     struct Pref {
@@ -994,7 +998,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
     auto fetch = [&](Pref& P, int tap, int chunk) {
         const unsigned char* wp = wbytes + ((size_t)tap * p.Cout + n0) * wrow + (size_t)chunk * 128 + bq;
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) P.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(br0 + BSTEP * j) * wrow);
+        for (int j = 0; j < BJ; ++j) P.b[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)min(br0 + BSTEP * j, ncols - 1) * wrow);       // (Cout = 64: rows past the layer repeat its last one; never stored)
         const int oy = ((ntaps == 9) ? tap / 3 - 1 : 0) + p.tap_shift, ox = ((ntaps == 9) ? tap % 3 - 1 : 0) + p.tap_shift;
         unsigned okm = 0;
 #pragma unroll
@@ -1065,6 +1069,13 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
             for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[kk][tn], acc[tm][tn], 0, 0, 0);
         };
+        if (!cols_live) {                             // (wave-uniform) staging and barriers only
+            fetch(P, more ? t1 : 0, more ? c1 : 0);
+            if (more) store(P, (s + 1) & 1);
+            __syncthreads();
+            if (++t1 == ntaps) { t1 = 0; ++c1; }
+            continue;
+        }
         ldB(0);
         ldA(0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1091,7 +1102,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
     float bsv[TN], slp[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        const int col = n0 + (wn * TN + tn) * 32 + li;
+        const int col = n0 + min((wn * TN + tn) * 32 + li, ncols - 1);
         bsv[tn] = p.bias ? p.bias[col] : 0.f;
         slp[tn] = (p.act == 2) ? p.slope[col] : p.alpha;
     }
@@ -1124,7 +1135,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) quad_transpose4(v[tn][0], v[tn][1], v[tn][2], v[tn][3], li);
                 const int off = s_out[(wm * TM + tm) * 32 + (li & 3) + 8 * g + 4 * kh];
-                if (off >= 0) {
+                if (off >= 0 && cols_live) {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
                         *reinterpret_cast<f32x4*>(p.y + (size_t)off * gycs + n0 + (wn * TN + tn) * 32 + (li & ~3)) =
@@ -1134,7 +1145,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int off = s_out[(wm * TM + tm) * 32 + i + 8 * g + 4 * kh];
-                    if (off < 0) continue;
+                    if (off < 0 || !cols_live) continue;
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) p.y[(size_t)off * gycs + n0 + (wn * TN + tn) * 32 + li] = v[tn][i];
                 }
@@ -1154,7 +1165,7 @@ __global__ __launch_bounds__(NTHR) void conv_bf16x3_gather_kernel(const e4s_conv
             }
         }
         __syncthreads();
-        if (tid < BN) {
+        if (tid < ncols) {
             double a = 0.0, q = 0.0;
 #pragma unroll
             for (int j = 0; j < NTHR / 64 / WN; ++j) { a += s_st[(j * BN + tid) * 2]; q += s_st[(j * BN + tid) * 2 + 1]; }
@@ -1171,7 +1182,7 @@ int launch_gather(const e4s_conv_params& p, hipStream_t st) {
     auto kern = conv_bf16x3_gather_kernel;
     static std::atomic<uint64_t> smem_set{0};
     if (int e = e4s_ensure_dyn_smem(reinterpret_cast<const void*>(kern), SMEM_GATHER, smem_set)) return e;
-    const int ntn = p.Cout / BN;
+    const int ntn = (p.Cout + BN - 1) / BN;               // (Cout = 64: one half-used tile)
     const int64_t npix = (int64_t)p.B * p.Ha * p.Wa;
     if (npix <= 0) return 0;
     if (npix * ntn >= (1ll << 31)) return (int)hipErrorInvalidValue;
@@ -1291,7 +1302,7 @@ extern "C" int e4s_conv_bf16x3_f32(const e4s_conv_params* pp, void* stream) {
     const e4s_conv_params& p = *pp;
     const bool up = (p.ncls == 4);
     if (p.istride == 2 || p.ntaps == 1) {      // encoder stride-2 3x3 / 1x1 shortcut convs: per-tap gather kernel
-        if (p.Cin % KC || p.Cout % BN || (p.ntaps != 9 && p.ntaps != 1) || p.ncls != 1 || p.ostride != 1 || p.tiles ||
+        if (p.Cin % KC || (p.Cout % BN && p.Cout != 64) || (p.ntaps != 9 && p.ntaps != 1) || p.ncls != 1 || p.ostride != 1 || p.tiles ||
             p.labels || p.in_scale || p.out_scale || p.in_stats || p.noise || p.Ho != p.Ha || p.Wo != p.Wa ||
             p.Hi >= 32767 || p.Wi >= 32767 || (p.Ha - 1) * p.istride >= p.Hi || (p.Wa - 1) * p.istride >= p.Wi ||
             p.tap_shift < 0 || p.tap_shift > 1 ||

@@ -63,8 +63,9 @@ def _conv_strided(x, conv, cout, stride, ntaps, want_stats=False, se=None):
     K.PRECISION asks for it and the launch has enough 256-pixel tiles, exact fp32 otherwise."""
     w = _pack3x3(conv)
     b, h, wd, _ = x.shape
-    tiles = (b * (h // stride) * (wd // stride) + 255) // 256 * (cout // 128 if cout % 128 == 0 else 0)
-    if K.PRECISION != "f32" and cout % 128 == 0 and (K.PRECISION == "bf16x3" or tiles >= K.BF16X3_MIN_BLOCKS):
+    covered = cout % 128 == 0 or cout == 64                      # (64: one half-used 128-column tile of the gather kernel)
+    tiles = (b * (h // stride) * (wd // stride) + 255) // 256 * ((cout + 127) // 128 if covered else 0)
+    if K.PRECISION != "f32" and covered and (K.PRECISION == "bf16x3" or tiles >= K.BF16X3_MIN_BLOCKS):
         if getattr(conv, "_e4s_split", None) is None or conv._e4s_split[0] != conv._e4s_pack[0]:
             conv._e4s_split = (conv._e4s_pack[0], K.split_bf16x2(w))
         return K.conv_mfma(x, w, cout, istride=stride, ntaps=ntaps, w_split=conv._e4s_split[1], want_stats=want_stats, se=se)

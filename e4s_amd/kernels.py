@@ -354,7 +354,7 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     p.act, p.alpha, p.gain = act, alpha, gain
     p.in_stats = fptr(in_stats)
     if w_split is not None:
-        gather_ok = (istride == 2 or ntaps == 1) and cin % 32 == 0 and cout % 128 == 0 and ncls == 1 and ostride == 1 \
+        gather_ok = (istride == 2 or ntaps == 1) and cin % 32 == 0 and (cout % 128 == 0 or cout == 64) and ncls == 1 and ostride == 1 \
             and plan is None and labels is None and in_scale is None and out_scale is None and noise is None \
             and in_stats is None
         if not gather_ok and (

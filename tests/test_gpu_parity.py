@@ -204,10 +204,12 @@ def test_conv_bf16x3_vs_conv2d_f64(b, h, w, cin, cout, full):
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,ntaps", [(2, 32, 32, 128, 128, 9), (1, 16, 48, 256, 256, 9), (3, 8, 8, 64, 128, 1),
-                                                   (1, 20, 12, 128, 256, 1), (2, 6, 10, 512, 512, 9)])
+                                                   (1, 20, 12, 128, 256, 1), (2, 6, 10, 512, 512, 9), (2, 64, 64, 64, 64, 9), (1, 18, 26, 64, 64, 9),
+                                                   (3, 10, 14, 32, 64, 1)])
 def test_conv_bf16x3_gather_stride2_vs_conv2d_f64(b, h, w, cin, cout, ntaps):
     """The encoder's stride-2 3x3 convs and 1x1 stride-2 shortcut convs on the per-tap gather split-bf16 kernel (ragged
-    pixel counts: tiles straddle rows and samples) against an fp64 convolution, 1e-4 of the output scale."""
+    pixel counts: tiles straddle rows and samples) against an fp64 convolution, 1e-4 of the output scale.  Cout = 64 (the first
+    stride-2 unit, helpers.py:125-137 with depth 64): one half-used 128-column tile whose upper waves issue no MFMAs and store nothing."""
     from e4s_amd import kernels as K
     g = torch.Generator().manual_seed(35)
     k = 3 if ntaps == 9 else 1
