@@ -429,14 +429,25 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
 // Split-K policy of the fp32 kernel.  It depends on ONE sample's pixel tiles and the channel count only -- never on the batch
 // or on the column tile the dispatch picks (which follows the batch) -- so a sample's result does not depend on what it is
 // batched with: maps of <= 2 pixel tiles (<= 16x16: IR-SE50's 14x14 / 7x7 layers, the generator's 4^2-16^2 layers) split
-// their input-channel chunks up to 8 ways, every split keeping >= 2 chunks.
+// their input-channel chunks up to 8 ways, every split keeping >= 2 chunks; larger maps with < 256 blocks per sample split just enough to get there.
 inline void f32_split(const e4s_conv_params& p, int64_t tiles_per_sample, int& ksplit, int& cper) {
     const int nchunk = p.Cin / KC;
     ksplit = 1;
     cper = nchunk;
-    if (tiles_per_sample > 2 || tiles_per_sample < 1 || nchunk < 4 || p.noise_per_channel || !p.splitk_ws) return;
+    if (tiles_per_sample < 1 || nchunk < 4 || p.noise_per_channel || !p.splitk_ws) return;
     int want = nchunk / 2;
     if (want > 8) want = 8;
+    if (tiles_per_sample > 2) {
+        // (plain contractions only: the styled / masked / tiled forms were never split above 2 tiles and their epilogues are not built for it)
+        if (p.labels || p.in_scale || p.out_scale || p.noise || p.tiles || p.in_stats || p.ncls != 1) return;
+        // Round 6: maps of a few dozen tiles too (the batch-1 encoder's stride-2 convs: 32 tiles x 4 column tiles = 128 blocks per sample, one
+        // block per CU, every stage an exposed gather round trip -- 125-150 us for 2.4 GFLOP): split until a SAMPLE has >= 256 blocks
+        const int64_t per_sample = tiles_per_sample * (p.Cout / 32);
+        if (per_sample >= 256) return;
+        const int need = (int)((256 + per_sample - 1) / per_sample);
+        if (want > need) want = need;
+        if (want < 2) return;
+    }
     cper = (nchunk + want - 1) / want;
     ksplit = (nchunk + cper - 1) / cper;
 }
