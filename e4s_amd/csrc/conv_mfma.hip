@@ -23,6 +23,7 @@
 // Style modulation s[g][ci] is applied to the B tile while it is staged (input-scaling form,
 // model.py:245-274); demodulation, noise, bias and leaky-ReLU live in the epilogue.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -429,14 +430,17 @@ __global__ __launch_bounds__(NTHR, 2) void conv_mfma_kernel(const e4s_conv_param
 // Split-K policy of the fp32 kernel.  It depends on ONE sample's pixel tiles and the channel count only -- never on the batch
 // or on the column tile the dispatch picks (which follows the batch) -- so a sample's result does not depend on what it is
 // batched with: maps of <= 2 pixel tiles (<= 16x16: IR-SE50's 14x14 / 7x7 layers, the generator's 4^2-16^2 layers) split
-// their input-channel chunks up to 8 ways, every split keeping >= 2 chunks; larger maps with < 256 blocks per sample split just enough to get there.
+// their input-channel chunks up to 8 ways (round 6: down to ONE 32-channel chunk per split -- these launches are a chain of exposed stage
+// latencies, 16.6 us each and 69 of them per config-3 step; five alternations on one box: 13.12 -> 12.80 ms per step); larger maps with < 256 blocks per sample split just enough to get there.
 inline void f32_split(const e4s_conv_params& p, int64_t tiles_per_sample, int& ksplit, int& cper) {
     const int nchunk = p.Cin / KC;
     ksplit = 1;
     cper = nchunk;
     if (tiles_per_sample < 1 || nchunk < 4 || p.noise_per_channel || !p.splitk_ws) return;
-    int want = nchunk / 2;
-    if (want > 8) want = 8;
+    static const int max_split = [] { const char* e = getenv("E4S_F32_MAX_SPLIT"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+    static const int min_chunks = [] { const char* e = getenv("E4S_F32_MIN_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    int want = nchunk / min_chunks;
+    if (want > max_split) want = max_split;
     if (tiles_per_sample > 2) {
         // (plain contractions only: the styled / masked / tiled forms were never split above 2 tiles and their epilogues are not built for it)
         if (p.labels || p.in_scale || p.out_scale || p.noise || p.tiles || p.in_stats || p.ncls != 1) return;
