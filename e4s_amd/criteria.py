@@ -29,9 +29,22 @@ from torch import nn
 from torch.autograd.function import once_differentiable
 from torch.nn import (BatchNorm1d, BatchNorm2d, Conv2d, Dropout, Linear, MaxPool2d, Module, PReLU, ReLU, Sequential)
 
+import functools
+
 from . import kernels as K
 from .encoders import SEModule, _conv3x3, _conv_strided, get_block
 from .packs import param_key
+
+
+def _plain_split(fn):
+    """The frozen loss networks accept e4s_conv_mfma_f32's K split on plain maps with few blocks per sample (kernels.f32_plain_split; their
+    28^2 / 56^2 layers at batch 1-2 are chains of exposed stage latencies otherwise).  Forward, feature extraction AND each backward: autograd runs
+    the backward on its own thread, where the forward's thread-local switch is not set."""
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with K.f32_plain_split():
+            return fn(*a, **k)
+    return wrapped
 
 # The reference ALWAYS loads trained weights into its loss networks (id_loss.py:15, face_parsing_loss.py:29, lpips/utils.py:11-20
 # + torchvision's pretrained AlexNet) and fails when they are missing.  Same here: a loss network without weights is an error
@@ -273,6 +286,7 @@ class _IDLossFn(torch.autograd.Function):
     """sum over scales of mean_i (1 - cos(feat_k(y_hat_i), feat_k(y_i))) with the gradient back to y_hat (NCHW)."""
 
     @staticmethod
+    @_plain_split
     def forward(ctx, y_hat, mod, y_feats):
         multi = mod.opts_multiscale
         tape = []
@@ -289,6 +303,7 @@ class _IDLossFn(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_plain_split
     def backward(ctx, gloss, _gsims):
         mod = ctx.mod
         if ctx.tape is None:
@@ -344,6 +359,7 @@ class IDLoss(Module):
             return K.adaptive_pool_bwd(dp1, in_shape)
         return K.adaptive_pool_bwd(dx112, in_shape, crop=self.CROP)
 
+    @_plain_split
     def extract_feats(self, x):
         """l2-normalised feature rows of x (NCHW), no gradient."""
         with torch.no_grad():
@@ -468,6 +484,7 @@ class _LPIPSFn(torch.autograd.Function):
     """sum over `sizes` of LPIPS(pool(x, s), pool(y, s)) with the gradient back to x (NCHW)."""
 
     @staticmethod
+    @_plain_split
     def forward(ctx, x, mod, sizes, y_feats):
         b = x.shape[0]
         tapes, feats_all = [], []
@@ -486,6 +503,7 @@ class _LPIPSFn(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_plain_split
     def backward(ctx, gout):
         mod = ctx.mod
         if ctx.tapes is None:
@@ -660,6 +678,7 @@ class unet(Module):
             dp = _conv3x3(du, _transposed(t1), cin)
             d = K.maxpool2_bwd(dp, tape[i - 1]["idx"], tuple(tape[i - 1]["f"].shape))
 
+    @_plain_split
     def extract_feats(self, inputs):
         """unet.py:69-91: l2-normalised rows of the five encoder maps (NCHW flatten order), no gradient."""
         with torch.no_grad():
@@ -670,6 +689,7 @@ class unet(Module):
 
 class _ParsingLossFn(torch.autograd.Function):
     @staticmethod
+    @_plain_split
     def forward(ctx, y_hat, mod, y_feats):
         tape = []
         x512 = mod._prep(y_hat)
@@ -683,6 +703,7 @@ class _ParsingLossFn(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_plain_split
     def backward(ctx, gloss, _gsims):
         mod = ctx.mod
         if ctx.tape is None:
@@ -718,6 +739,7 @@ class FaceParsingLoss(Module):
     def _prep(self, x):
         return K.adaptive_pool(x.detach(), (512, 512))          # NCHW -> NHWC [B,512,512,3] (identity bins at 512^2)
 
+    @_plain_split
     def extract_feats(self, x):
         with torch.no_grad():
             feats = self.G.features_nhwc(self._prep(x))

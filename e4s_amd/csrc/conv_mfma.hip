@@ -443,7 +443,12 @@ inline void f32_split(const e4s_conv_params& p, int64_t tiles_per_sample, int& k
     if (want > max_split) want = max_split;
     if (tiles_per_sample > 2) {
         // (plain contractions only: the styled / masked / tiled forms were never split above 2 tiles and their epilogues are not built for it)
-        if (p.labels || p.in_scale || p.out_scale || p.noise || p.tiles || p.in_stats || p.ncls != 1) return;
+        // OPT-IN (p.split_hint, set by the frozen loss networks; env E4S_F32_PLAIN_SPLIT=1 forces it everywhere, =0 forbids it): the re-ordered sums
+        // are as accurate as the unsplit ones (7e-7 of scale vs fp64), but through the TRAINED encoder's PReLU gates a re-ordering alone moved the
+        // worst weight-gradient tensor of the fp64 gradient test from 1.7e-3 to 3.1e-3 relative L2 (gate flips on 512-pixel maps)
+        static const int forced = [] { const char* e = getenv("E4S_F32_PLAIN_SPLIT"); return e ? atoi(e) : -1; }();
+        const bool on = forced >= 0 ? forced != 0 : p.split_hint != 0;
+        if (!on || p.labels || p.in_scale || p.out_scale || p.noise || p.tiles || p.in_stats || p.ncls != 1) return;
         // Round 6: maps of a few dozen tiles too (the batch-1 encoder's stride-2 convs: 32 tiles x 4 column tiles = 128 blocks per sample, one
         // block per CU, every stage an exposed gather round trip -- 125-150 us for 2.4 GFLOP): split until a SAMPLE has >= 256 blocks
         const int64_t per_sample = tiles_per_sample * (p.Cout / 32);

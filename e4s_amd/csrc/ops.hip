@@ -127,7 +127,7 @@ __global__ void upfirdn2d_kernel(const float* __restrict__ x, const float* __res
 
 }  // namespace
 
-extern "C" int e4s_abi_version(void) { return 13; }
+extern "C" int e4s_abi_version(void) { return 14; }
 extern "C" const char* e4s_build_arch(void) { return "gfx950"; }
 
 extern "C" int e4s_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* y, int64_t n,

@@ -286,6 +286,21 @@ def region_plan(labels, num_regions, ha, wa, nphase):
 
 
 # ---- the conv --------------------------------------------------------------------------------
+_split_tl = threading.local()
+
+
+@contextlib.contextmanager
+def f32_plain_split(on=True):
+    """Inside this context e4s_conv_mfma_f32 may split K on plain maps with < 256 blocks per sample (e4s_conv_params.split_hint): the frozen
+    loss networks opt in (criteria.py, forward AND backward -- autograd runs the backward on its own thread, so each Function sets it again)."""
+    prev = getattr(_split_tl, "on", False)
+    _split_tl.on = bool(on)
+    try:
+        yield
+    finally:
+        _split_tl.on = prev
+
+
 def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, in_scale=None, out_scale=None,
               noise=None, noise_w=None, noise_per_channel=False, bias=None, slope=None, act=0, alpha=0.2,
               gain=LRELU_GAIN, spatial=None, anchors=None, labels=None, num_regions=1, w_split=None, in_stats=None,
@@ -353,6 +368,7 @@ def conv_mfma(x, w, cout, *, plan=None, istride=1, ostride=1, ntaps=9, ncls=1, i
     p.bias, p.slope = fptr(bias), fptr(slope)
     p.act, p.alpha, p.gain = act, alpha, gain
     p.in_stats = fptr(in_stats)
+    p.split_hint = 1 if getattr(_split_tl, "on", False) else 0
     if w_split is not None:
         gather_ok = (istride == 2 or ntaps == 1) and cin % 32 == 0 and (cout % 128 == 0 or cout == 64) and ncls == 1 and ostride == 1 \
             and plan is None and labels is None and in_scale is None and out_scale is None and noise is None \

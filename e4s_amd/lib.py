@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E4S_LIB_PATH") or os.path.join(_HERE, "libe4s_hip.so")      # (E4S_LIB_PATH: A/B runs of two builds)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -45,6 +45,7 @@ class ConvParams(ctypes.Structure):
         ("noise", c_p), ("noise_w", c_p), ("noise_bstride", c_l), ("noise_per_channel", c_i),
         ("bias", c_p), ("slope", c_p), ("act", c_i), ("alpha", c_f), ("gain", c_f),
         ("in_stats", c_p), ("y_cstride", c_i), ("splitk_ws", c_p), ("stats_ws", c_p), ("stats_slots", c_i), ("tap_shift", c_i),
+        ("split_hint", c_i),
     ]
 
 

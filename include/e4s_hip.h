@@ -157,6 +157,10 @@ typedef struct {
     int stats_slots;         /* tiles per sample = slots per (b, c) */
     int tap_shift;           /* gather mode (istride 2 / ntaps 1 kernels): input coord = anchor*istride + tap - 1 + tap_shift;
                                 1 = the padding-0 stride-2 conv behind a Blur (ConvLayer, model.py:683-700) */
+    int split_hint;          /* ABI v14, e4s_conv_mfma_f32 only: 1 = the caller accepts a K split on PLAIN maps of more than 2 pixel tiles with
+                                fewer than 256 blocks per sample (the frozen loss networks' 28^2 / 56^2 layers at batch 1-2: one block per CU and
+                                every stage an exposed round trip otherwise).  Same products, another order of fp32 additions; 0 (default): such
+                                maps are never split -- trained networks keep one summation order whatever the policy of the day */
 } e4s_conv_params;
 
 /* y = epilogue( sum_{tap,ci} x[anchor*istride + tap - 1, ci] * in_scale[g,ci] * w[cls,tap,co,ci] )
@@ -169,7 +173,8 @@ int e4s_conv_mfma_f32(const e4s_conv_params* p, int spatial, void* stream);
 /* floats of p->splitk_ws this launch may use (0: none).  Maps of <= 2 pixel tiles per sample (<= 16x16: 14x14 / 7x7 layers,
  * the 4^2-16^2 generator layers) split their input-channel chunks up to 8 ways over blockIdx.y; partial sums are added in a
  * fixed order by the second stage that applies the epilogue.  The policy looks at one sample's geometry only, so results do
- * not depend on the batch.  With splitk_ws == NULL the launch never splits. */
+ * not depend on the batch.  With splitk_ws == NULL the launch never splits.  (ABI v14: p->split_hint widens the policy to plain maps
+ * with < 256 blocks per sample.) */
 int64_t e4s_conv_mfma_ws_floats(const e4s_conv_params* p, int spatial);
 
 /* Exact up-sampling StyledConv: conv_transpose2d(stride 2) + 4x4 blur (model.py:287-300) with the transposed conv's

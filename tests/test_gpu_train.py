@@ -352,7 +352,9 @@ def test_net3_full_loss_generator_step_gradients_vs_oracle_f64(train_G, storage)
     """storage="bf16" (BASELINE.json configs[4] as it names the step; e4s_amd/tape.py): the activations the forward parks for the backward
     -- encoder / generator tapes, the loss networks' and D's saved tensors -- are STORED as bf16 and widened on use; forward values are
     unchanged, the gradients carry the 2^-9 rounding of those operands: relative L2 per parameter tensor <= 1e-2 (measured 3.8e-3; fp32
-    storage 1.7e-3; printed).
+    storage 1.7e-3, bound 2e-3; printed).  (That fp32 figure is sensitive to the ORDER of fp32 additions in the trained encoder -- a K split of its batch-2
+    stride-2 convs, same products, moved the worst tensor to 3.1e-3 through PReLU gate flips on 512-pixel maps -- which is why e4s_conv_mfma_f32 splits plain
+    maps only on request: e4s_conv_params.split_hint, set by the frozen loss networks alone.)
     train_G=True is the configuration the reference trains (train_options.py:32-33 `train_G`, `train_D` default True; coach.py:324-331:
     G.convs[:K] / G.to_rgbs / G.input / conv1 / to_rgb1 trainable, the mapping network G.style and the layers past K frozen): the
     generator's weight, modulation, noise-strength and bias gradients go through the same chain and are checked like the rest.
