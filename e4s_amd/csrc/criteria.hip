@@ -314,7 +314,8 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
 // d(pixel) = sum_c w_c (fx_c/(|fx|+eps) - fy_c/(|fy|+eps))^2; one wave per pixel, <= 8 channels per lane (C <= 512).
 constexpr int LP_MAXPL = 8;
 constexpr float LP_EPS = 1e-10f;
-constexpr int LP_PIX_PER_BLOCK = 64;     // 4 waves x 16 pixels each, summed in pixel order
+constexpr int LP_PIX_PER_WAVE = 4;       // (round 6: was 16 -- a wave walks its pixels one exposed round trip after the other: 30 us per launch, 15 launches per step)
+constexpr int LP_PIX_PER_BLOCK = 4 * LP_PIX_PER_WAVE;     // 4 waves x LP_PIX_PER_WAVE pixels each, summed in pixel order
 
 __global__ void lpips_layer_kernel(const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ w,
                                    double* __restrict__ part, int HW, int C, int blocks_per_img) {
@@ -322,8 +323,8 @@ __global__ void lpips_layer_kernel(const float* __restrict__ fx, const float* __
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __shared__ double s_d[4];
     double dsum = 0.0;
-    for (int k = 0; k < 16; ++k) {
-        const int p = blk * LP_PIX_PER_BLOCK + wave * 16 + k;
+    for (int k = 0; k < LP_PIX_PER_WAVE; ++k) {
+        const int p = blk * LP_PIX_PER_BLOCK + wave * LP_PIX_PER_WAVE + k;
         if (p >= HW) break;
         const float* px = fx + ((int64_t)b * HW + p) * C;
         const float* py = fy + ((int64_t)b * HW + p) * C;
