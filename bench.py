@@ -307,8 +307,8 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
         fpl.load_state_dict(synth.synth_module_state_dict(fpl, 0, "fp."))
         lpips, idl, fpl = lpips.to(target.device).eval(), idl.to(target.device).eval(), fpl.to(target.device).eval()
 
-    # the three loss networks are independent chains of batch-1 launches: each on its own stream, forked from and joined to the step's
-    # stream inside the capture (e4s_amd.optim.forked_sum; E4S_BENCH_LOSS_STREAMS=0: one stream, for A/B runs -- same loss, same latent)
+    # the three loss networks are independent chains of batch-1 launches: forked from and joined to the step's stream inside the capture
+    # (e4s_amd.optim.forked_sum; E4S_BENCH_LOSS_STREAMS=0: one stream, for A/B runs -- same loss, same latent)
     fork = os.environ.get("E4S_BENCH_LOSS_STREAMS", "1") != "0"
     last = {}
     from e4s_amd.optim import forked_sum
@@ -327,7 +327,12 @@ def optimisation_leg(net, one, steps, losses="full", graphed=False):
             if "parsing" in terms:
                 fns.append(lambda: 0.1 * fpl(img, target)[0])
             if fork:
-                loss = forked_sum(loss, fns, inputs=(img, target))
+                # ONE side branch -- the identity network, the longest chain -- and the rest on the capturing stream under it: every side branch of
+                # a replayed hipGraph costs cross-queue edges.  Measured, two alternations on one box, ms per step: all three forked
+                # 12.87-12.90, LPIPS alone 12.35-12.39, ID alone 11.98-12.00, parsing alone 14.43, ID + LPIPS 12.60, none 14.5.
+                # (E4S_FORK_SIDE=0,1,2 restores the three branches.)  Same terms, same order of addition.
+                side = [i for i, t in enumerate(t for t in ("lpips", "id", "parsing") if t in terms) if t == "id"] or None
+                loss = forked_sum(loss, fns, inputs=(img, target), side_terms=None if os.environ.get("E4S_FORK_SIDE") else side)
             else:
                 for fn in fns:
                     loss = loss + fn()

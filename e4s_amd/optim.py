@@ -10,6 +10,8 @@ hyper-parameters and state as torch.optim.Adam (no amsgrad).
   schedule reaches a captured graph); the updates of ALL parameters go out as multi-tensor launches (e4s_adam_multi_dev_f32, 48 tensors
   per launch with their pointers in the kernel arguments): Net3's 344 tensors are 1 + 8 launches per step, not 688.
 Measured at 1024^2: 11.6 ms replayed vs 11.9 ms eager on the l2-only step, 20.4 vs ~25 ms with the LPIPS and identity terms."""
+import os
+
 import torch
 
 from . import kernels as K
@@ -243,29 +245,43 @@ class GraphedStep:
 _FORK_STREAMS = {}
 
 
-def forked_sum(base, terms, inputs=()):
+def forked_sum(base, terms, inputs=(), side_terms=None):
     """base + terms[0]() + terms[1]() + ... (added in that order), each term evaluated on ITS OWN side stream forked from the current
     one and joined before the sum.  For loss terms that are independent chains of small launches -- the LPIPS / identity / parsing
     networks of scripts/optimization.py:88-122 on one 1024^2 image: ~1 100 batch-1 launches that a single stream serialises (8.7 ms of a
     15.8 ms optimisation step; forked: 14.5 ms, same loss and same latent bit for bit after 200 replayed steps).  Works eagerly and inside
     a GraphedStep capture (the side streams fork from and join the capturing stream, so they are part of the capture; autograd runs each
     term's backward on the stream of its forward and orders the gradient hand-offs itself).
-    inputs: tensors the terms read that were produced on the current stream (recorded on the side streams for the allocator)."""
+    inputs: tensors the terms read that were produced on the current stream (recorded on the side streams for the allocator).
+    side_terms: indices of the terms that get a side stream (default: all); the others run on the current stream under them.  Inside a capture
+    fewer branches can be faster than more: a replayed hipGraph pays for every cross-queue edge (config 3: the identity network alone on a side
+    stream 12.0 ms per step, all three loss networks forked 12.9, none 14.5; the batch-2 train step is fastest as ONE chain)."""
     main = torch.cuda.current_stream()
     key = (main.device, len(terms))
     side = _FORK_STREAMS.get(key)
     if side is None:
         side = _FORK_STREAMS[key] = [torch.cuda.Stream(device=main.device) for _ in terms]
+    if side_terms is None:
+        env = os.environ.get("E4S_FORK_SIDE")                # (experiments: comma-separated indices of the terms that get a side stream)
+        side_terms = range(len(terms)) if env is None else [int(t) for t in env.split(",") if t != ""]
+    on_side = set(side_terms)
     parts = []
-    for fn, st in zip(terms, side):
+    for i, (fn, st) in enumerate(zip(terms, side)):
+        if i not in on_side:
+            parts.append(None)
+            continue
         st.wait_stream(main)
         with torch.cuda.stream(st):
             for t in inputs:
                 t.record_stream(st)
-            parts.append(fn())
+            parts[len(parts):] = [fn()]
+    for i, fn in enumerate(terms):                            # the rest on the current stream, under the side branches
+        if i not in on_side:
+            parts[i] = fn()
     out = base
-    for part, st in zip(parts, side):
-        main.wait_stream(st)
-        part.record_stream(main)
+    for i, (part, st) in enumerate(zip(parts, side)):
+        if i in on_side:
+            main.wait_stream(st)
+            part.record_stream(main)
         out = out + part
     return out
