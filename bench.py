@@ -514,9 +514,8 @@ def train_leg(dev, lat, steps=10, batch=2, losses="full", warmup=3, train_G=True
            "batch": batch, "steps": steps, "warmup": warmup,
            "images_per_s": round(batch * 1e3 / g_ms, 2), "trainable_parameters": int(sum(p.numel() for p in params)),
            "losses": losses, "ema": net_ema is not None, "train_G": bool(train_G), "train_D": disc is not None,
-           "activation_storage": "bf16" if bf16 else "fp32", "loss_networks_forked": bool(it.fork_losses), "loss_networks_forked_in_graph": False,
-           # (the eager step forks the loss networks onto side streams; the captured one does not: side branches of a replayed hipGraph are
-           # spread over hardware queues and cost 6-8 ms here)
+           "activation_storage": "bf16" if bf16 else "fp32", "loss_networks_forked": {"id": "identity network on a side stream, the rest on the step's stream (eager and captured)"}.get(it.fork_losses, str(it.fork_losses)),
+           # (ONE side branch: side branches of a replayed hipGraph are spread over hardware queues and cost more than they hide beyond the first)
            "g_step_best_ms": round(min(g_ms, g_eager_ms), 2), "g_step_best_mode": "graph" if g_ms <= g_eager_ms else "eager",
            "trainable_generator_parameters": int(sum(p.numel() for p in net.G.parameters() if p.requires_grad))}
     if disc is not None and time_d:

@@ -116,7 +116,7 @@ class TrainIteration:
     ddp.GradAverager (N > 1) or None; net_ema: EMA copy of net or None; ema_decay: coach.py:29's ACCUM by default."""
 
     def __init__(self, net, disc, crit, opt, opt_d, lo=None, averager=None, averager_d=None, net_ema=None, ema_decay=EMA_DECAY,
-                 fork_losses=True, bf16_storage=False):
+                 fork_losses="id", bf16_storage=False):
         self.net, self.disc, self.crit, self.opt, self.opt_d = net, disc, crit, opt, opt_d
         # BASELINE.json configs[4] names bf16: True stores what the forward passes park in HBM for their backward (encoder / generator tapes,
         # the loss networks' and D's saved tensors) as bf16 (e4s_amd/tape.py); arithmetic, weights, moments and gradients stay fp32.  Pair it
@@ -124,7 +124,13 @@ class TrainIteration:
         self.bf16_storage = bf16_storage
         # calc_loss's loss networks (parsing UNet, IR-SE50, LPIPS x3) are independent chains of small launches: each on its own stream,
         # forked from and joined to the step's stream (optim.forked_sum; eager and inside a capture) -- same terms, same order of addition
-        self.fork_losses = fork_losses and os.environ.get("E4S_FORK_LOSSES", "1") != "0"        # (env: A/B switch, tools/)
+        # fork_losses: "id" (default; True means the same) = ONE side stream, for the identity network, the longest chain -- the others run on the
+        # step's stream under it; "all" = every term on its own side stream; False = one chain.  Eager and captured steps use the SAME placement:
+        # autograd accumulates the terms' image gradients in an order that follows the placement, so a capture with another placement than its eager
+        # twin differs from it in the last bit (test_graphed_g_step_equals_the_eager_loop).
+        if os.environ.get("E4S_FORK_LOSSES", "1") == "0":          # (env: A/B switch, tools/)
+            fork_losses = False
+        self.fork_losses = "id" if fork_losses is True else fork_losses
         self.lo = lo or LossOpts()
         self.averager, self.averager_d, self.net_ema, self.ema_decay = averager, averager_d, net_ema, ema_decay
         # `net` may be the reference's wrapper, nn.parallel.DistributedDataParallel(net, find_unused_parameters=True,
@@ -136,13 +142,14 @@ class TrainIteration:
 
     # ---- coach.py:403-453 -------------------------------------------------------------------------------------------
     def calc_loss(self, img, recon, latent=None):
-        lo, terms, fns = self.lo, {}, []
+        lo, terms, fns, keys = self.lo, {}, [], []
 
         def term(key, weight, fn):
             def run():
                 terms[key] = fn()
                 return terms[key] * weight
             fns.append(run)
+            keys.append(key)
         if lo.face_parsing_lambda > 0 and "parsing" in self.crit:
             term("parsing", lo.face_parsing_lambda, lambda: self.crit["parsing"](recon, img)[0])
         if lo.id_lambda > 0 and "id" in self.crit:
@@ -159,7 +166,11 @@ class TrainIteration:
                  lambda: w_norm_loss(latent, self.core.latent_avg, getattr(self.core.opts, "start_from_latent_avg", True)))
         if self.fork_losses and recon.is_cuda and len(fns) > 1:
             from .optim import forked_sum
-            loss = forked_sum(0.0, fns, inputs=(recon, img))      # ((0 + parsing) + id) + l2 + lpips: coach.py:403-453's order
+            # fork_losses == "id": ONE side branch, the identity network (the longest chain), the rest on the current stream under it
+            side = [keys.index("id")] if (self.fork_losses == "id" and "id" in keys and not os.environ.get("E4S_FORK_SIDE")) else None
+            if self.fork_losses == "id" and "id" not in keys:
+                side = []                                         # no identity term: one chain
+            loss = forked_sum(0.0, fns, inputs=(recon, img), side_terms=side)      # ((0 + parsing) + id) + l2 + lpips: coach.py:403-453's order
         else:
             loss = 0.0
             for fn in fns:
@@ -242,7 +253,7 @@ class TrainIteration:
             if hasattr(c, "_target"):
                 c._target = None
 
-    def graphed_g_step(self, img, onehot, warmup=2, fork_losses_in_graph=False, **fwd):
+    def graphed_g_step(self, img, onehot, warmup=2, fork_losses_in_graph=None, **fwd):
         """The G step (forward, every loss term incl. the target features, backward, [bucketed gradient all-reduces,] fused Adam, EMA)
         captured as ONE HIP graph: returns an optim.GraphedStep; `.step()` replays it on whatever `img` / `onehot` hold then (static
         buffers, refilled in place).  Needs FusedAdam(capturable=True).  With a ddp.GradAverager the RCCL all-reduces are captured with
@@ -265,11 +276,16 @@ class TrainIteration:
             self.forget_targets()
             if self.disc is not None:
                 disc_autograd.invalidate_packs(self.disc)
-            # The loss networks are NOT forked inside the capture (they are in the eager step): a replayed hipGraph with side branches is
-            # spread over several hardware queues and pays for every cross-queue edge -- measured on the batch-2 step at 1024^2, three
-            # alternations on one box: 60.6-62.6 ms forked vs 54.2-54.4 ms as one chain (DEBUG_HIP_FORCE_GRAPH_QUEUES=1 gives the forked graph
-            # the same 54.5 ms).  Same terms, same order of addition either way (optim.forked_sum's contract).
-            fork, self.fork_losses = self.fork_losses, self.fork_losses and fork_losses_in_graph
+            # Inside the capture only ONE loss network -- the identity net, the longest chain -- gets a side stream (the eager step forks them all):
+            # a replayed hipGraph is spread over several hardware queues and pays for every cross-queue edge.  Batch-2 step at 1024^2, alternations on
+            # one box, ms: all four terms forked 60.6-62.6 (bimodal), one chain 53.5-54.4, LPIPS alone on the side 52.3-52.5, **ID alone 51.2-51.3**,
+            # parsing alone 55.2-55.6 (DEBUG_HIP_FORCE_GRAPH_QUEUES=1 gives the fully forked graph the one-chain time: the diagnosis).  Same terms, same
+            # order of addition either way (optim.forked_sum's contract).  fork_losses_in_graph: None (default: the iteration's own placement, "id")
+            # | "id" | "all" | False (one chain) -- anything but None makes the capture differ from the eager twin in the last bit.
+            in_graph = "all" if os.environ.get("E4S_G_FORK_IN_GRAPH") == "1" else fork_losses_in_graph          # (env: experiments with E4S_FORK_SIDE)
+            fork = self.fork_losses
+            if in_graph is not None and self.fork_losses:
+                self.fork_losses = in_graph
             try:
                 loss, _ = self.g_step(img, onehot, **fwd)
             finally:
